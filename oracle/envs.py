@@ -175,12 +175,16 @@ class OracleGoEnv(OracleEnv):
         lib().oracle_go_area_score(brd.ctypes.data, self.board_size, ctypes.byref(b), ctypes.byref(w))
         return b.value, w.value
 
-    def get_result_string(self):
-        # go.py:194-200 + go_engine.py:527-534
-        if self._s.last_move == -1:
-            return "B+R" if self.winner == self.black_player else "W+R"
+    def position_result(self):
+        # go_engine.py:527-534 Position.result_string
         s = lib().oracle_go_score(ctypes.byref(self._s))
         return "B+%.1f" % s if s > 0 else "W+%.1f" % abs(s) if s < 0 else "DRAW"
+
+    def get_result_string(self):
+        # go.py:194-200
+        if self._s.last_move == -1:
+            return "B+R" if self.winner == self.black_player else "W+R"
+        return self.position_result()
 
 
 class OracleGomokuEnv(OracleEnv):
