@@ -1,0 +1,65 @@
+"""ctypes view of include/azsp.h (the C ABI of libazsp.so).  Library-agnostic: `Binding` wraps any
+CDLL exporting the azsp_* symbols.  The product obtains its Binding from alpha_zero_amd._lib.load(),
+which only ever loads the HIP build and refuses to run without a GPU."""
+import ctypes as C
+
+GAME_GO, GAME_GOMOKU = 0, 1
+FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16 = 0, 1, 2, 3
+ST_NEED_ROOT, ST_SEARCH, ST_MOVE_DONE, ST_IDLE, ST_WAIT_BUF = 0, 1, 2, 3, 4
+
+SYMBOLS = [
+    "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
+    "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
+    "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral",
+]
+
+COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
+                 "nodes_created", "game_rounds", "stalls"]
+
+
+class AzspConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "game", "board_size", "num_games", "num_parallel", "num_simulations", "max_nodes", "root_noise", "deterministic",
+        "reuse_tree", "warm_up_steps", "has_resign", "check_resign_after_steps", "force_resign_disabled", "inject_random",
+        "inject_moves", "stop_after_move", "max_plies", "stop_at_game_end", "feature_dtype", "log_moves", "log_capacity",
+        "max_steps", "num_to_win", "training_steps", "rank", "device")] + [
+        ("c_puct_base", C.c_float), ("c_puct_init", C.c_float), ("disable_resign_ratio", C.c_float), ("reserved0", C.c_float),
+        ("dirichlet_eps", C.c_double), ("dirichlet_alpha", C.c_double), ("resign_threshold", C.c_double), ("komi", C.c_double),
+        ("seed", C.c_uint64)]
+
+
+class AzspGeometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_actions", "num_points", "planes", "batch_rows", "max_nodes", "budget", "table_len",
+                                         "stage_capacity")] + [("device_bytes", C.c_int64), ("node_record_bytes", C.c_int32),
+                                                               ("reserved", C.c_int32)]
+
+
+class AzspError(RuntimeError):
+    pass
+
+
+class Binding:
+    def __init__(self, cdll, name="libazsp"):
+        self.dll, self.name = cdll, name
+        missing = [s for s in SYMBOLS if not hasattr(cdll, s)]
+        if missing:
+            raise AzspError(f"{name} does not export {missing}")
+        V, I, P = C.c_void_p, C.c_int32, C.POINTER
+        sig = {
+            "azsp_create": [P(AzspConfig), P(V)], "azsp_destroy": [V], "azsp_geometry": [V, P(AzspGeometry)],
+            "azsp_set_tables": [V, V, V, V, I], "azsp_set_injection": [V, V, V, I], "azsp_reset_games": [V, V],
+            "azsp_env_step": [V, V, V, V, V, V, V], "azsp_set_state": [V, I, V, V, I, I, I, I, I, I, V],
+            "azsp_begin_move": [V, V, V], "azsp_select": [V, V, V, V], "azsp_expand_backup": [V, V, V, V],
+            "azsp_round": [V, V, V, V, V, V], "azsp_get_status": [V, V, V, V], "azsp_get_search": [V, I, I, V, V, V, V],
+            "azsp_commit_move": [V, V, V], "azsp_harvest": [V, V, V, V, I, V, I, P(I), P(I), V],
+            "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],
+        }
+        for k, a in sig.items():
+            f = getattr(cdll, k)
+            f.argtypes, f.restype = a, C.c_int
+        cdll.azsp_last_error.argtypes, cdll.azsp_last_error.restype = [V], C.c_char_p
+
+    def check(self, rc, handle=None, what=""):
+        if rc != 0:
+            msg = self.dll.azsp_last_error(handle).decode() if handle else ""
+            raise AzspError(f"{what} failed with code {rc} {msg}")

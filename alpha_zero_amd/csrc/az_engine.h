@@ -1,0 +1,1004 @@
+// az_engine.h -- batched PUCT self-play: one 64-lane wave owns one game (tree + real position).
+//
+// Restates, for thousands of concurrent games resident in HBM, the reference search and actor:
+//   alpha_zero/core/mcts_v2.py   best_child :142-185, expand :188-210, backup :213-232,
+//                                add_dirichlet_noise :235-262, generate_search_policy :265-298,
+//                                uct_search :301-450, virtual loss :453-482, parallel_uct_search :485-657
+//   alpha_zero/core/pipeline.py  play_and_record_one_game :289-382 (samples, resignation, z back-fill)
+//   alpha_zero/envs/base.py      observation :228-259
+// Data layout (per game, all in HBM):
+//   node record  = [Hdr | N f32[AP] | W f32[AP] | P f32[AP] | child i16[AP]]   (REC bytes, 128-B aligned rows)
+//                  Hdr carries the position reached by the node, so a descent is an index walk and
+//                  a child position is computed once, when the child is created (the reference
+//                  re-steps a deep-copied env from the root on every simulation: mcts_v2.py:382-402)
+//   GameRec      = real position, 8-deep board history, root statistics, per-round leaf table
+// Numerics: every floating-point expression keeps the operand precision and evaluation order of the
+// NumPy original (float32 rows, float64 noisy root priors, Python-double root statistics on a fresh
+// root), compiled with -ffp-contract=off, so visit counts match the reference exactly.
+#pragma once
+#include "az_rules.h"
+#include <math.h>
+
+#define AZ_MAXP 32        // max leaves per game per round (num_parallel)
+#define AZ_PATH_CAP 64    // max tree depth handled lane-parallel (one lane per edge)
+#define AZ_INJ_K 16       // injected sampling uniforms per move
+
+enum { AZS_NEED_ROOT = 0, AZS_SEARCH = 1, AZS_MOVE_DONE = 2, AZS_IDLE = 3, AZS_WAIT_BUF = 4 };
+enum { AZ_ERR_NODES = 1, AZ_ERR_DEPTH = 2, AZ_ERR_SAMPLE = 4, AZ_ERR_STAGE = 8 };
+enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3 };
+enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
+// statistics counters (u64 each)
+enum { AZC_SIMS = 0, AZC_NODE_VISITS, AZC_BACKUP_EDGES, AZC_LEAVES, AZC_DUP_LEAVES, AZC_TERMINAL_HITS, AZC_MOVES,
+       AZC_GAMES, AZC_ROOT_EVALS, AZC_NODES_CREATED, AZC_ROUNDS, AZC_STALLS, AZC_COUNT = 16 };
+
+struct AzCfg {
+    int game, n, G, P, sims, budget, parallel_mode, max_nodes;
+    int root_noise, deterministic, reuse_tree, warm_up_steps;
+    int has_resign, check_resign_after, force_resign_disabled;  // force: -1 draw per game, 0/1 fixed
+    int inject, inj_moves, stop_after_move, max_plies, stop_at_game_end;
+    int feat_dtype, tab_len, log_moves, log_cap, stage_cap, training_steps;
+    float one_minus_eps_f32, disable_resign_ratio;
+    double eps, alpha, resign_threshold;
+    RuleCfg rc;
+    u64 seed;
+    int rank, pad_;
+};
+
+struct AzMem {
+    unsigned char* nodes;    // [G][max_nodes][REC]
+    unsigned char* games;    // [G] GameRec
+    double* rootP;           // [G][AP]   float64 root priors (after Dirichlet noise)
+    int16_t* free_stack;     // [G][max_nodes]
+    int* leaf_path;          // [G][P][AZ_PATH_CAP]  (node << 16) | move per edge, root first
+    const double* pbc_np;    // [tab_len] pb_c for a node whose visit count is an np.float32
+    const double* pbc_py;    // [tab_len] pb_c for a fresh root whose visit count is a Python float
+    const float* sqrt32;     // [tab_len] float32(sqrt(n))
+    const double* inj_noise; // [G][inj_moves][A]
+    const double* inj_unif;  // [G][inj_moves][AZ_INJ_K]
+    u64* stg_planes;         // [G][2][stage_cap][16][W]
+    float* stg_pi;           // [G][2][stage_cap][A]
+    unsigned char* stg_meta; // [G][2][stage_cap]   1 = black to move
+    int* stg_hdr;            // [G][2][16]  see SH_*
+    // move log (tests / shim): per game per logged move
+    double* log_pi;          // [G][log_cap][A]
+    float* log_childN;       // [G][log_cap][A]
+    double* log_q;           // [G][log_cap][4]  root_q, child_q, root_N before search (unused), move
+    u64* counters;           // [AZC_COUNT]
+    int* err;                // [1]
+};
+
+enum { SH_STATE = 0, SH_LEN, SH_WINNER, SH_AREA_B, SH_AREA_W, SH_PASSES, SH_RESIGNED, SH_RESIGN_DISABLED, SH_MARKED,
+       SH_COULD_WON, SH_MARKED_PLAYER, SH_UID, SH_TRAINING_STEPS, SH_REWARD, SH_LAST_PLAYER, SH_COUNT = 16 };
+
+template <int W> struct GameRec {
+    EnvState<W> env;     // the real position (== the root node's position)
+    u64 hist[8][2][W];   // boards, newest first; hist[0] is the current board (base.py:261-266)
+    double root_W;       // DummyNode slots of the root (mcts_v2.py:56-62)
+    double out_root_q, out_child_q;
+    int root_N;
+    int root, n_free, status, root_fresh, root_noisy, ply, n_leaves, root_eval_pending;
+    int uid, num_passes, marked_player, resign_disabled, cur_buf, out_move, noise_pending, noise_ready, games_done, pad0_;
+    int16_t leaf_node[AZ_MAXP];
+    uint8_t leaf_depth[AZ_MAXP];
+};
+
+struct AzAtomic {
+#if defined(__HIPCC__)
+    static AZ_D void add(u64* p, u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd((unsigned long long*)p, (unsigned long long)v);
+#else
+        *p += v;
+#endif
+    }
+    static AZ_D int fetch_add_i32(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return atomicAdd(p, v);
+#else
+        const int o = *p;
+        *p += v;
+        return o;
+#endif
+    }
+#else
+    static inline void add(u64* p, u64 v) { *p += v; }
+    static inline int fetch_add_i32(int* p, int v) {
+        const int o = *p;
+        *p += v;
+        return o;
+    }
+#endif
+};
+
+// Philox4x32-10 counter-based generator (production randomness: one independent stream per
+// (seed, rank, game slot, game uid, ply, purpose, lane); replaces the actor's global np.random state).
+struct Philox {
+    static AZ_HD void round(u32 (&c)[4], u32 k0, u32 k1) {
+        const u64 p0 = (u64)0xD2511F53u * c[0], p1 = (u64)0xCD9E8D57u * c[2];
+        const u32 n0 = (u32)(p1 >> 32) ^ c[1] ^ k0, n1 = (u32)p1, n2 = (u32)(p0 >> 32) ^ c[3] ^ k1, n3 = (u32)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    static AZ_HD void gen(u64 key, u32 c0, u32 c1, u32 c2, u32 c3, u32 (&out)[4]) {
+        u32 c[4] = {c0, c1, c2, c3};
+        u32 k0 = (u32)key, k1 = (u32)(key >> 32);
+        for (int i = 0; i < 10; ++i) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        for (int i = 0; i < 4; ++i) out[i] = c[i];
+    }
+    static AZ_HD double u01(u32 hi, u32 lo) {  // 53-bit uniform in [0,1)
+        return (double)((((u64)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+    }
+};
+
+template <int W> struct Scratch {
+    u64 planes[16][W];
+    int path[AZ_PATH_CAP];
+};
+
+template <class Wv, int N, int GAME> struct Engine {
+    typedef Wv Wave;
+    typedef Rules<Wv, N> R;
+    typedef BBOps<N> O;
+    typedef typename O::B B;
+    static constexpr int GAME_ID = GAME;
+    static constexpr int NP = N * N;
+    static constexpr int A = NP + (GAME == AZ_GO ? 1 : 0);
+    static constexpr int W = O::W;
+    static constexpr int AP = (A + 31) / 32 * 32;
+    static constexpr int EPL = (AP + 63) / 64;
+    typedef EnvState<W> S;
+    typedef GameRec<W> GR;
+    typedef Scratch<W> SC;
+    struct Hdr {
+        S st;
+        int16_t parent, move;
+        uint8_t expanded, pad_[3];
+    };
+    static constexpr int HDR = ((int)sizeof(Hdr) + 127) / 128 * 128;
+    static constexpr int REC = (HDR + 3 * AP * 4 + AP * 2 + 127) / 128 * 128;
+    static constexpr int GREC = ((int)sizeof(GR) + 127) / 128 * 128;
+
+    const AzCfg& c;
+    const AzMem& m;
+    const int g;
+    SC& sc;
+    GR& gr;
+    u64 cnt[AZC_COUNT];
+
+    AZ_HD Engine(const AzCfg& c_, const AzMem& m_, int g_, SC& sc_)
+        : c(c_), m(m_), g(g_), sc(sc_), gr(*(GR*)(m_.games + (size_t)g_ * GREC)) {
+        for (int i = 0; i < AZC_COUNT; ++i) cnt[i] = 0;
+    }
+
+    // ---- addressing -------------------------------------------------------------------------
+    AZ_HD unsigned char* rec(int node) const { return m.nodes + ((size_t)g * c.max_nodes + node) * REC; }
+    AZ_HD Hdr& hdr(int node) const { return *(Hdr*)rec(node); }
+    AZ_HD float* rowN(int node) const { return (float*)(rec(node) + HDR); }
+    AZ_HD float* rowW(int node) const { return (float*)(rec(node) + HDR + AP * 4); }
+    AZ_HD float* rowP(int node) const { return (float*)(rec(node) + HDR + 2 * AP * 4); }
+    AZ_HD int16_t* rowC(int node) const { return (int16_t*)(rec(node) + HDR + 3 * AP * 4); }
+    AZ_HD double* rootP() const { return m.rootP + (size_t)g * AP; }
+    AZ_HD int* leaf_path(int slot) const { return m.leaf_path + ((size_t)g * c.P + slot) * AZ_PATH_CAP; }
+    AZ_HD void fail(int code) const {
+        if (Wv::first()) *m.err |= code;
+    }
+
+    AZ_HD bool action_legal(const S& s, int a) const {
+        if (a < NP) return (s.legal[a >> 6] >> (a & 63)) & 1ull;
+        return GAME == AZ_GO && !(s.flags & AZF_TERMINAL);  // go_engine.py:441 pass is always legal
+    }
+
+    // ---- node pool --------------------------------------------------------------------------
+    AZ_HD int alloc_node() {
+        if (gr.n_free <= 0) {
+            fail(AZ_ERR_NODES);
+            return 0;
+        }
+        const int idx = m.free_stack[(size_t)g * c.max_nodes + gr.n_free - 1];
+        if (Wv::first()) gr.n_free -= 1;
+        Wv::sync();
+        cnt[AZC_NODES_CREATED]++;
+        return idx;
+    }
+    AZ_HD void free_all_nodes() {
+        int16_t* fs = m.free_stack + (size_t)g * c.max_nodes;
+        const int mn = c.max_nodes;
+        for (int base = 0; base < mn; base += AZ_WAVE)
+            Wv::lanes([&](int lane) {
+                const int i = base + lane;
+                if (i < mn) {
+                    fs[i] = (int16_t)(mn - 1 - i);  // pops yield 0,1,2,...
+                    hdr(i).parent = -2;             // tag: not in use (see reroot)
+                }
+            });
+        if (Wv::first()) {
+            gr.n_free = mn;
+            gr.root = -1;
+        }
+        Wv::sync();
+    }
+
+    // ---- game lifecycle ---------------------------------------------------------------------
+    AZ_HD void stage_begin() {  // claim a staging buffer for the game that starts now
+        int* sh = m.stg_hdr + ((size_t)g * 2 + gr.cur_buf) * SH_COUNT;
+        if (Wv::first()) {
+            sh[SH_STATE] = AZB_FILLING;
+            sh[SH_LEN] = 0;
+        }
+    }
+    AZ_HD void new_game() {
+        if (Wv::first()) {
+            R::reset(gr.env, GAME);
+            if (GAME == AZ_GOMOKU) gr.env.flags = 0;
+            for (int k = 0; k < 8; ++k)
+                for (int q = 0; q < 2; ++q)
+                    for (int w = 0; w < W; ++w) gr.hist[k][q][w] = 0;
+            gr.ply = 0;
+            gr.num_passes = 0;
+            gr.marked_player = -1;
+            gr.uid = gr.games_done * c.G + g;
+            gr.n_leaves = 0;
+            gr.root_eval_pending = 0;
+            gr.noise_pending = 0;
+            int rd = 1;  // pipeline.py:244-246
+            if (c.force_resign_disabled >= 0) rd = c.force_resign_disabled;
+            else if (c.has_resign && c.resign_threshold > -1.0) {
+                u32 r[4];
+                Philox::gen(c.seed + (u64)c.rank, (u32)g, (u32)gr.uid, 0u, 0x5E51u, r);
+                rd = Philox::u01(r[0], r[1]) > (double)c.disable_resign_ratio ? 0 : 1;
+            }
+            gr.resign_disabled = rd;
+            gr.status = AZS_NEED_ROOT;
+        }
+        Wv::sync();
+        free_all_nodes();
+        stage_begin();
+        Wv::sync();
+    }
+
+    // ---- row arithmetic (operand precision of the NumPy original) ----------------------------
+    // root W: Python float while the root is fresh, np.float32 after a re-root (mcts_v2.py:439-443)
+    AZ_HD void root_add_W(double v) {
+        if (Wv::first()) {
+            if (gr.root_fresh) gr.root_W = gr.root_W + v;
+            else gr.root_W = (double)((float)gr.root_W + (float)v);
+        }
+    }
+    // Apply `delta` to W (and +1 to N when count) on every edge of a path and on the root slot.
+    // Edge d (0 = root's child) receives delta * (-1)^(depth-1-d); the root receives delta*(-1)^depth.
+    // One lane per edge: edges of one path are distinct (parent,move) slots, and the same slot is
+    // always handled by the same lane (its depth), so program order == reference order per slot.
+    AZ_HD void path_update(const int* path, int depth, float delta, bool flip, bool count) {
+        Wv::lanes([&](int lane) {
+            if (lane < depth) {
+                const int e = path[lane];
+                const int node = e >> 16, mv = e & 0xffff;
+                const float v = (flip && ((depth - 1 - lane) & 1)) ? -delta : delta;
+                float* w = rowW(node) + mv;
+                *w = *w + v;  // float32 += (mcts_v2.py:230 / :466 / :481)
+                if (count) {
+                    float* n = rowN(node) + mv;
+                    *n = *n + 1.0f;
+                }
+            }
+        });
+        root_add_W((double)((flip && (depth & 1)) ? -delta : delta));
+        if (count && Wv::first()) gr.root_N += 1;
+        if (count) cnt[AZC_BACKUP_EDGES] += (u64)depth + 1;
+        Wv::sync();
+    }
+
+    // ---- PUCT selection (mcts_v2.py:99-109, :142-185) -----------------------------------------
+    AZ_HD int puct_argmax(int node, bool at_root, int n_self) {
+        const S& s = hdr(node).st;
+        const float* rn = rowN(node);
+        const float* rw = rowW(node);
+        const float* rp = rowP(node);
+        const double* rp64 = rootP();
+        int ti = n_self < c.tab_len ? n_self : c.tab_len - 1;
+        const bool fresh = at_root && gr.root_fresh;
+        const double pbc64 = fresh ? m.pbc_py[ti] : m.pbc_np[ti];
+        const float pbc32 = (float)pbc64;
+        const float sq32 = m.sqrt32[ti];
+        const bool noisy = at_root && gr.root_noisy;
+        cnt[AZC_NODE_VISITS]++;
+        return Wv::argmax_first([&](int lane, double& best, int& bi) {
+            for (int j = 0; j < EPL; ++j) {
+                const int a = lane + 64 * j;
+                if (a >= A || !action_legal(s, a)) continue;
+                const float n = rn[a], w = rw[a];
+                const float q = w / (n > 0.0f ? n : 1.0f);
+                const float r = sq32 / (1.0f + n);
+                double sco;
+                if (noisy) {
+                    const double u = (pbc64 * rp64[a]) * (double)r;  // float64 priors at the noisy root
+                    sco = (double)(-q) + u;
+                } else {
+                    const float u = (pbc32 * rp[a]) * r;
+                    sco = (double)(-q + u);
+                }
+                if (bi < 0 || sco > best) {
+                    best = sco;
+                    bi = a;
+                }
+            }
+        });
+    }
+
+    // One descent from the root.  Returns 0 = leaf reached (unexpanded, non-terminal), 1 = terminal.
+    AZ_HD int descend(int& node_out, int& depth_out) {
+        int node = gr.root, depth = 0, n_self = gr.root_N;
+        for (;;) {
+            const int mv = puct_argmax(node, depth == 0, n_self);
+            if (depth >= AZ_PATH_CAP) {
+                fail(AZ_ERR_DEPTH);
+                node_out = node;
+                depth_out = depth;
+                return 1;
+            }
+            int child = rowC(node)[mv];
+            if (child < 0) {  // lazy child creation (mcts_v2.py:182-183); its position is computed once
+                child = alloc_node();
+                Hdr& h = hdr(child);
+                S ns;
+                R::template step<GAME>(hdr(node).st, mv, c.rc, ns);
+                if (Wv::first()) {
+                    h.st = ns;
+                    h.parent = (int16_t)node;
+                    h.move = (int16_t)mv;
+                    h.expanded = 0;
+                    rowC(node)[mv] = (int16_t)child;
+                }
+                Wv::sync();
+            }
+            if (Wv::first()) sc.path[depth] = (node << 16) | mv;
+            n_self = (int)rowN(node)[mv];
+            depth++;
+            node = child;
+            const Hdr& h = hdr(node);
+            if (h.st.flags & AZF_TERMINAL) {
+                node_out = node;
+                depth_out = depth;
+                Wv::sync();
+                return 1;
+            }
+            if (!h.expanded) {
+                node_out = node;
+                depth_out = depth;
+                Wv::sync();
+                return 0;
+            }
+        }
+    }
+
+    // ---- observation planes (base.py:228-259) -------------------------------------------------
+    // board k plies back from `leaf`: the leaf, its ancestors up to the root, then the real-game history
+    AZ_HD void gather_planes(int leaf, int depth, int me) {
+        Wv::lanes([&](int lane) {
+            for (int t = lane; t < 16 * W; t += AZ_WAVE) {
+                const int w = t % W, pc = t / W, k = pc >> 1, col = (pc & 1) ? 1 - me : me;
+                u64 v;
+                if (depth < 0) v = gr.hist[k][col][w];  // the real position: the history ring itself
+                else if (k == 0) v = hdr(leaf).st.stones[col][w];
+                else if (k <= depth) v = hdr(sc.path[depth - k] >> 16).st.stones[col][w];
+                else v = gr.hist[k - depth][col][w];
+                sc.planes[pc][w] = v;
+            }
+        });
+        Wv::sync();
+    }
+    template <class T> AZ_HD void emit_planes(T* out, T one, int me) {
+        const int total = 17 * NP;
+        const bool black = me == 0;
+        Wv::lanes([&](int lane) {
+            for (int e = lane; e < total; e += AZ_WAVE) {
+                const int pl = e / NP, p = e - pl * NP;
+                bool v = pl < 16 ? ((sc.planes[pl][p >> 6] >> (p & 63)) & 1ull) : black;
+                out[e] = v ? one : (T)0;
+            }
+        });
+    }
+    AZ_HD void write_features(void* feat, int slot, int me) {
+        const size_t row = ((size_t)g * c.P + slot) * (size_t)(17 * NP);
+        switch (c.feat_dtype) {
+            case AZ_FEAT_I8: emit_planes<int8_t>((int8_t*)feat + row, (int8_t)1, me); break;
+            case AZ_FEAT_F32: emit_planes<u32>((u32*)feat + row, 0x3F800000u, me); break;
+            case AZ_FEAT_BF16: emit_planes<uint16_t>((uint16_t*)feat + row, (uint16_t)0x3F80u, me); break;
+            default: emit_planes<uint16_t>((uint16_t*)feat + row, (uint16_t)0x3C00u, me); break;
+        }
+    }
+
+    // ---- select phase -------------------------------------------------------------------------
+    AZ_HD void select(void* feat, unsigned char* valid) {
+        unsigned char* vrow = valid + (size_t)g * c.P;
+        if (gr.status == AZS_NEED_ROOT) {
+            // mcts_v2.py:364-368: the root position itself is evaluated first
+            if (gr.root < 0) {
+                const int r = alloc_node();
+                if (Wv::first()) {
+                    Hdr& h = hdr(r);
+                    h.st = gr.env;
+                    h.parent = -1;
+                    h.move = -1;
+                    h.expanded = 0;
+                    gr.root = r;
+                }
+                Wv::sync();
+            }
+            gather_planes(gr.root, 0, gr.env.to_play);
+            write_features(feat, 0, gr.env.to_play);
+            Wv::lanes([&](int lane) {
+                if (lane < c.P) vrow[lane] = lane == 0 ? 1 : 0;
+            });
+            if (Wv::first()) {
+                gr.root_eval_pending = 1;
+                gr.n_leaves = 0;
+            }
+            cnt[AZC_ROOT_EVALS]++;
+            Wv::sync();
+            return;
+        }
+        int nleaf = 0;
+        if (gr.status == AZS_SEARCH && !gr.noise_pending) {
+            int attempts = 0;
+            // mcts_v2.py:572: up to P leaves in at most 2P attempts, one after another (each descent
+            // sees the virtual losses of the previous ones); uct_search (:378-418) is the P == 1 case
+            const int max_att = c.parallel_mode ? 2 * c.P : 1;
+            while (nleaf < c.P && attempts < max_att) {
+                attempts++;
+                int node, depth;
+                const int term = descend(node, depth);
+                cnt[AZC_SIMS]++;
+                if (term) {
+                    // mcts_v2.py:407-411 / :604-608: back up -reward, node stays unexpanded
+                    cnt[AZC_TERMINAL_HITS]++;
+                    path_update(sc.path, depth, (float)(-(int)hdr(node).st.reward), true, true);
+                    if (!c.parallel_mode && gr.root_N < c.budget) attempts = 0;  // uct_search keeps looping (:378)
+                    if (!c.parallel_mode && gr.root_N >= c.budget) break;
+                    continue;
+                }
+                if (c.parallel_mode) path_update(sc.path, depth, 1.0f, false, false);  // add_virtual_loss :453-467
+                int* lp = leaf_path(nleaf);
+                Wv::lanes([&](int lane) {
+                    if (lane < depth) lp[lane] = sc.path[lane];
+                });
+                if (Wv::first()) {
+                    gr.leaf_node[nleaf] = (int16_t)node;
+                    gr.leaf_depth[nleaf] = (uint8_t)depth;
+                }
+                const int me = hdr(node).st.to_play;
+                gather_planes(node, depth, me);
+                write_features(feat, nleaf, me);
+                nleaf++;
+                cnt[AZC_LEAVES]++;
+            }
+        }
+        Wv::lanes([&](int lane) {
+            if (lane < c.P) vrow[lane] = lane < nleaf ? 1 : 0;
+        });
+        if (Wv::first()) gr.n_leaves = nleaf;
+        Wv::sync();
+    }
+
+    // ---- expand + backup phase (mcts_v2.py:188-232, :616-625) -----------------------------------
+    AZ_HD void expand_node(int node, const float* prior) {
+        float* rn = rowN(node);
+        float* rw = rowW(node);
+        float* rp = rowP(node);
+        int16_t* rc = rowC(node);
+        Wv::lanes([&](int lane) {
+            for (int a = lane; a < AP; a += AZ_WAVE) {
+                rp[a] = a < A ? prior[a] : 0.0f;  // stored unmasked, not renormalised (:209)
+                rn[a] = 0.0f;
+                rw[a] = 0.0f;
+                rc[a] = -1;
+            }
+        });
+        if (Wv::first()) hdr(node).expanded = 1;
+        Wv::sync();
+    }
+    AZ_HD void apply_outputs(const float* priors, const float* values) {
+        const size_t row0 = (size_t)g * c.P;
+        if (gr.root_eval_pending) {
+            expand_node(gr.root, priors + row0 * A);
+            if (Wv::first()) {
+                gr.root_N = 1;  // backup(root, value) on DummyNode slots: 0.0 + 1, 0.0 + value
+                gr.root_W = (double)values[row0];
+                gr.root_fresh = 1;
+                gr.root_noisy = 0;
+                gr.root_eval_pending = 0;
+                gr.status = AZS_SEARCH;
+                gr.noise_pending = c.root_noise;
+            }
+            Wv::sync();
+            return;
+        }
+        const int nl = gr.n_leaves;
+        for (int s = 0; s < nl; ++s) {
+            const int node = gr.leaf_node[s], depth = gr.leaf_depth[s];
+            const int* lp = leaf_path(s);
+            if (c.parallel_mode) path_update(lp, depth, -1.0f, false, false);  // revert_virtual_loss :470-482
+            if (hdr(node).expanded) {  // picked twice in one round: evaluation wasted (:621-622)
+                cnt[AZC_DUP_LEAVES]++;
+                continue;
+            }
+            expand_node(node, priors + (row0 + s) * A);
+            path_update(lp, depth, values[row0 + s], true, true);
+        }
+        if (Wv::first()) gr.n_leaves = 0;
+        Wv::sync();
+    }
+
+    // ---- Dirichlet noise at the root (mcts_v2.py:235-262) ---------------------------------------
+    AZ_HD double gamma_sample(double alpha, u64 key, u32 c0, u32 c1, u32 c2) {
+        // Marsaglia-Tsang for alpha+1, boosted by U^(1/alpha) (alpha < 1)
+        const double d = alpha + 1.0 - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * d);
+        for (u32 it = 0;; ++it) {
+            u32 r[4], q[4];
+            Philox::gen(key, c0, c1, c2, 2u * it, r);
+            Philox::gen(key, c0, c1, c2, 2u * it + 1u, q);
+            const double u1 = Philox::u01(r[0], r[1]) + 1.0 / 18014398509481984.0, u2 = Philox::u01(r[2], r[3]);
+            const double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+            const double v0 = 1.0 + cc * x;
+            if (v0 <= 0.0) continue;
+            const double v = v0 * v0 * v0, u = Philox::u01(q[0], q[1]) + 1.0 / 18014398509481984.0;
+            if (log(u) < 0.5 * x * x + d - d * v + d * log(v) || it > 64) {
+                const double ub = Philox::u01(q[2], q[3]) + 1.0 / 18014398509481984.0;
+                return d * v * exp(log(ub) / alpha);
+            }
+        }
+    }
+    AZ_HD void apply_noise() {
+        const int root = gr.root;
+        const S& s = hdr(root).st;
+        const float* rp = rowP(root);
+        double* rp64 = rootP();
+        const double* inj = c.inject ? m.inj_noise + ((size_t)g * c.inj_moves + (gr.ply < c.inj_moves ? gr.ply : c.inj_moves - 1)) * A : nullptr;
+        double total = 1.0;
+        if (!c.inject) {
+            // Dirichlet(alpha) over ALL actions = normalised Gamma(alpha) draws (:259-260)
+            const u64 key = c.seed + (u64)c.rank;
+            double part = 0.0;
+            Wv::lanes([&](int lane) {
+                for (int a = lane; a < A; a += AZ_WAVE) rp64[a] = gamma_sample(c.alpha, key, (u32)g, (u32)gr.uid, ((u32)gr.ply << 12) | (u32)a);
+            });
+            Wv::sync();
+            for (int a = 0; a < A; ++a) part += rp64[a];
+            total = part > 0.0 ? part : 1.0;
+        }
+        Wv::lanes([&](int lane) {
+            for (int a = lane; a < AP; a += AZ_WAVE) {
+                double v = 0.0;
+                if (a < A) {
+                    const double nz = c.inject ? inj[a] : rp64[a] / total;
+                    // child_P * (1 - eps) stays float32, noise * eps is float64, the sum is float64 (:262)
+                    v = (double)(rp[a] * c.one_minus_eps_f32) + (action_legal(s, a) ? nz : 0.0) * c.eps;
+                }
+                rp64[a] = v;
+            }
+        });
+        if (Wv::first()) {
+            gr.root_noisy = 1;
+            gr.noise_pending = 0;
+        }
+        Wv::sync();
+    }
+
+    // ---- end of a search: policy, move, sample, env step, re-root ---------------------------------
+    static AZ_HD float pairwise_sum_f32(const float* a, int n) {
+        // numpy's float32 add.reduce order (pairwise, 8 accumulators, blocks of 128), so that the
+        // Gomoku policy (float32 in the reference) sums in the same order
+        if (n < 8) {
+            float r = 0.0f;
+            for (int i = 0; i < n; ++i) r = r + a[i];
+            return r;
+        }
+        if (n <= 128) {
+            float r[8];
+            for (int j = 0; j < 8; ++j) r[j] = a[j];
+            int i = 8;
+            for (; i < n - (n % 8); i += 8)
+                for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+            float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; i < n; ++i) res = res + a[i];
+            return res;
+        }
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
+    }
+
+    // generate_search_policy (mcts_v2.py:265-298) into pi64[A] (scratch = rootP row is free to reuse
+    // only AFTER the search, so the policy is written to the move log / staging directly).
+    AZ_HD void search_policy(bool warm, double* pi64) {
+        const S& s = hdr(gr.root).st;
+        const float* rn = rowN(gr.root);
+        if (GAME == AZ_GO) {
+            // legal(int64) * child_N(float32) -> float64; n**5 and the sum are exact integers in float64
+            Wv::lanes([&](int lane) {
+                for (int a = lane; a < A; a += AZ_WAVE) {
+                    double x = action_legal(s, a) ? (double)rn[a] : 0.0;
+                    if (!warm) {
+                        const double x2 = x * x;
+                        x = x2 * x2 * x;
+                    }
+                    pi64[a] = x;
+                }
+            });
+            Wv::sync();
+            double sum = 0.0;
+            for (int a = 0; a < A; ++a) sum += pi64[a];
+            if (sum > 0.0) {
+                Wv::lanes([&](int lane) {
+                    for (int a = lane; a < A; a += AZ_WAVE) pi64[a] = pi64[a] / sum;
+                });
+            }
+        } else {
+            // legal(int8) * child_N(float32) stays float32 (Gomoku)
+            float* tmp = (float*)pi64;  // A floats fit in the first half of the A doubles
+            Wv::lanes([&](int lane) {
+                for (int a = lane; a < A; a += AZ_WAVE) {
+                    float x = action_legal(s, a) ? rn[a] : 0.0f;
+                    if (!warm) {
+                        const double d = (double)x, d2 = d * d;
+                        x = (float)(d2 * d2 * d);
+                    }
+                    tmp[a] = x;
+                }
+            });
+            Wv::sync();
+            const float sum = pairwise_sum_f32(tmp, A);
+            // widen in place from the top so no element is overwritten before it is read
+            if (Wv::first())
+                for (int a = A - 1; a >= 0; --a) {
+                    const float x = tmp[a];
+                    pi64[a] = (double)(sum > 0.0f ? x / sum : x);
+                }
+        }
+        Wv::sync();
+    }
+
+    // np.random.choice(p=pi): cdf = cumsum(p) (sequential, float64), cdf /= cdf[-1], first i with cdf[i] > u
+    AZ_HD int sample_move(const double* pi64, bool warm) {
+        const S& s = hdr(gr.root).st;
+        double tot = 0.0;
+        for (int a = 0; a < A; ++a) tot += pi64[a];
+        const double* inj = c.inject ? m.inj_unif + ((size_t)g * c.inj_moves + (gr.ply < c.inj_moves ? gr.ply : c.inj_moves - 1)) * AZ_INJ_K : nullptr;
+        int mv = -1;
+        for (int t = 0; t < 64; ++t) {
+            double u;
+            if (c.inject) u = inj[t < AZ_INJ_K ? t : AZ_INJ_K - 1];
+            else {
+                u32 r[4];
+                Philox::gen(c.seed + (u64)c.rank, (u32)g, (u32)gr.uid, ((u32)gr.ply << 12) | 0xFFFu, 0x1000u + (u32)t, r);
+                u = Philox::u01(r[0], r[1]);
+            }
+            double acc = 0.0;
+            mv = A - 1;
+            for (int a = 0; a < A; ++a) {
+                acc += pi64[a];
+                if (acc / tot > u) {
+                    mv = a;
+                    break;
+                }
+            }
+            // mcts_v2.py:433 / :640: redraw while pass during warm-up, or illegal
+            const bool bad = (warm && GAME == AZ_GO && mv == NP) || !action_legal(s, mv);
+            if (!bad) return mv;
+        }
+        // the reference would loop forever here; fall back to the most visited legal point
+        fail(AZ_ERR_SAMPLE);
+        return mv;
+    }
+
+    AZ_HD void record_sample(const double* pi64) {
+        int* sh = m.stg_hdr + ((size_t)g * 2 + gr.cur_buf) * SH_COUNT;
+        const int k = sh[SH_LEN];
+        if (k >= c.stage_cap) {
+            fail(AZ_ERR_STAGE);
+            return;
+        }
+        const size_t idx = ((size_t)g * 2 + gr.cur_buf) * c.stage_cap + k;
+        u64* pl = m.stg_planes + idx * 16 * W;
+        float* pi = m.stg_pi + idx * A;
+        const int me = gr.env.to_play;
+        // observation BEFORE the move, mover's perspective (pipeline.py:323): the history ring itself
+        Wv::lanes([&](int lane) {
+            for (int t = lane; t < 16 * W; t += AZ_WAVE) {
+                const int w = t % W, pc = t / W, kk = pc >> 1, col = (pc & 1) ? 1 - me : me;
+                pl[t] = gr.hist[kk][col][w];
+            }
+            for (int a = lane; a < A; a += AZ_WAVE) pi[a] = (float)pi64[a];
+        });
+        if (Wv::first()) {
+            m.stg_meta[idx] = me == 0 ? 1 : 0;
+            sh[SH_LEN] = k + 1;
+        }
+        Wv::sync();
+    }
+
+    AZ_HD void push_history(const S& s) {
+        if (Wv::first()) {
+            for (int k = 7; k > 0; --k)
+                for (int q = 0; q < 2; ++q)
+                    for (int w = 0; w < W; ++w) gr.hist[k][q][w] = gr.hist[k - 1][q][w];
+            for (int q = 0; q < 2; ++q)
+                for (int w = 0; w < W; ++w) gr.hist[0][q][w] = s.stones[q][w];
+        }
+        Wv::sync();
+    }
+
+    // Keep the subtree below `child`, return every other node to the free stack (mcts_v2.py:436-446).
+    AZ_HD void reroot(int child, int mv) {
+        const int old_root = gr.root;
+        const float cn = rowN(old_root)[mv], cw = rowW(old_root)[mv];
+        int16_t* fs = m.free_stack + (size_t)g * c.max_nodes;
+        const int mn = c.max_nodes;
+        // nodes currently in use = everything not on the free stack; mark them via a scratch pass:
+        // a node is kept iff walking up its parents reaches `child` before reaching the old root.
+        int nfree = gr.n_free;
+        // 1) collect "in use" flags: build a bitmap in LDS-free fashion by testing membership lazily:
+        //    free-stack entries are exactly the unused nodes, so first invalidate them.
+        //    We re-create the stack from scratch: [previously free nodes] + [newly dropped nodes].
+        // parents of free nodes are garbage, so tag free nodes by parent = -2 when they are released.
+        for (int base = 0; base < mn; base += AZ_WAVE) {
+            const u64 drop = Wv::ballot([&](int lane) -> bool {
+                const int i = base + lane;
+                if (i >= mn) return false;
+                int p = hdr(i).parent;
+                if (p == -2) return false;  // already free
+                int cur = i;
+                for (int hops = 0; hops < mn; ++hops) {
+                    if (cur == child) return false;  // kept
+                    if (cur == old_root || p < 0) return true;
+                    cur = p;
+                    p = hdr(cur).parent;
+                }
+                return true;
+            });
+            Wv::lanes([&](int lane) {
+                if ((drop >> lane) & 1ull) {
+                    const int pos = nfree + __builtin_popcountll(drop & ((1ull << lane) - 1ull));
+                    fs[pos] = (int16_t)(base + lane);
+                }
+            });
+            Wv::sync();
+            // tag after the whole chunk was classified (walks of later chunks stop at p < 0 / -2 anyway)
+            Wv::lanes([&](int lane) {
+                if ((drop >> lane) & 1ull) hdr(base + lane).parent = -2;
+            });
+            nfree += __builtin_popcountll(drop);
+            Wv::sync();
+        }
+        if (Wv::first()) {
+            gr.n_free = nfree;
+            gr.root = child;
+            hdr(child).parent = -1;
+            gr.root_N = (int)cn;  // np.float32 copies of the child's slot (mcts_v2.py:439-443)
+            gr.root_W = (double)cw;
+            gr.root_fresh = 0;
+            gr.root_noisy = 0;
+            gr.noise_pending = c.root_noise;
+        }
+        Wv::sync();
+    }
+
+    AZ_HD void finalize_game(const S& fin, int last_player, int resigned) {
+        int* sh = m.stg_hdr + ((size_t)g * 2 + gr.cur_buf) * SH_COUNT;
+        if (Wv::first()) {
+            sh[SH_WINNER] = fin.winner;
+            sh[SH_AREA_B] = fin.area[0];
+            sh[SH_AREA_W] = fin.area[1];
+            sh[SH_PASSES] = gr.num_passes;
+            sh[SH_RESIGNED] = resigned;
+            sh[SH_RESIGN_DISABLED] = gr.resign_disabled;
+            // pipeline.py:361-365
+            const int marked = (c.has_resign && gr.resign_disabled && gr.marked_player >= 0) ? 1 : 0;
+            sh[SH_MARKED] = marked;
+            sh[SH_COULD_WON] = (marked && fin.winner == gr.marked_player) ? 1 : 0;
+            sh[SH_MARKED_PLAYER] = gr.marked_player;
+            sh[SH_UID] = gr.uid;
+            sh[SH_TRAINING_STEPS] = c.training_steps;
+            sh[SH_REWARD] = fin.reward;  // reward of `last_player` (pipeline.py:349-354 turns it into z at harvest)
+            sh[SH_LAST_PLAYER] = last_player;
+            sh[SH_STATE] = AZB_COMPLETE;
+            gr.games_done += 1;
+        }
+        cnt[AZC_GAMES]++;
+        Wv::sync();
+    }
+
+    // Try to start the next game in the other staging buffer; stall (AZS_WAIT_BUF) until the host harvested it.
+    AZ_HD void next_game() {
+        if (c.stop_at_game_end) {
+            if (Wv::first()) gr.status = AZS_IDLE;
+            Wv::sync();
+            return;
+        }
+        const int other = 1 - gr.cur_buf;
+        const int* sh = m.stg_hdr + ((size_t)g * 2 + other) * SH_COUNT;
+        if (sh[SH_STATE] != AZB_FREE) {
+            if (Wv::first()) gr.status = AZS_WAIT_BUF;
+            cnt[AZC_STALLS]++;
+            Wv::sync();
+            return;
+        }
+        if (Wv::first()) gr.cur_buf = other;
+        Wv::sync();
+        new_game();
+    }
+
+    // ---- end of a search (mcts_v2.py:421-450) ----------------------------------------------------
+    AZ_HD double root_q() const {
+        if (gr.root_N <= 0) return 0.0;
+        return gr.root_fresh ? gr.root_W / (double)gr.root_N : (double)((float)gr.root_W / (float)gr.root_N);
+    }
+    AZ_HD int log_slot() const { return c.log_moves ? (gr.ply < c.log_cap ? gr.ply : c.log_cap - 1) : 0; }
+    AZ_HD double* pi_slot() const { return m.log_pi + ((size_t)g * c.log_cap + log_slot()) * A; }
+
+    // Policy + (batched mode) move choice.  In drop-in mode (stop_after_move) the caller samples the
+    // move itself from the published pi, exactly like mcts_v2.py:433-434 does with np.random.choice.
+    AZ_HD void search_done() {
+        const bool warm = !(gr.env.steps > c.warm_up_steps);  // pipeline.py:320
+        double* pi64 = pi_slot();
+        search_policy(warm, pi64);
+        const float* rn = rowN(gr.root);
+        if (c.log_moves || c.stop_after_move) {
+            float* ln = m.log_childN + ((size_t)g * c.log_cap + log_slot()) * A;
+            Wv::lanes([&](int lane) {
+                for (int a = lane; a < A; a += AZ_WAVE) ln[a] = rn[a];
+            });
+        }
+        if (c.stop_after_move) {
+            if (Wv::first()) {
+                gr.out_root_q = root_q();
+                gr.status = AZS_MOVE_DONE;
+            }
+            Wv::sync();
+            return;
+        }
+        int mv;
+        if (c.deterministic) {
+            mv = Wv::argmax_first([&](int lane, double& best, int& bi) {  // np.argmax(child_N), unmasked (:429)
+                for (int a = lane; a < A; a += AZ_WAVE)
+                    if (bi < 0 || (double)rn[a] > best) {
+                        best = (double)rn[a];
+                        bi = a;
+                    }
+            });
+        } else {
+            mv = sample_move(pi64, warm);
+        }
+        commit_actor(mv, pi64);
+    }
+
+    // best_child_Q = -Q(chosen child) in float32 (:446); 0.0 when the move has no child node (:425)
+    AZ_HD double child_q_of(int mv, int& child) const {
+        child = (mv >= 0 && mv < A) ? rowC(gr.root)[mv] : -1;
+        if (child < 0) return 0.0;
+        const float cn = rowN(gr.root)[mv], cw = rowW(gr.root)[mv];
+        return cn > 0.0f ? (double)(-(cw / cn)) : -0.0;
+    }
+    AZ_HD void log_outputs(int mv, double rq, double cq) {
+        if (Wv::first()) {
+            gr.out_move = mv;
+            gr.out_root_q = rq;
+            gr.out_child_q = cq;
+            if (c.log_moves && gr.ply < c.log_cap) {
+                double* lq = m.log_q + ((size_t)g * c.log_cap + gr.ply) * 4;
+                lq[0] = rq;
+                lq[1] = cq;
+                lq[2] = (double)gr.root_N;
+                lq[3] = (double)mv;
+            }
+        }
+        cnt[AZC_MOVES]++;
+        Wv::sync();
+    }
+
+    // Drop-in uct_search: the caller steps its own env; only the tree advances (mcts_v2.py:436-446).
+    AZ_HD void commit_host(int mv) {
+        if (gr.status != AZS_MOVE_DONE) return;
+        int child;
+        const double cq = child_q_of(mv, child);
+        log_outputs(mv, root_q(), cq);
+        if (child >= 0 && c.reuse_tree && !(hdr(child).st.flags & AZF_TERMINAL)) {
+            const S ns = hdr(child).st;
+            if (Wv::first()) {
+                gr.env = ns;
+                gr.ply += 1;
+            }
+            Wv::sync();
+            push_history(ns);
+            reroot(child, mv);
+            if (Wv::first()) gr.status = AZS_SEARCH;
+        } else {
+            free_all_nodes();
+            if (Wv::first()) gr.status = AZS_IDLE;
+        }
+        if (Wv::first()) gr.noise_ready = 0;
+        Wv::sync();
+    }
+
+    // Batched actor step (pipeline.py:323-346): sample, resignation rule, env step, re-root / game end.
+    AZ_HD void commit_actor(int mv, const double* pi64) {
+        int child;
+        const double rq = root_q();
+        const double cq = child_q_of(mv, child);
+        log_outputs(mv, rq, cq);
+        if (child < 0) {  // cannot happen: a sampled / most-visited move always has a visited child
+            fail(AZ_ERR_SAMPLE);
+            if (Wv::first()) gr.status = AZS_IDLE;
+            Wv::sync();
+            return;
+        }
+        record_sample(pi64);
+        const int mover = gr.env.to_play;
+        bool resign = false;
+        if (GAME == AZ_GO && c.has_resign && gr.env.steps > c.check_resign_after) {
+            // root_Q is a Python float on a fresh root, np.float32 otherwise; best_child_Q is np.float32
+            const bool lo_root = gr.root_fresh ? (rq < c.resign_threshold) : ((float)rq < (float)c.resign_threshold);
+            const bool lo_child = (float)cq < (float)c.resign_threshold;
+            if (lo_root && lo_child) {
+                if (gr.marked_player < 0 && Wv::first()) gr.marked_player = mover;
+                Wv::sync();
+                if (!gr.resign_disabled) resign = true;
+            }
+        }
+        S ns;
+        if (resign) R::go_resign(gr.env, ns);
+        else ns = hdr(child).st;
+        if (Wv::first()) {
+            if (GAME == AZ_GO && !resign && mv == NP) gr.num_passes += 1;
+            gr.env = ns;
+            gr.ply += 1;
+        }
+        Wv::sync();
+        push_history(ns);
+        if (ns.flags & AZF_TERMINAL) {
+            finalize_game(ns, mover, resign ? 1 : 0);
+            next_game();
+            return;
+        }
+        if (c.max_plies > 0 && gr.ply >= c.max_plies) {
+            if (Wv::first()) gr.status = AZS_IDLE;
+            Wv::sync();
+            return;
+        }
+        if (c.reuse_tree) {
+            reroot(child, mv);
+        } else {
+            free_all_nodes();
+            if (Wv::first()) gr.status = AZS_NEED_ROOT;
+            Wv::sync();
+        }
+    }
+
+    // ---- one engine round for this game ---------------------------------------------------------
+    AZ_HD void flush_counters() {
+        if (Wv::first())
+            for (int i = 0; i < AZC_COUNT; ++i)
+                if (cnt[i]) AzAtomic::add(m.counters + i, cnt[i]);
+    }
+    // phase A+B: consume the evaluator's outputs, finish as many moves as the budget allows
+    AZ_HD void advance(const float* priors, const float* values) {
+        if (gr.status == AZS_WAIT_BUF) next_game();
+        if (gr.root_eval_pending || gr.n_leaves > 0) apply_outputs(priors, values);
+        for (int guard = 0; guard < 8; ++guard) {
+            if (gr.status != AZS_SEARCH) break;
+            if (gr.noise_pending && (!c.stop_after_move || gr.noise_ready)) apply_noise();
+            if (gr.noise_pending) break;  // drop-in mode: the noise vector arrives with begin_move
+            if (gr.root_N < c.budget) break;
+            search_done();
+        }
+    }
+    AZ_HD void round(const float* priors, const float* values, void* feat, unsigned char* valid) {
+        advance(priors, values);
+        select(feat, valid);
+        cnt[AZC_ROUNDS]++;
+        flush_counters();
+    }
+};

@@ -1,0 +1,115 @@
+// az_wave.h -- the 64-lane wavefront as a programming model.
+//
+// Every engine routine is written once, against a `Wave` policy:
+//   * code outside a `Wv::lanes(...)` section is WAVE-UNIFORM: on gfx950 all 64 lanes run it
+//     redundantly on identical values (the compiler keeps such values in SGPRs / scalar ALU),
+//   * `Wv::lanes(f)` runs f(lane) on every lane (SPMD section; lanes only write their own data),
+//   * `Wv::ballot / any / argmax_first / sum_*` are the cross-lane primitives.
+// `WaveDev` maps these to CDNA4 wave64 hardware (v_cmp -> 64-bit ballot masks, DPP/bpermute
+// reductions).  `WaveHost` replays the same sections with a 64-iteration loop; it exists so
+// the *identical* engine source can be unit-tested on a machine without a GPU (tests/hosttwin,
+// never linked into the product library).
+#pragma once
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef long long i64;
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AZ_HD __host__ __device__ __forceinline__
+#define AZ_D __device__ __forceinline__
+#else
+#define AZ_HD inline
+#define AZ_D inline
+#endif
+
+#define AZ_WAVE 64
+
+#if defined(__HIPCC__)
+struct WaveDev {
+    static AZ_D int lane() { return (int)(threadIdx.x & 63u); }
+    static AZ_D bool first() { return lane() == 0; }
+    template <class F> static AZ_D void lanes(F&& f) { f(lane()); }
+    template <class F> static AZ_D u64 ballot(F&& f) { return __ballot(f(lane()) ? 1 : 0); }
+    // Orders this wave's earlier LDS/global accesses before later ones (cross-lane hand-over inside ONE
+    // wave).  A wave's memory instructions are issued and serviced in order, so a compiler-level
+    // barrier is all that is needed; no cross-wave traffic exists in this engine (one wave == one game).
+    static AZ_D void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // Max over lanes of a double; every lane gets the result.
+    static AZ_D double max_f64(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double w = __shfl_xor(v, o, 64);
+            v = w > v ? w : v;
+        }
+        return v;
+    }
+    static AZ_D int min_i32(int v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int w = __shfl_xor(v, o, 64);
+            v = w < v ? w : v;
+        }
+        return v;
+    }
+    // f(lane, score&, idx&): the lane's best candidate (idx < 0: none).  Returns the index with the
+    // largest score, lowest index on ties (np.argmax semantics, mcts_v2.py:178).
+    template <class F> static AZ_D int argmax_first(F&& f) {
+        double s = -1.0e300;
+        int idx = -1;
+        f(lane(), s, idx);
+        if (idx < 0) s = -1.0e300;
+        double m = max_f64(s);
+        int cand = (idx >= 0 && s == m) ? idx : 0x7fffffff;
+        return min_i32(cand);
+    }
+    static AZ_D int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    template <class F> static AZ_D int sum_i32(F&& f) {
+        int v = f(lane());
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+};
+#endif
+
+struct WaveHost {
+    static bool first() { return true; }
+    template <class F> static void lanes(F&& f) {
+        for (int l = 0; l < AZ_WAVE; ++l) f(l);
+    }
+    template <class F> static u64 ballot(F&& f) {
+        u64 m = 0;
+        for (int l = 0; l < AZ_WAVE; ++l)
+            if (f(l)) m |= 1ull << l;
+        return m;
+    }
+    static void sync() {}
+    template <class F> static int argmax_first(F&& f) {
+        double best = -1.0e300;
+        int bi = 0x7fffffff;
+        for (int l = 0; l < AZ_WAVE; ++l) {
+            double s = -1.0e300;
+            int idx = -1;
+            f(l, s, idx);
+            if (idx < 0) continue;
+            if (s > best || (s == best && idx < bi)) {
+                best = s;
+                bi = idx;
+            }
+        }
+        return bi;
+    }
+    static int bcast0(int v) { return v; }
+    template <class F> static int sum_i32(F&& f) {
+        int v = 0;
+        for (int l = 0; l < AZ_WAVE; ++l) v += f(l);
+        return v;
+    }
+};

@@ -1,0 +1,65 @@
+// azsp_hip.hip -- HIP / gfx950 backend of the engine: builds libazsp.so (the product).
+// One workgroup = 256 threads = 4 wavefronts = 4 independent games (no inter-wave traffic, no
+// __syncthreads); game g runs on block g/4, which the dispatcher places on XCD (g/4) % 8 in every
+// launch, so a game's tree stays affine to one XCD's L2 across rounds.
+#include <hip/hip_runtime.h>
+
+#include "azsp_impl.h"
+
+static hipError_t g_last = hipSuccess;
+#define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
+
+template <int N, int GAME, class Op>
+__global__ void __launch_bounds__(256) k_game(const AzCfg c, const AzMem m, const Op op) {
+    __shared__ Scratch<Geo<N>::W> sc[4];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int g = (int)blockIdx.x * 4 + wave;
+    if (g >= c.G) return;
+    Engine<WaveDev, N, GAME> e(c, m, g, sc[wave]);
+    op(e);
+}
+
+__global__ void __launch_bounds__(256) k_dihedral(const DihedralArgs a, long long total) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
+        az_dihedral_elem(a, t);
+}
+
+namespace azb {
+void* alloc(size_t n) {
+    void* p = nullptr;
+    if (AZ_HIP(hipMalloc(&p, n))) return nullptr;
+    if (AZ_HIP(hipMemset(p, 0, n))) {
+        hipFree(p);
+        return nullptr;
+    }
+    return p;
+}
+void release(void* p) { (void)hipFree(p); }
+int h2d(void* d, const void* s, size_t n, void* st) {
+    if (AZ_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st))) return -1;
+    return AZ_HIP(hipStreamSynchronize((hipStream_t)st));  // the host buffer may be reused by the caller
+}
+int d2h(void* d, const void* s, size_t n, void* st) {
+    if (AZ_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st))) return -1;
+    return AZ_HIP(hipStreamSynchronize((hipStream_t)st));
+}
+int zero(void* d, size_t n, void* st) { return AZ_HIP(hipMemsetAsync(d, 0, n, (hipStream_t)st)); }
+int sync(void* st) { return AZ_HIP(hipStreamSynchronize((hipStream_t)st)); }
+int set_device(int dev) {
+    int n = 0;
+    if (AZ_HIP(hipGetDeviceCount(&n)) || n < 1) return -1;
+    return AZ_HIP(hipSetDevice(dev));
+}
+const char* backend_error() { return hipGetErrorString(g_last); }
+template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* st) {
+    const dim3 grid((unsigned)((c.G + 3) / 4)), block(256);
+    hipLaunchKernelGGL((k_game<N, GAME, Op>), grid, block, 0, (hipStream_t)st, c, m, op);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_dihedral(const DihedralArgs& a, long long total, void* st) {
+    long long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_dihedral, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a, total);
+    return AZ_HIP(hipGetLastError());
+}
+}  // namespace azb

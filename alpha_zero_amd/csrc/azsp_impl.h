@@ -1,0 +1,688 @@
+// azsp_impl.h -- the C ABI of include/azsp.h, written once against a tiny backend interface
+// (namespace azb: alloc / copy / launch).  alpha_zero_amd/csrc/azsp_hip.hip provides the HIP
+// backend (the product, libazsp.so); tests/hosttwin/azsp_host.cpp provides a host backend that
+// runs the identical engine source wave-by-wave on the CPU for unit tests without a GPU.
+#pragma once
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/azsp.h"
+#include "az_engine.h"
+
+#define AZ_FOR_EACH_VARIANT(X) \
+    X(5, AZ_GO) X(9, AZ_GO) X(13, AZ_GO) X(19, AZ_GO) X(7, AZ_GOMOKU) X(9, AZ_GOMOKU) X(13, AZ_GOMOKU) X(15, AZ_GOMOKU)
+
+// ------------------------------------------------------------------------------------------------
+// per-game operations (functors: trivially copyable, passed by value to the kernel)
+// ------------------------------------------------------------------------------------------------
+struct OpReset {
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (E::Wave::first()) {
+            e.gr.games_done = 0;
+            e.gr.cur_buf = 0;
+            e.gr.noise_ready = 0;
+            int* sh = e.m.stg_hdr + (size_t)e.g * 2 * SH_COUNT;
+            sh[SH_STATE] = AZB_FREE;
+            sh[SH_COUNT + SH_STATE] = AZB_FREE;
+        }
+        E::Wave::sync();
+        e.new_game();
+    }
+};
+struct OpRound {
+    const float* priors;
+    const float* values;
+    void* feat;
+    unsigned char* valid;
+    int do_advance, do_select;
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (do_advance) e.advance(priors, values);
+        if (do_select) {
+            e.select(feat, valid);
+            e.cnt[AZC_ROUNDS]++;
+        }
+        e.flush_counters();
+    }
+};
+struct OpBeginMove {
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (E::Wave::first()) e.gr.noise_ready = 1;
+        E::Wave::sync();
+    }
+};
+struct OpCommit {
+    const int* moves;
+    template <class E> AZ_HD void operator()(E& e) const {
+        e.commit_host(moves[e.g]);
+        e.flush_counters();
+    }
+};
+struct OpStatus {
+    int* status;
+    double* q;
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (E::Wave::first()) {
+            int* s = status + (size_t)e.g * 8;
+            s[0] = e.gr.status;
+            s[1] = e.gr.ply;
+            s[2] = e.gr.root_N;
+            s[3] = e.gr.n_leaves;
+            s[4] = e.gr.out_move;
+            s[5] = e.gr.games_done;
+            s[6] = e.gr.root_eval_pending;
+            s[7] = e.gr.noise_pending;
+            q[(size_t)e.g * 2] = e.gr.out_root_q;
+            q[(size_t)e.g * 2 + 1] = e.gr.out_child_q;
+        }
+    }
+};
+// packed position uploaded by azsp_set_state: u64 stones[2][W], u64 hist[8][2][W], int scalars[8]
+struct OpSetState {
+    int slot;
+    const u64* packed;
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (e.g != slot) return;
+        typedef typename E::R R;
+        typedef typename E::O O;
+        const int W = E::W;
+        const int* sc = (const int*)(packed + 2 * W + 16 * W);
+        typename E::S s;
+        for (int q = 0; q < 2; ++q)
+            for (int w = 0; w < W; ++w) s.stones[q][w] = packed[q * W + w];
+        s.to_play = (uint8_t)sc[0];
+        s.steps = (int16_t)sc[1];
+        s.ko = (int16_t)sc[2];
+        s.flags = sc[3] ? AZF_LASTPASS : 0;
+        s.caps[0] = (uint16_t)sc[4];
+        s.caps[1] = (uint16_t)sc[5];
+        s.winner = -1;
+        s.reward = 0;
+        s.area[0] = s.area[1] = 0;
+        const typename E::B own = R::ld(s.stones[s.to_play]), opp = R::ld(s.stones[1 - s.to_play]);
+        const typename E::B legal = E::GAME_ID == AZ_GO ? R::go_legal(own, opp, s.ko) : O::inv(O::bor(own, opp));
+        R::st(s.legal, legal);
+        if (E::Wave::first()) {
+            e.gr.env = s;
+            for (int k = 0; k < 8; ++k)
+                for (int q = 0; q < 2; ++q)
+                    for (int w = 0; w < W; ++w) e.gr.hist[k][q][w] = packed[2 * W + (k * 2 + q) * W + w];
+            e.gr.ply = 0;
+            e.gr.num_passes = 0;
+            e.gr.marked_player = -1;
+            e.gr.n_leaves = 0;
+            e.gr.root_eval_pending = 0;
+            e.gr.noise_pending = 0;
+            e.gr.noise_ready = 0;
+            e.gr.status = AZS_NEED_ROOT;
+        }
+        E::Wave::sync();
+        e.free_all_nodes();
+    }
+};
+struct OpEnvStep {
+    const int* actions;
+    int8_t* board;
+    int8_t* legal;
+    int* scalars;
+    int8_t* obs;
+    template <class E> AZ_HD void operator()(E& e) const {
+        typedef typename E::R R;
+        typedef typename E::S S;
+        const int NP = E::NP, A = E::A;
+        const bool go = E::GAME_ID == AZ_GO;
+        const int a = actions ? actions[e.g] : -2;
+        int illegal = 0;
+        if (a != -2) {
+            const S cur = e.gr.env;
+            S ns;
+            if (cur.flags & AZF_TERMINAL) illegal = 1;                    // RuntimeError('Game is over') go.py:90-91
+            else if (a == -1 && go) R::go_resign(cur, ns);
+            else if (a < 0 || a >= A) illegal = 2;                        // ValueError('Invalid action') go.py:92-93
+            else if (!e.action_legal(cur, a)) illegal = 3;                // ValueError('Illegal action') go.py:94-95
+            else R::template step<E::GAME_ID>(cur, a, e.c.rc, ns);
+            if (!illegal) {
+                if (E::Wave::first()) {
+                    e.gr.env = ns;
+                    e.gr.ply += 1;
+                }
+                E::Wave::sync();
+                e.push_history(ns);
+            }
+        }
+        const S& s = e.gr.env;
+        const int b_id = 1, w_id = go ? -1 : 2;
+        E::Wave::lanes([&](int lane) {
+            for (int p = lane; p < NP; p += AZ_WAVE) {
+                const bool bk = (s.stones[0][p >> 6] >> (p & 63)) & 1ull, wh = (s.stones[1][p >> 6] >> (p & 63)) & 1ull;
+                if (board) board[(size_t)e.g * NP + p] = (int8_t)(bk ? b_id : (wh ? w_id : 0));
+            }
+            if (legal)
+                for (int x = lane; x < A; x += AZ_WAVE) legal[(size_t)e.g * A + x] = e.action_legal(s, x) ? 1 : 0;
+        });
+        if (scalars) {
+            int ab = 0, aw = 0;
+            if (go) R::go_area(R::ld(s.stones[0]), R::ld(s.stones[1]), ab, aw);
+            if (E::Wave::first()) {
+                int* o = scalars + (size_t)e.g * 12;
+                o[0] = s.ko;
+                o[1] = s.caps[0];
+                o[2] = s.caps[1];
+                o[3] = s.steps;
+                o[4] = s.to_play == 0 ? b_id : w_id;
+                o[5] = (s.flags & AZF_TERMINAL) ? 1 : 0;
+                o[6] = s.reward;
+                o[7] = s.winner < 0 ? 0 : (s.winner == 0 ? b_id : w_id);
+                o[8] = ab;
+                o[9] = aw;
+                o[10] = illegal;
+                o[11] = (s.flags & AZF_LASTPASS) ? 1 : 0;
+            }
+        }
+        if (obs) {
+            e.gather_planes(-1, -1, s.to_play);
+            int8_t* out = obs + (size_t)e.g * 17 * NP;
+            e.template emit_planes<int8_t>(out, (int8_t)1, s.to_play);
+        }
+        E::Wave::sync();
+    }
+};
+struct OpHarvest {
+    int8_t* states;
+    float* pi;
+    float* z;
+    int cap;
+    int* games;
+    int max_games;
+    int* out_counts;  // [0] samples, [1] games
+    template <class E> AZ_HD void operator()(E& e) const {
+        const int NP = E::NP, A = E::A, W = E::W;
+        const bool go = E::GAME_ID == AZ_GO;
+        const int b_id = 1, w_id = go ? -1 : 2;
+        for (int b = 0; b < 2; ++b) {
+            int* sh = e.m.stg_hdr + ((size_t)e.g * 2 + b) * SH_COUNT;
+            if (sh[SH_STATE] != AZB_COMPLETE) continue;
+            const int len = sh[SH_LEN];
+            int start = 0, gi = 0;
+            if (E::Wave::first()) {
+                start = AzAtomic::fetch_add_i32(out_counts, len);
+                gi = AzAtomic::fetch_add_i32(out_counts + 1, 1);
+                if (start + len > cap || gi >= max_games) {  // no room this time: roll back, keep the buffer
+                    AzAtomic::fetch_add_i32(out_counts, -len);
+                    AzAtomic::fetch_add_i32(out_counts + 1, -1);
+                    start = -1;
+                }
+            }
+            start = E::Wave::bcast0(start);
+            gi = E::Wave::bcast0(gi);
+            if (start < 0) continue;
+            const int reward = sh[SH_REWARD], last_player = sh[SH_LAST_PLAYER];
+            for (int k = 0; k < len; ++k) {
+                const size_t idx = ((size_t)e.g * 2 + b) * e.c.stage_cap + k;
+                const u64* pl = e.m.stg_planes + idx * 16 * W;
+                const float* spi = e.m.stg_pi + idx * A;
+                const int black = e.m.stg_meta[idx];
+                int8_t* so = states + (size_t)(start + k) * 17 * NP;
+                float* po = pi + (size_t)(start + k) * A;
+                E::Wave::lanes([&](int lane) {
+                    for (int x = lane; x < 17 * NP; x += AZ_WAVE) {
+                        const int plane = x / NP, p = x - plane * NP;
+                        so[x] = plane < 16 ? (int8_t)((pl[plane * W + (p >> 6)] >> (p & 63)) & 1ull) : (int8_t)black;
+                    }
+                    for (int x = lane; x < A; x += AZ_WAVE) po[x] = spi[x];
+                });
+                if (E::Wave::first()) {
+                    // pipeline.py:349-354: z = reward for the samples of the last player, -reward for the others
+                    const int mover = black ? 0 : 1;
+                    z[start + k] = reward == 0 ? 0.0f : (mover == last_player ? (float)reward : (float)-reward);
+                }
+            }
+            if (E::Wave::first()) {
+                int* o = games + (size_t)gi * 16;
+                o[0] = start;
+                o[1] = len;
+                o[2] = sh[SH_WINNER] < 0 ? 0 : (sh[SH_WINNER] == 0 ? b_id : w_id);
+                o[3] = sh[SH_AREA_B];
+                o[4] = sh[SH_AREA_W];
+                o[5] = sh[SH_PASSES];
+                o[6] = sh[SH_RESIGNED];
+                o[7] = sh[SH_RESIGN_DISABLED];
+                o[8] = sh[SH_MARKED];
+                o[9] = sh[SH_COULD_WON];
+                o[10] = sh[SH_MARKED_PLAYER] < 0 ? 0 : (sh[SH_MARKED_PLAYER] == 0 ? b_id : w_id);
+                o[11] = sh[SH_UID];
+                o[12] = sh[SH_TRAINING_STEPS];
+                o[13] = reward;
+                o[14] = last_player == 0 ? b_id : w_id;
+                o[15] = e.g;
+                sh[SH_STATE] = AZB_FREE;
+            }
+            E::Wave::sync();
+        }
+    }
+};
+
+// Dihedral-8 gather (utils/transformation.py:34-110): flat element kernel, pure permutation of bytes.
+struct DihedralArgs {
+    const unsigned char* sin;
+    unsigned char* sout;
+    const unsigned char* pin;
+    unsigned char* pout;
+    int ses, pes, batch, ch, n, A, op;
+};
+AZ_HD int az_dihedral_src(int op, int n, int i, int j) {
+    int r, c;
+    switch (op) {
+        case 1: r = i; c = n - 1 - j; break;          // hflip: reverse the last dim (:46)
+        case 2: r = n - 1 - i; c = j; break;          // vflip (:71)
+        case 3: r = j; c = n - 1 - i; break;          // rot90 counter-clockwise (transformation_test.py:231-274)
+        case 4: r = n - 1 - i; c = n - 1 - j; break;  // rot180
+        case 5: r = n - 1 - j; c = i; break;          // rot270
+        case 6: r = j; c = i; break;                  // transpose (extra)
+        case 7: r = n - 1 - j; c = n - 1 - i; break;  // anti-transpose (extra)
+        default: r = i; c = j; break;
+    }
+    return r * n + c;
+}
+AZ_HD void az_copy_elem(unsigned char* d, const unsigned char* s, int es) {
+    for (int b = 0; b < es; ++b) d[b] = s[b];
+}
+AZ_HD void az_dihedral_elem(const DihedralArgs& a, long long t) {
+    const int np = a.n * a.n;
+    const long long ns = (long long)a.batch * a.ch * np;
+    if (t < ns) {
+        if (!a.sin) return;
+        const int p = (int)(t % np);
+        const long long base = t - p;
+        const int src = az_dihedral_src(a.op, a.n, p / a.n, p % a.n);
+        az_copy_elem(a.sout + t * a.ses, a.sin + (base + src) * a.ses, a.ses);
+    } else {
+        t -= ns;
+        if (!a.pin || t >= (long long)a.batch * a.A) return;
+        const int x = (int)(t % a.A);
+        const long long base = t - x;
+        const int src = x < np ? az_dihedral_src(a.op, a.n, x / a.n, x % a.n) : x;  // pass column untouched
+        az_copy_elem(a.pout + t * a.pes, a.pin + (base + src) * a.pes, a.pes);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine handle
+// ------------------------------------------------------------------------------------------------
+struct AzHandle {
+    AzspConfig pub;
+    AzCfg cfg;
+    AzMem mem;
+    std::string err;
+    std::vector<void*> allocs;
+    int A, AP, W, NP, REC, GREC;
+    long long bytes;
+    int* d_status;
+    double* d_q;
+    int* d_moves;
+    u64* d_packed;
+    int* d_hcounts;
+    int* d_games;
+    int d_games_cap;
+};
+
+namespace azb {  // implemented by the backend translation unit
+void* alloc(size_t n);
+void release(void* p);
+int h2d(void* dst, const void* src, size_t n, void* stream);
+int d2h(void* dst, const void* src, size_t n, void* stream);
+int zero(void* dst, size_t n, void* stream);
+int sync(void* stream);
+int set_device(int dev);
+const char* backend_error();
+template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream);
+int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
+}  // namespace azb
+
+template <class T> static T* az_new(AzHandle* h, size_t count) {
+    size_t n = count * sizeof(T);
+    if (n == 0) n = sizeof(T);
+    void* p = azb::alloc(n);
+    if (!p) return nullptr;
+    h->allocs.push_back(p);
+    h->bytes += (long long)n;
+    return (T*)p;
+}
+
+template <class Op> static int az_run(AzHandle* h, const Op& op, void* stream) {
+    int rc = AZSP_EINVAL;
+    switch (h->cfg.game * 100 + h->cfg.n) {
+#define AZ_CASE(NN, GG) \
+    case (GG) * 100 + (NN): rc = azb::launch<NN, GG, Op>(h->cfg, h->mem, op, stream); break;
+        AZ_FOR_EACH_VARIANT(AZ_CASE)
+#undef AZ_CASE
+        default: break;
+    }
+    if (rc != 0) {
+        h->err = std::string("kernel launch failed: ") + azb::backend_error();
+        return AZSP_EDEVICE;
+    }
+    return AZSP_OK;
+}
+
+static int az_geometry_of(int game, int n, int* A, int* AP, int* W, int* REC, int* GREC) {
+    switch (game * 100 + n) {
+#define AZ_CASE(NN, GG)                              \
+    case (GG) * 100 + (NN): {                        \
+        typedef Engine<WaveHost, NN, GG> E;          \
+        *A = E::A; *AP = E::AP; *W = E::W; *REC = E::REC; *GREC = E::GREC; \
+        return 0;                                    \
+    }
+        AZ_FOR_EACH_VARIANT(AZ_CASE)
+#undef AZ_CASE
+        default: return -1;
+    }
+}
+
+static int az_check_engine_fault(AzHandle* h, void* stream) {
+    int e = 0;
+    if (azb::d2h(&e, h->mem.err, sizeof(int), stream) != 0) {
+        h->err = std::string("copy failed: ") + azb::backend_error();
+        return AZSP_EDEVICE;
+    }
+    if (e) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "engine fault flags 0x%x (1=node pool exhausted, 2=tree deeper than %d, 4=move sampling, 8=staging full)", e,
+                 AZ_PATH_CAP);
+        h->err = buf;
+        return AZSP_EENGINE;
+    }
+    return AZSP_OK;
+}
+
+extern "C" {
+
+int azsp_create(const AzspConfig* p, void** out) {
+    if (!p || !out) return AZSP_EINVAL;
+    *out = nullptr;
+    AzHandle* h = new AzHandle();
+    h->pub = *p;
+    h->bytes = 0;
+    if (az_geometry_of(p->game, p->board_size, &h->A, &h->AP, &h->W, &h->REC, &h->GREC) != 0 || p->num_games < 1 ||
+        p->num_parallel < 1 || p->num_parallel > AZ_MAXP || p->num_simulations < 1) {
+        delete h;
+        return AZSP_EINVAL;
+    }
+    if (azb::set_device(p->device) != 0) {
+        delete h;
+        return AZSP_EDEVICE;
+    }
+    h->NP = p->board_size * p->board_size;
+    AzCfg& c = h->cfg;
+    memset(&c, 0, sizeof c);
+    c.game = p->game;
+    c.n = p->board_size;
+    c.G = p->num_games;
+    c.P = p->num_parallel;
+    c.sims = p->num_simulations;
+    c.parallel_mode = p->num_parallel > 1 ? 1 : 0;                    // pipeline.py:132
+    c.budget = p->num_simulations + (c.parallel_mode ? c.P : 0);      // mcts_v2.py:378 / :568
+    c.max_nodes = p->max_nodes > 0 ? p->max_nodes : c.budget + 2 * c.P + 8;
+    if (c.max_nodes > 32000) {
+        delete h;
+        return AZSP_EINVAL;
+    }
+    c.root_noise = p->root_noise;
+    c.deterministic = p->deterministic;
+    c.reuse_tree = p->reuse_tree;
+    c.warm_up_steps = p->warm_up_steps;
+    c.has_resign = (p->game == AZSP_GAME_GO && p->has_resign && p->resign_threshold > -1.0) ? 1 : 0;
+    c.check_resign_after = p->check_resign_after_steps;
+    c.force_resign_disabled = p->force_resign_disabled;
+    c.inject = p->inject_random;
+    c.inj_moves = p->inject_moves > 0 ? p->inject_moves : 1;
+    c.stop_after_move = p->stop_after_move;
+    c.max_plies = p->max_plies;
+    c.stop_at_game_end = p->stop_at_game_end;
+    c.feat_dtype = p->feature_dtype;
+    c.log_moves = p->log_moves;
+    c.log_cap = (p->log_moves && p->log_capacity > 0) ? p->log_capacity : 1;
+    c.tab_len = c.budget + 3 * c.P + 16;
+    c.training_steps = p->training_steps;
+    c.one_minus_eps_f32 = (float)(1.0 - p->dirichlet_eps);            // child_P * (1 - eps): float32 row times Python float
+    c.disable_resign_ratio = p->disable_resign_ratio;
+    c.eps = p->dirichlet_eps;
+    c.alpha = p->dirichlet_alpha;
+    c.resign_threshold = p->resign_threshold;
+    c.rc.max_steps = p->max_steps > 0 ? p->max_steps : 2 * h->NP;     // go.py:48
+    c.rc.num_to_win = p->num_to_win > 0 ? p->num_to_win : 5;
+    c.rc.komi = p->komi;
+    c.seed = p->seed;
+    c.rank = p->rank;
+    c.stage_cap = p->stop_after_move ? 1 : (p->game == AZSP_GAME_GO ? c.rc.max_steps : h->NP);
+
+    const size_t G = (size_t)c.G;
+    AzMem& m = h->mem;
+    memset(&m, 0, sizeof m);
+    m.nodes = az_new<unsigned char>(h, G * c.max_nodes * h->REC);
+    m.games = az_new<unsigned char>(h, G * h->GREC);
+    m.rootP = az_new<double>(h, G * h->AP);
+    m.free_stack = az_new<int16_t>(h, G * c.max_nodes);
+    m.leaf_path = az_new<int>(h, G * c.P * AZ_PATH_CAP);
+    m.pbc_np = az_new<double>(h, c.tab_len);
+    m.pbc_py = az_new<double>(h, c.tab_len);
+    m.sqrt32 = az_new<float>(h, c.tab_len);
+    m.inj_noise = az_new<double>(h, c.inject ? G * c.inj_moves * h->A : (c.stop_after_move ? G * h->A : 1));
+    m.inj_unif = az_new<double>(h, c.inject ? G * c.inj_moves * AZ_INJ_K : 1);
+    m.stg_planes = az_new<u64>(h, G * 2 * c.stage_cap * 16 * h->W);
+    m.stg_pi = az_new<float>(h, G * 2 * c.stage_cap * h->A);
+    m.stg_meta = az_new<unsigned char>(h, G * 2 * c.stage_cap);
+    m.stg_hdr = az_new<int>(h, G * 2 * SH_COUNT);
+    m.log_pi = az_new<double>(h, G * c.log_cap * h->A);
+    m.log_childN = az_new<float>(h, G * c.log_cap * h->A);
+    m.log_q = az_new<double>(h, G * c.log_cap * 4);
+    m.counters = az_new<u64>(h, AZC_COUNT);
+    m.err = az_new<int>(h, 4);
+    h->d_status = az_new<int>(h, G * 8);
+    h->d_q = az_new<double>(h, G * 2);
+    h->d_moves = az_new<int>(h, G);
+    h->d_packed = az_new<u64>(h, 18 * h->W + 8);
+    h->d_hcounts = az_new<int>(h, 4);
+    h->d_games_cap = (int)(2 * G);
+    h->d_games = az_new<int>(h, (size_t)h->d_games_cap * 16);
+    if (!m.nodes || !m.games || !m.rootP || !m.free_stack || !m.leaf_path || !m.stg_planes || !m.stg_pi || !m.log_pi ||
+        !h->d_games || !m.err) {
+        for (void* q : h->allocs) azb::release(q);
+        delete h;
+        return AZSP_ENOMEM;
+    }
+    // the injected-noise path is also how drop-in mode receives its per-call Dirichlet draw
+    if (c.stop_after_move && !c.inject) {
+        c.inject = 1;
+        c.inj_moves = 1;
+    }
+    *out = h;
+    int rc = az_run(h, OpReset(), nullptr);
+    if (rc == 0) rc = azb::sync(nullptr) == 0 ? 0 : AZSP_EDEVICE;
+    return rc;
+}
+
+int azsp_destroy(void* e) {
+    if (!e) return AZSP_EINVAL;
+    AzHandle* h = (AzHandle*)e;
+    azb::sync(nullptr);
+    for (void* q : h->allocs) azb::release(q);
+    delete h;
+    return AZSP_OK;
+}
+
+const char* azsp_last_error(void* e) { return e ? ((AzHandle*)e)->err.c_str() : "null engine"; }
+
+int azsp_geometry(void* e, AzspGeometry* g) {
+    if (!e || !g) return AZSP_EINVAL;
+    AzHandle* h = (AzHandle*)e;
+    g->num_actions = h->A;
+    g->num_points = h->NP;
+    g->planes = 17;
+    g->batch_rows = h->cfg.G * h->cfg.P;
+    g->max_nodes = h->cfg.max_nodes;
+    g->budget = h->cfg.budget;
+    g->table_len = h->cfg.tab_len;
+    g->stage_capacity = h->cfg.stage_cap;
+    g->device_bytes = h->bytes;
+    g->node_record_bytes = h->REC;
+    g->reserved = 0;
+    return AZSP_OK;
+}
+
+int azsp_set_tables(void* e, const double* a, const double* b, const float* s, int32_t len) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !a || !b || !s || len != h->cfg.tab_len) return AZSP_EINVAL;
+    if (azb::h2d((void*)h->mem.pbc_np, a, sizeof(double) * len, nullptr) || azb::h2d((void*)h->mem.pbc_py, b, sizeof(double) * len, nullptr) ||
+        azb::h2d((void*)h->mem.sqrt32, s, sizeof(float) * len, nullptr))
+        return AZSP_EDEVICE;
+    return AZSP_OK;
+}
+
+int azsp_set_injection(void* e, const double* noise, const double* unif, int32_t moves) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !h->pub.inject_random || moves != h->cfg.inj_moves) return AZSP_EINVAL;
+    const size_t G = h->cfg.G;
+    if (noise && azb::h2d((void*)h->mem.inj_noise, noise, sizeof(double) * G * moves * h->A, nullptr)) return AZSP_EDEVICE;
+    if (unif && azb::h2d((void*)h->mem.inj_unif, unif, sizeof(double) * G * moves * AZ_INJ_K, nullptr)) return AZSP_EDEVICE;
+    return AZSP_OK;
+}
+
+int azsp_reset_games(void* e, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    return az_run(h, OpReset(), stream);
+}
+
+int azsp_env_step(void* e, const int32_t* actions, int8_t* board, int8_t* legal, int32_t* scalars, int8_t* obs, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    OpEnvStep op = {actions, board, legal, scalars, obs};
+    return az_run(h, op, stream);
+}
+
+int azsp_set_state(void* e, int32_t slot, const int8_t* board, const int8_t* hist, int32_t to_play, int32_t steps, int32_t ko,
+                   int32_t last_was_pass, int32_t caps_b, int32_t caps_w, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !board || !hist || slot < 0 || slot >= h->cfg.G) return AZSP_EINVAL;
+    const int W = h->W, NP = h->NP;
+    const int w_id = h->cfg.game == AZ_GO ? -1 : 2;
+    std::vector<u64> pk(18 * W + 8, 0);
+    for (int p = 0; p < NP; ++p) {
+        if (board[p] == 1) pk[0 * W + (p >> 6)] |= 1ull << (p & 63);
+        else if (board[p] == w_id) pk[1 * W + (p >> 6)] |= 1ull << (p & 63);
+    }
+    for (int k = 0; k < 8; ++k)
+        for (int p = 0; p < NP; ++p) {
+            const int8_t v = hist[k * NP + p];
+            if (v == 1) pk[2 * W + (k * 2 + 0) * W + (p >> 6)] |= 1ull << (p & 63);
+            else if (v == w_id) pk[2 * W + (k * 2 + 1) * W + (p >> 6)] |= 1ull << (p & 63);
+        }
+    int* sc = (int*)(pk.data() + 18 * W);
+    sc[0] = to_play == 1 ? 0 : 1;
+    sc[1] = steps;
+    sc[2] = ko;
+    sc[3] = last_was_pass;
+    sc[4] = caps_b;
+    sc[5] = caps_w;
+    if (azb::h2d(h->d_packed, pk.data(), pk.size() * sizeof(u64), stream)) return AZSP_EDEVICE;
+    OpSetState op = {slot, h->d_packed};
+    return az_run(h, op, stream);
+}
+
+int azsp_begin_move(void* e, const double* noise, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    if (noise && azb::h2d((void*)h->mem.inj_noise, noise, sizeof(double) * (size_t)h->cfg.G * h->A, stream)) return AZSP_EDEVICE;
+    return az_run(h, OpBeginMove(), stream);
+}
+
+int azsp_select(void* e, void* feat, uint8_t* valid, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !feat || !valid) return AZSP_EINVAL;
+    OpRound op = {nullptr, nullptr, feat, valid, 0, 1};
+    return az_run(h, op, stream);
+}
+
+int azsp_expand_backup(void* e, const float* priors, const float* values, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !priors || !values) return AZSP_EINVAL;
+    OpRound op = {priors, values, nullptr, nullptr, 1, 0};
+    return az_run(h, op, stream);
+}
+
+int azsp_round(void* e, const float* priors, const float* values, void* feat, uint8_t* valid, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !priors || !values || !feat || !valid) return AZSP_EINVAL;
+    OpRound op = {priors, values, feat, valid, 1, 1};
+    return az_run(h, op, stream);
+}
+
+int azsp_get_status(void* e, int32_t* status, double* q, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    OpStatus op = {h->d_status, h->d_q};
+    int rc = az_run(h, op, stream);
+    if (rc) return rc;
+    if (status && azb::d2h(status, h->d_status, sizeof(int) * 8 * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
+    if (q && azb::d2h(q, h->d_q, sizeof(double) * 2 * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
+    return az_check_engine_fault(h, stream);
+}
+
+int azsp_get_search(void* e, int32_t slot, int32_t ply, double* pi, float* cn, double* q, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || slot < 0 || slot >= h->cfg.G || ply < 0 || ply >= h->cfg.log_cap) return AZSP_EINVAL;
+    const size_t o = (size_t)slot * h->cfg.log_cap + ply;
+    if (pi && azb::d2h(pi, h->mem.log_pi + o * h->A, sizeof(double) * h->A, stream)) return AZSP_EDEVICE;
+    if (cn && azb::d2h(cn, h->mem.log_childN + o * h->A, sizeof(float) * h->A, stream)) return AZSP_EDEVICE;
+    if (q && azb::d2h(q, h->mem.log_q + o * 4, sizeof(double) * 4, stream)) return AZSP_EDEVICE;
+    return AZSP_OK;
+}
+
+int azsp_commit_move(void* e, const int32_t* moves, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !moves) return AZSP_EINVAL;
+    if (azb::h2d(h->d_moves, moves, sizeof(int) * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
+    OpCommit op = {h->d_moves};
+    return az_run(h, op, stream);
+}
+
+int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int32_t* games, int32_t max_games, int32_t* n_samples,
+                 int32_t* n_games, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !states || !pi || !z || !games || !n_samples || !n_games || cap < 1) return AZSP_EINVAL;
+    if (max_games > h->d_games_cap) max_games = h->d_games_cap;
+    if (azb::zero(h->d_hcounts, sizeof(int) * 4, stream)) return AZSP_EDEVICE;
+    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hcounts};
+    int rc = az_run(h, op, stream);
+    if (rc) return rc;
+    int cnt[4];
+    if (azb::d2h(cnt, h->d_hcounts, sizeof cnt, stream)) return AZSP_EDEVICE;
+    *n_samples = cnt[0];
+    *n_games = cnt[1];
+    if (cnt[1] > 0 && azb::d2h(games, h->d_games, sizeof(int) * 16 * (size_t)cnt[1], stream)) return AZSP_EDEVICE;
+    return az_check_engine_fault(h, stream);
+}
+
+int azsp_counters(void* e, uint64_t* out, int32_t reset, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !out) return AZSP_EINVAL;
+    if (azb::d2h(out, h->mem.counters, sizeof(u64) * AZC_COUNT, stream)) return AZSP_EDEVICE;
+    if (reset && azb::zero(h->mem.counters, sizeof(u64) * AZC_COUNT, stream)) return AZSP_EDEVICE;
+    return AZSP_OK;
+}
+
+int azsp_dihedral(const void* sin, void* sout, int32_t ses, const void* pin, void* pout, int32_t pes, int32_t batch, int32_t ch,
+                  int32_t n, int32_t A, int32_t op, void* stream) {
+    if (batch < 0 || n < 1 || op < 0 || op > 7) return AZSP_EINVAL;
+    if (pin && A != n * n && A != n * n + 1) return AZSP_EINVAL;  // ValueError('Expect ...') transformation.py:36-39
+    if ((sin && (ses < 1 || ses > 8 || !sout)) || (pin && (pes < 1 || pes > 8 || !pout))) return AZSP_EINVAL;
+    DihedralArgs a = {(const unsigned char*)sin, (unsigned char*)sout, (const unsigned char*)pin, (unsigned char*)pout, ses, pes, batch, ch, n, A, op};
+    const long long total = (long long)batch * ch * n * n + (long long)batch * A;
+    if (total == 0) return AZSP_OK;
+    return azb::launch_dihedral(a, total, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
+}
+
+}  // extern "C"

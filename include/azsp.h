@@ -1,0 +1,187 @@
+/*
+ * azsp.h -- C ABI of the MI355X batched self-play engine (libazsp.so).
+ *
+ * The upstream reference (michaelnny/alpha_zero) is pure Python and has no FFI; the "plugin API"
+ * of its self-play hot path is three Python call surfaces.  This header is what a binding for
+ * that path would bind (ctypes stub in INTEGRATION.md); each entry point names the reference
+ * interface it replaces (paths relative to the reference repo):
+ *
+ *   azsp_create / azsp_destroy        engine for G concurrent games: replaces one actor process per game
+ *                                     (alpha_zero/training_go.py:317-347, core/pipeline.py:166-218)
+ *   azsp_reset_games                  env.reset() for every slot                (envs/base.py:93-112, envs/go.py:76-86)
+ *   azsp_env_step                     BoardGameEnv.step / legal_actions / observation / score as a batch
+ *                                     (envs/go.py:88-161, envs/gomoku.py:45-83, envs/go_engine.py:417-441,
+ *                                      :123-152, envs/base.py:228-259)
+ *   azsp_set_state                    the `env` argument of uct_search()        (core/mcts_v2.py:301-311)
+ *   azsp_begin_move                   add_dirichlet_noise at the start of a search (core/mcts_v2.py:375-376, :565-566)
+ *   azsp_select                       Phase 1 of (parallel_)uct_search: best_child descents, virtual loss,
+ *                                     and env.observation() of the leaves       (core/mcts_v2.py:572-611)
+ *   azsp_expand_backup                Phases 2-3: expand + backup, then (when the budget is met) policy,
+ *                                     move, sample recording, env.step, re-root (core/mcts_v2.py:614-657,
+ *                                      core/pipeline.py:323-346)
+ *   azsp_round                        azsp_expand_backup + azsp_select in one launch
+ *   azsp_get_status / azsp_get_search the tuple uct_search() returns            (core/mcts_v2.py:450)
+ *   azsp_commit_move                  sub-tree reuse after the caller chose the move (core/mcts_v2.py:436-446)
+ *   azsp_harvest                      data_queue.put((game_seq, stats))         (core/pipeline.py:283, :349-380)
+ *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
+ *                                     (utils/transformation.py:34-110)
+ *
+ * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
+ * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
+ * named *_dev are device (HBM) addresses owned by the caller (e.g. torch tensors) and must stay
+ * alive until `stream` (a hipStream_t, NULL = default stream) has drained; pointers named *_host
+ * are host memory.  One host thread per engine.  Colours at this boundary use the reference's
+ * ids: Go black = 1, white = -1; Gomoku black = 1, white = 2 (envs/go.py:63-64, envs/base.py:33-34).
+ */
+#ifndef AZSP_H
+#define AZSP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZSP_GAME_GO 0
+#define AZSP_GAME_GOMOKU 1
+
+#define AZSP_FEAT_I8 0
+#define AZSP_FEAT_F32 1
+#define AZSP_FEAT_BF16 2
+#define AZSP_FEAT_F16 3
+
+#define AZSP_OK 0
+#define AZSP_EINVAL (-1)   /* bad argument / unsupported configuration */
+#define AZSP_ENOMEM (-2)
+#define AZSP_EDEVICE (-3)  /* HIP runtime error */
+#define AZSP_EENGINE (-4)  /* engine-side fault flag raised (node pool, depth, staging), see azsp_last_error */
+
+/* Game status codes reported by azsp_get_status */
+#define AZSP_ST_NEED_ROOT 0
+#define AZSP_ST_SEARCH 1
+#define AZSP_ST_MOVE_DONE 2
+#define AZSP_ST_IDLE 3
+#define AZSP_ST_WAIT_BUF 4
+
+typedef struct AzspConfig {
+    int32_t game;              /* AZSP_GAME_* */
+    int32_t board_size;        /* Go: 5, 9, 13, 19   Gomoku: 7, 9, 13, 15 */
+    int32_t num_games;         /* G: concurrent games (one wavefront each) */
+    int32_t num_parallel;      /* P: leaves per game per round; 1 selects uct_search semantics (pipeline.py:132-156) */
+    int32_t num_simulations;   /* budget: root.N < sims (+P when P > 1)      (mcts_v2.py:378, :568) */
+    int32_t max_nodes;         /* node pool per game; 0 = sims + 3P + 8 */
+    int32_t root_noise;        /* mcts_v2.py:375 */
+    int32_t deterministic;     /* mcts_v2.py:427-429 */
+    int32_t reuse_tree;        /* 0: root_node=None on every move (pipeline.py:836) */
+    int32_t warm_up_steps;     /* pipeline.py:320 */
+    int32_t has_resign;        /* Go only */
+    int32_t check_resign_after_steps;
+    int32_t force_resign_disabled; /* -1: draw per game with disable_resign_ratio (pipeline.py:244-246); 0/1: fixed */
+    int32_t inject_random;     /* 1: noise / uniforms come from azsp_set_injection (parity runs) */
+    int32_t inject_moves;      /* plies covered by the injection tables */
+    int32_t stop_after_move;   /* 1: drop-in uct_search mode, the caller picks and commits the move */
+    int32_t max_plies;         /* >0: a game idles after this many moves (tests) */
+    int32_t stop_at_game_end;  /* 1: slots idle after their first game (tests) */
+    int32_t feature_dtype;     /* AZSP_FEAT_* of the tensor written by azsp_select */
+    int32_t log_moves;         /* keep per-move pi / child_N / Q logs (tests, drop-in mode) */
+    int32_t log_capacity;      /* plies per game kept in the log */
+    int32_t max_steps;         /* Go: 0 = 2*N*N (go.py:48) */
+    int32_t num_to_win;        /* Gomoku (gomoku.py:26) */
+    int32_t training_steps;    /* tag copied into every finished game (pipeline.py:271) */
+    int32_t rank;              /* added to seed, mirrors set_seed(seed + rank) (pipeline.py:193) */
+    int32_t device;            /* HIP device ordinal */
+    float c_puct_base;         /* used by the caller to build the pb_c table (azsp_set_tables) */
+    float c_puct_init;
+    float disable_resign_ratio;
+    float reserved0;
+    double dirichlet_eps;      /* 0.25 (mcts_v2.py:235) */
+    double dirichlet_alpha;    /* 0.03 */
+    double resign_threshold;   /* <= -1 disables resignation (pipeline.py:216) */
+    double komi;               /* 7.5 (go.py:46) */
+    uint64_t seed;
+} AzspConfig;
+
+/* Sizes the caller needs to allocate its tensors. */
+typedef struct AzspGeometry {
+    int32_t num_actions;       /* A = N*N (+1 pass for Go) */
+    int32_t num_points;        /* N*N */
+    int32_t planes;            /* 17 */
+    int32_t batch_rows;        /* G*P rows of features / priors / values */
+    int32_t max_nodes;
+    int32_t budget;
+    int32_t table_len;         /* entries expected by azsp_set_tables */
+    int32_t stage_capacity;    /* max samples per game */
+    int64_t device_bytes;      /* HBM allocated by the engine */
+    int32_t node_record_bytes;
+    int32_t reserved;
+} AzspGeometry;
+
+int azsp_create(const AzspConfig* cfg, void** out_engine);
+int azsp_destroy(void* engine);
+const char* azsp_last_error(void* engine);
+int azsp_geometry(void* engine, AzspGeometry* out);
+
+/* pb_c(n) = log((1 + n + base)/base) + init for n = 0..len-1, as the reference evaluates it for a
+ * node whose visit count is an np.float32 (pbc_np) or a Python float (fresh root, pbc_py), and
+ * float32(sqrt(n)) (mcts_v2.py:99-102).  Host pointers; copied. */
+int azsp_set_tables(void* engine, const double* pbc_np_host, const double* pbc_py_host, const float* sqrt32_host, int32_t len);
+
+/* Injected randomness for parity runs: noise[G][moves][A] (np.random.dirichlet outputs) and
+ * uniforms[G][moves][16] (the u of each np.random.choice draw).  Host pointers; copied. */
+int azsp_set_injection(void* engine, const double* noise_host, const double* uniforms_host, int32_t moves);
+
+/* Start a new game in every slot (env.reset()). */
+int azsp_reset_games(void* engine, void* stream);
+
+/* Standalone environment kernels.  actions_dev[G]: action, -1 = resign (Go), -2 = no-op (export only).
+ * Outputs (each may be NULL): board int8[G][N*N] (reference colour ids), legal int8[G][A],
+ * scalars int32[G][12] = {ko, caps_black, caps_white, steps, to_play, done, reward, winner, area_black,
+ * area_white, illegal, last_was_pass}, obs int8[G][17][N][N]. */
+int azsp_env_step(void* engine, const int32_t* actions_dev, int8_t* board_dev, int8_t* legal_dev, int32_t* scalars_dev,
+                  int8_t* obs_dev, void* stream);
+
+/* Load an arbitrary position into slot `slot` and make it the (fresh, unevaluated) search root.
+ * board_host int8[N*N] and hist_host int8[8][N*N] (newest first, hist[0] == board) use reference colour ids. */
+int azsp_set_state(void* engine, int32_t slot, const int8_t* board_host, const int8_t* hist_host, int32_t to_play,
+                   int32_t steps, int32_t ko, int32_t last_was_pass, int32_t caps_black, int32_t caps_white, void* stream);
+
+/* Drop-in mode: hand the Dirichlet draw of this search to the engine (noise_host double[G][A] or NULL). */
+int azsp_begin_move(void* engine, const double* noise_host, void* stream);
+
+int azsp_select(void* engine, void* features_dev, uint8_t* valid_dev, void* stream);
+int azsp_expand_backup(void* engine, const float* priors_dev, const float* values_dev, void* stream);
+int azsp_round(void* engine, const float* priors_dev, const float* values_dev, void* features_dev, uint8_t* valid_dev,
+               void* stream);
+
+/* status_host int32[G][8] = {status, ply, root_N, n_leaves, last_move, games_done, root_eval_pending, noise_pending};
+ * q_host double[G][2] = {root_Q, best_child_Q} of the last finished search.  Synchronises the stream. */
+int azsp_get_status(void* engine, int32_t* status_host, double* q_host, void* stream);
+
+/* Search outputs of `slot` at log index `ply` (log_moves or drop-in mode): pi double[A], child_N float[A],
+ * q double[4] = {root_Q, best_child_Q, root_N, move}.  Synchronises the stream. */
+int azsp_get_search(void* engine, int32_t slot, int32_t ply, double* pi_host, float* child_n_host, double* q_host, void* stream);
+
+/* Drop-in mode: the caller's chosen moves (int32[G], host); re-roots each tree on the chosen child. */
+int azsp_commit_move(void* engine, const int32_t* moves_host, void* stream);
+
+/* Collect finished games.  states int8[cap][17][N][N], pi float[cap][A], z float[cap] receive the samples of
+ * whole games back to back; games_host int32[max_games][16] = {start, length, winner(ref id, 0 none), area_black,
+ * area_white, num_passes, resigned, resign_disabled, marked_for_resign, could_won, marked_player(ref id, 0 none),
+ * uid, training_steps, reward, last_player(ref id), slot}.  Synchronises the stream. */
+int azsp_harvest(void* engine, int8_t* states_dev, float* pi_dev, float* z_dev, int32_t sample_capacity,
+                 int32_t* games_host, int32_t max_games, int32_t* n_samples_out, int32_t* n_games_out, void* stream);
+
+/* counters_host uint64[16]: simulations, best_child calls, backup edges, leaves, duplicate leaves, terminal hits,
+ * moves, games, root evaluations, nodes created, game-rounds, buffer stalls. */
+int azsp_counters(void* engine, uint64_t* counters_host, int32_t reset, void* stream);
+
+/* Dihedral-8 transform of a batch (no engine needed): op 0 identity, 1 h-flip, 2 v-flip, 3/4/5 = rot90/180/270
+ * counter-clockwise (the reference's five), 6 transpose, 7 anti-transpose.  elem_size in bytes (1, 2, 4 or 8).
+ * states [B][C][N][N], pi [B][A] with A == N*N or N*N+1 (pass column untouched). */
+int azsp_dihedral(const void* states_in_dev, void* states_out_dev, int32_t state_elem_size, const void* pi_in_dev,
+                  void* pi_out_dev, int32_t pi_elem_size, int32_t batch, int32_t channels, int32_t board_size,
+                  int32_t num_actions, int32_t op, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZSP_H */

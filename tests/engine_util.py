@@ -1,0 +1,160 @@
+"""Shared drivers for the engine parity tests.  The same functions run against
+  * the host twin (tests/hosttwin, CPU, `-m "not gpu"`): identical engine source, WaveHost policy
+  * libazsp.so on a MI355X (`-m gpu`): the product
+and compare with the golden vectors produced by the reference / with the CPU oracle."""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+from alpha_zero_amd import _abi
+from alpha_zero_amd.core.engine import Engine, EngineConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_twin = None
+
+
+def hosttwin_binding():
+    """Builds (once) and loads the host twin -- test infrastructure, never used by the product."""
+    global _twin
+    if _twin is None:
+        src = os.path.join(HERE, "hosttwin", "azsp_host.cpp")
+        so = os.path.join(HERE, "hosttwin", "libazsp_hosttwin.so")
+        deps = [src] + [os.path.join(ROOT, "alpha_zero_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "alpha_zero_amd", "csrc"))
+                        if f.endswith(".h")] + [os.path.join(ROOT, "include", "azsp.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+        _twin = _abi.Binding(ctypes.CDLL(so), "hosttwin")
+    return _twin
+
+
+def gpu_binding():
+    from alpha_zero_amd import _lib
+
+    return _lib.load(require_gpu=True)
+
+
+def backend(kind):
+    """kind: 'host' | 'gpu' -> (binding, torch device string)"""
+    return (hosttwin_binding(), "cpu") if kind == "host" else (gpu_binding(), "cuda")
+
+
+# ---------------------------------------------------------------------------------------------------
+# environment replay: G games advance in lock-step through azsp_env_step
+# ---------------------------------------------------------------------------------------------------
+def replay_env_batch(kind, game, n, move_lists, num_to_win=5, max_steps=0, komi=7.5, want_obs=True):
+    """Returns per game (played, state_digest16, obs_digest16, final scalars row)."""
+    binding, dev = backend(kind)
+    G = len(move_lists)
+    eng = Engine(binding, EngineConfig(game=game, board_size=n, num_games=G, num_parallel=1, num_simulations=2, num_to_win=num_to_win,
+                                       max_steps=max_steps, komi=komi, stop_after_move=True), device=dev)
+    hs = [hashlib.sha256() for _ in range(G)]
+    ho = [hashlib.sha256() for _ in range(G)]
+    lens = np.array([len(m) for m in move_lists])
+    T = int(lens.max()) if G else 0
+    played = np.zeros(G, dtype=np.int64)
+    alive = np.ones(G, dtype=bool)
+    out = eng.env_step(None, want_obs=want_obs)
+
+    def absorb(out, mask):
+        sc = out["scalars"]
+        rec = np.concatenate([
+            out["board"].reshape(G, -1).view(np.uint8), out["legal"].view(np.uint8),
+            np.ascontiguousarray(sc[:, [0, 1, 2, 3]].astype("<i2")).view(np.uint8).reshape(G, 8),
+            np.ascontiguousarray(sc[:, [4, 5, 6]].astype(np.int8)).view(np.uint8)], axis=1)
+        obs = out["obs"].reshape(G, -1) if want_obs else None
+        for g in np.flatnonzero(mask):
+            hs[g].update(rec[g].tobytes())
+            if want_obs:
+                ho[g].update(obs[g].tobytes())
+
+    absorb(out, alive)
+    final = out["scalars"].copy()
+    for t in range(T):
+        acts = np.full(G, -2, dtype=np.int32)
+        for g in range(G):
+            if alive[g] and t < lens[g]:
+                acts[g] = move_lists[g][t]
+            else:
+                alive[g] = False
+        if not alive.any():
+            break
+        out = eng.env_step(acts, want_obs=want_obs)
+        ill = out["scalars"][:, 10] != 0
+        stepped = alive & ~ill
+        alive &= ~ill
+        absorb(out, stepped)
+        played += stepped
+        final[stepped] = out["scalars"][stepped]
+        alive &= out["scalars"][:, 5] == 0  # stop after the game ended
+    eng.close()
+    return [(int(played[g]), hs[g].digest()[:16], ho[g].digest()[:16], final[g]) for g in range(G)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# search / actor replay against an MCTS golden file
+# ---------------------------------------------------------------------------------------------------
+def run_golden_selfplay(kind, G_gold, eval_batch):
+    """Runs the batched actor on the games of one golden file with the recorded randomness injected.
+    Returns (engine logs per game, harvest tuple)."""
+    g, cfg = G_gold.g, G_gold.cfg
+    binding, dev = backend(kind)
+    ngames = cfg["games"]
+    idxs = [G_gold.moves_of_game(i) for i in range(ngames)]
+    M = max(len(ix) for ix in idxs) + 1
+    A = G_gold.A
+    noise = np.zeros((ngames, M, A))
+    unif = np.zeros((ngames, M, 16))
+    for gi, ix in enumerate(idxs):
+        noise[gi, : len(ix)] = g["noise"][ix]
+        unif[gi, : len(ix)] = g["uniforms"][ix]
+    ec = EngineConfig(
+        game=cfg["game"], board_size=cfg["n"], num_games=ngames, num_parallel=cfg["parallel"], num_simulations=cfg["sims"],
+        c_puct_base=cfg["c_puct_base"], c_puct_init=cfg["c_puct_init"], root_noise=cfg.get("root_noise", True),
+        deterministic=cfg.get("deterministic", False), reuse_tree=cfg.get("reuse", True), warm_up_steps=cfg["warm_up_steps"],
+        resign_threshold=cfg.get("resign_threshold", -1.0), check_resign_after_steps=cfg.get("check_resign_after_steps", 40),
+        force_resign_disabled=1 if cfg.get("resign_disabled", True) else 0, inject_random=True, inject_moves=M,
+        max_plies=cfg.get("max_moves") or 0, stop_at_game_end=True, feature_dtype=_abi.FEAT_I8, log_moves=True, log_capacity=M)
+    eng = Engine(binding, ec, device=dev)
+    eng.set_injection(noise, unif)
+    eng.reset_games()
+    n_evals = np.zeros((ngames, M), dtype=np.int64)
+    rounds = 0
+    eng.select()
+    while True:
+        valid = eng.valid.cpu().numpy().astype(bool)
+        st, _ = eng.status()
+        if not valid.any() and np.all(st[:, 0] == _abi.ST_IDLE):
+            break
+        feats = eng.features.cpu().numpy()
+        pri = np.zeros((eng.rows, A), dtype=np.float32)
+        val = np.zeros(eng.rows, dtype=np.float32)
+        rows = np.flatnonzero(valid)
+        if len(rows):
+            p, v = eval_batch(feats[rows], A)
+            pri[rows], val[rows] = p, v
+            for r in rows:
+                gi = r // eng.P
+                n_evals[gi, min(st[gi, 1], M - 1)] += 1
+        eng.priors.copy_(torch.from_numpy(pri))
+        eng.values.copy_(torch.from_numpy(val))
+        eng.round()
+        rounds += 1
+        assert rounds < 200000
+    logs = []
+    st, _ = eng.status()
+    for gi, ix in enumerate(idxs):
+        per = []
+        for k in range(len(ix)):
+            pi, cn, q = eng.get_search(gi, k)
+            per.append(dict(pi=pi, child_N=cn, root_q=q[0], child_q=q[1], move=int(q[3])))
+        logs.append(per)
+    states, pi, z, games = eng.harvest()
+    hv = (states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy(), games)
+    counters = eng.counters()
+    eng.close()
+    return logs, hv, n_evals, counters
