@@ -153,8 +153,129 @@ def run_golden_selfplay(kind, G_gold, eval_batch):
             pi, cn, q = eng.get_search(gi, k)
             per.append(dict(pi=pi, child_N=cn, root_q=q[0], child_q=q[1], move=int(q[3])))
         logs.append(per)
-    states, pi, z, games = eng.harvest()
-    hv = (states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy(), games)
+    parts, base = [], 0
+    while True:  # the output window may be smaller than all finished games: harvest until drained
+        states, pi, z, games = eng.harvest()
+        if len(games) == 0:
+            break
+        games = games.copy()
+        games[:, 0] += base
+        base += len(z)
+        parts.append((states.cpu().numpy().copy(), pi.cpu().numpy().copy(), z.cpu().numpy().copy(), games))
+    if parts:
+        hv = tuple(np.concatenate([p[i] for p in parts]) for i in range(4))
+    else:
+        hv = (np.zeros((0, 17, eng.N, eng.N), np.int8), np.zeros((0, A), np.float32), np.zeros(0, np.float32), np.zeros((0, 16), np.int32))
     counters = eng.counters()
     eng.close()
     return logs, hv, n_evals, counters
+
+
+# ---------------------------------------------------------------------------------------------------
+# engine vs CPU oracle on fresh seeded games (no golden file needed; used by -m gpu tests and smoke())
+# ---------------------------------------------------------------------------------------------------
+def oracle_selfplay(game, n, sims, P, ngames, seed, max_moves, eval_func_factory, warm_up_steps=4, resign_threshold=-1.0,
+                    resign_disabled=True, check_resign_after_steps=40, max_steps=0):
+    """Plays `ngames` games with the CPU oracle; returns (noise, uniforms, per-move logs, game results)."""
+    from oracle import actor, mcts
+    from oracle.envs import OracleGoEnv, OracleGomokuEnv
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    A = n * n + (1 if game == "go" else 0)
+    M = max_moves + 1
+    noise = rng.dirichlet(np.full(A, 0.03), size=(ngames, M))
+    unif = rng.random((ngames, M, 16))
+    logs, results = [], []
+    for gi in range(ngames):
+        env = OracleGoEnv(n, max_steps=max_steps) if game == "go" else OracleGomokuEnv(n)
+        per = []
+
+        def on_move(k, env_, move, pi, rq, cq, root):
+            cn = root.N[root.parent[root.root]].copy() if root is not None else None
+            per.append(dict(move=int(move), pi=np.asarray(pi, dtype=np.float64), root_q=float(rq), child_q=float(cq), child_N=cn))
+
+        seq, stats = actor.play_one_game(
+            env, eval_func_factory(A), num_simulations=sims, num_parallel=P, warm_up_steps=warm_up_steps,
+            check_resign_after_steps=check_resign_after_steps, resign_threshold=resign_threshold, resign_disabled=resign_disabled,
+            rand_for_move=lambda k: mcts.InjectedRand(noise[gi, k], unif[gi, k]), on_move=on_move, max_moves=max_moves)
+        logs.append(per)
+        results.append((seq, stats))
+    return noise, unif, logs, results
+
+
+def engine_selfplay_injected(kind, game, n, sims, P, noise, unif, max_moves, eval_batch, warm_up_steps=4, resign_threshold=-1.0,
+                             resign_disabled=True, check_resign_after_steps=40, max_steps=0, feature_dtype=_abi.FEAT_I8):
+    binding, dev = backend(kind)
+    ngames, M, A = noise.shape
+    ec = EngineConfig(game=game, board_size=n, num_games=ngames, num_parallel=P, num_simulations=sims, warm_up_steps=warm_up_steps,
+                      resign_threshold=resign_threshold, check_resign_after_steps=check_resign_after_steps,
+                      force_resign_disabled=1 if resign_disabled else 0, inject_random=True, inject_moves=M, max_plies=max_moves,
+                      stop_at_game_end=True, feature_dtype=feature_dtype, log_moves=True, log_capacity=M, max_steps=max_steps)
+    eng = Engine(binding, ec, device=dev)
+    eng.set_injection(noise, unif)
+    eng.reset_games()
+    eng.select()
+    rounds = 0
+    while True:
+        valid = eng.valid.cpu().numpy().astype(bool)
+        st, _ = eng.status()
+        if not valid.any() and np.all(st[:, 0] == _abi.ST_IDLE):
+            break
+        rows = np.flatnonzero(valid)
+        pri = np.zeros((eng.rows, A), dtype=np.float32)
+        val = np.zeros(eng.rows, dtype=np.float32)
+        if len(rows):
+            feats = eng.features[torch.as_tensor(rows, device=eng.features.device)].to(torch.float32).cpu().numpy().astype(np.int8)
+            pri[rows], val[rows] = eval_batch(feats, A)
+        eng.priors.copy_(torch.from_numpy(pri))
+        eng.values.copy_(torch.from_numpy(val))
+        eng.round()
+        rounds += 1
+        assert rounds < 500000
+    st, _ = eng.status()
+    logs = []
+    for gi in range(ngames):
+        per = []
+        for k in range(min(int(st[gi, 1]), M)):
+            pi, cn, q = eng.get_search(gi, k)
+            per.append(dict(pi=pi, child_N=cn, root_q=q[0], child_q=q[1], move=int(q[3])))
+        logs.append(per)
+    states, pi, z, games = eng.harvest(sample_capacity=max(64, ngames * eng.geo.stage_capacity), max_games=2 * ngames)
+    hv = (states.cpu().numpy().copy(), pi.cpu().numpy().copy(), z.cpu().numpy().copy(), games.copy())
+    cnt = eng.counters()
+    eng.close()
+    return logs, hv, cnt
+
+
+def compare_engine_with_oracle(kind, game, n, sims, P, ngames, seed, max_moves, **kw):
+    """Bit-exact comparison of the engine with the oracle on seeded games; returns the engine counters."""
+    from alpha_zero_amd.core.pipeline import game_stats_from_row
+    from synth_eval import eval_batch, make_eval_func
+
+    noise, unif, ologs, ores = oracle_selfplay(game, n, sims, P, ngames, seed, max_moves, lambda A: make_eval_func(A), **kw)
+    elogs, (states, pis, zs, games), cnt = engine_selfplay_injected(kind, game, n, sims, P, noise, unif, max_moves, eval_batch, **kw)
+    by_slot = {int(r[15]): r for r in games}
+    for gi in range(ngames):
+        assert len(elogs[gi]) == len(ologs[gi]), (gi, len(elogs[gi]), len(ologs[gi]))
+        for k, (e, o) in enumerate(zip(elogs[gi], ologs[gi])):
+            where = (game, n, gi, k)
+            assert e["move"] == o["move"], where
+            if o["child_N"] is not None:
+                assert np.array_equal(e["child_N"], o["child_N"]), where
+            assert e["root_q"] == o["root_q"] and e["child_q"] == o["child_q"], where
+            if game == "go":
+                assert np.array_equal(e["pi"], o["pi"]), where
+            else:
+                assert np.abs(e["pi"] - o["pi"]).max() <= 1e-6, where
+        seq, stats = ores[gi]
+        if seq is None:
+            assert gi not in by_slot
+            continue
+        row = by_slot[gi]
+        s0, ln = int(row[0]), int(row[1])
+        assert ln == len(seq)
+        assert np.array_equal(states[s0:s0 + ln], np.stack([t.state for t in seq]))
+        assert np.array_equal(zs[s0:s0 + ln], np.array([t.value for t in seq], dtype=np.float32))
+        est = game_stats_from_row(row, game=game, komi=7.5, resign_threshold=kw.get("resign_threshold", -1.0))
+        assert est == stats, (est, stats)
+    return cnt

@@ -1,0 +1,88 @@
+"""GPU tier (MI355X): the HIP build (libazsp.so) through the C ABI vs the reference's golden vectors
+and vs the CPU oracle.  Integer / board work is bit-exact; search statistics are bit-exact under
+injected randomness (visit counts, moves, Q, Go pi); Gomoku pi within 1e-6 (float32 np.power in the
+reference is platform dependent)."""
+import os
+
+import numpy as np
+import pytest
+
+import engine_util as eu
+import golden_mcts
+import parity_checks as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_go9_all_shipped_sgf_games(golden_dir):
+    bad, n = pc.check_go_file("gpu", os.path.join(golden_dir, "go9_sgf.npz"), 9, chunk=4096)
+    assert n == 10288 and not bad, bad[:5]
+
+
+@pytest.mark.parametrize("n", [5, 9, 13, 19])
+def test_gpu_go_random_playouts(golden_dir, n):
+    bad, cnt = pc.check_go_file("gpu", os.path.join(golden_dir, f"go{n}_random.npz"), n)
+    assert cnt > 0 and not bad
+
+
+def test_gpu_gomoku_playouts_and_lines(golden_dir):
+    bad, cnt = pc.check_gomoku_file("gpu", os.path.join(golden_dir, "gomoku.npz"))
+    assert cnt == 536 and not bad
+
+
+@pytest.mark.parametrize("name", golden_mcts.names())
+def test_gpu_search_and_actor_match_reference(name):
+    pc.check_mcts_golden("gpu", name)
+
+
+@pytest.mark.parametrize("game,n,sims,P,ngames,moves,kw", [
+    ("go", 9, 200, 8, 8, 30, {}),
+    ("go", 5, 48, 4, 16, 60, dict(resign_threshold=-0.3, resign_disabled=False, check_resign_after_steps=5)),
+    ("go", 13, 64, 8, 2, 16, {}),
+    ("go", 19, 64, 8, 2, 10, {}),
+    ("gomoku", 13, 200, 8, 4, 24, {}),
+    ("gomoku", 7, 40, 1, 8, 49, {}),
+    ("gomoku", 15, 64, 8, 2, 20, {}),
+])
+def test_gpu_engine_matches_oracle_on_fresh_games(game, n, sims, P, ngames, moves, kw):
+    cnt = eu.compare_engine_with_oracle("gpu", game, n, sims, P, ngames, seed=100 + n + sims, max_moves=moves, **kw)
+    assert cnt["sims"] > 0
+
+
+def test_gpu_env_vs_oracle_random_playouts_4096_games():
+    """BASELINE size G = 4096: random legal playouts chosen from the engine's own legal masks, then the
+    whole trajectories are replayed through the C oracle and compared position by position."""
+    from alpha_zero_amd.core.engine import Engine, EngineConfig
+    from oracle.envs import OracleGoEnv
+
+    binding, dev = eu.backend("gpu")
+    G, n = 4096, 9
+    eng = Engine(binding, EngineConfig(game="go", board_size=n, num_games=G, num_parallel=1, num_simulations=2, stop_after_move=True), device=dev)
+    rng = np.random.Generator(np.random.PCG64(7))
+    out = eng.env_step(None)
+    traj = []
+    alive = np.ones(G, dtype=bool)
+    for t in range(60):
+        legal = out["legal"].astype(bool)
+        legal[:, -1] = False
+        acts = np.full(G, -2, dtype=np.int32)
+        r = rng.random((G, legal.shape[1])) * legal
+        pick = r.argmax(axis=1)
+        has = legal.any(axis=1)
+        acts[alive & has] = pick[alive & has]
+        acts[alive & ~has] = n * n
+        out = eng.env_step(acts)
+        traj.append((acts.copy(), out["board"].copy(), out["legal"].copy(), out["scalars"].copy()))
+        assert not out["scalars"][alive, 10].any()
+        alive &= out["scalars"][:, 5] == 0
+    eng.close()
+    for g in range(0, G, 37):  # the oracle is the slow side: check every 37th game completely
+        env = OracleGoEnv(n)
+        env.reset()
+        for acts, board, legal, sc in traj:
+            if acts[g] == -2:
+                break
+            env.step(int(acts[g]))
+            assert np.array_equal(env.board, board[g])
+            assert np.array_equal(env.legal_actions.astype(np.int8), legal[g])
+            assert env.ko == sc[g, 0] and env.caps == (sc[g, 1], sc[g, 2]) and env.steps == sc[g, 3]
