@@ -1,0 +1,114 @@
+"""Policy/value ResNet of the self-play path on PyTorch-ROCm (reference: alpha_zero/core/network.py:85-173).
+
+`AlphaZeroNet` keeps the reference's module tree, so its state_dict keys line up one-to-one
+(`conv_block.{0,1}`, `res_blocks.{i}.conv_block{1,2}.{0,1}`, `policy_head.{0,1,4}`,
+`value_head.{0,1,4,6}`) and shipped / learner checkpoints load unchanged.
+
+`InferenceNet` is the leaf evaluator the engine calls every round: eval-mode BatchNorm folded into
+the preceding convolution, channels-last, optional bf16/fp16, softmax over all A actions in fp32
+(priors are never masked or renormalised: pipeline.py:102-117), outputs written straight into the
+engine's priors/values tensors.  MFMA is used here and only here (MIOpen / hipBLASLt kernels).
+"""
+from typing import Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def _conv_bn(cin, cout, k, pad):
+    return [nn.Conv2d(cin, cout, kernel_size=k, stride=1, padding=pad, bias=False), nn.BatchNorm2d(cout)]
+
+
+class ResNetBlock(nn.Module):
+    """conv-BN-ReLU-conv-BN, + skip, ReLU (network.py:42-82)."""
+
+    def __init__(self, num_filters: int) -> None:
+        super().__init__()
+        self.conv_block1 = nn.Sequential(*_conv_bn(num_filters, num_filters, 3, 1), nn.ReLU())
+        self.conv_block2 = nn.Sequential(*_conv_bn(num_filters, num_filters, 3, 1))
+
+    def forward(self, x):
+        return F.relu(self.conv_block2(self.conv_block1(x)) + x)
+
+
+class AlphaZeroNet(nn.Module):
+    def __init__(self, input_shape: Tuple, num_actions: int, num_res_block: int = 19, num_filters: int = 256,
+                 num_fc_units: int = 256, gomoku: bool = False) -> None:
+        super().__init__()
+        c, h, w = input_shape
+        pad = 3 if gomoku else 1  # network.py:101-105: Gomoku pads the stem by 3 -> spatial size grows by 4
+        oh, ow = h + 2 * pad - 2, w + 2 * pad - 2
+        self.conv_block = nn.Sequential(*_conv_bn(c, num_filters, 3, pad), nn.ReLU())
+        self.res_blocks = nn.Sequential(*[ResNetBlock(num_filters) for _ in range(num_res_block)])
+        self.policy_head = nn.Sequential(*_conv_bn(num_filters, 2, 1, 0), nn.ReLU(), nn.Flatten(), nn.Linear(2 * oh * ow, num_actions))
+        self.value_head = nn.Sequential(*_conv_bn(num_filters, 1, 1, 0), nn.ReLU(), nn.Flatten(), nn.Linear(oh * ow, num_fc_units),
+                                        nn.ReLU(), nn.Linear(num_fc_units, 1), nn.Tanh())
+        for m in self.modules():  # network.py:30-39
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_uniform_(m.weight, nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        f = self.res_blocks(self.conv_block(x))
+        return self.policy_head(f), self.value_head(f)
+
+
+def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """Eval-mode BN(conv(x)) == conv'(x) + b'."""
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return conv.weight * s.view(-1, 1, 1, 1), bn.bias - bn.running_mean * s
+
+
+class InferenceNet(nn.Module):
+    """Frozen, BN-folded, channels-last copy of an AlphaZeroNet for the engine's leaf batches."""
+
+    def __init__(self, net: AlphaZeroNet, dtype=torch.bfloat16, channels_last=True):
+        super().__init__()
+        net = net.eval()
+        self.dtype = dtype
+        self.mf = torch.channels_last if channels_last else torch.contiguous_format
+        self.stem_pad = net.conv_block[0].padding[0]
+        with torch.no_grad():
+            convs = [_fold(net.conv_block[0], net.conv_block[1])]
+            for blk in net.res_blocks:
+                convs.append(_fold(blk.conv_block1[0], blk.conv_block1[1]))
+                convs.append(_fold(blk.conv_block2[0], blk.conv_block2[1]))
+            self.n_blocks = len(net.res_blocks)
+            self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
+            self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
+            pw, pb = _fold(net.policy_head[0], net.policy_head[1])
+            vw, vb = _fold(net.value_head[0], net.value_head[1])
+            # both 1x1 heads share one convolution (2 policy planes + 1 value plane)
+            self.head_w = nn.Parameter(torch.cat([pw, vw], 0).to(dtype).contiguous(memory_format=self.mf), requires_grad=False)
+            self.head_b = nn.Parameter(torch.cat([pb, vb], 0).to(dtype), requires_grad=False)
+            self.pol_fc_w = nn.Parameter(net.policy_head[4].weight.to(dtype), requires_grad=False)
+            self.pol_fc_b = nn.Parameter(net.policy_head[4].bias.to(dtype), requires_grad=False)
+            self.val_fc1_w = nn.Parameter(net.value_head[4].weight.to(dtype), requires_grad=False)
+            self.val_fc1_b = nn.Parameter(net.value_head[4].bias.to(dtype), requires_grad=False)
+            self.val_fc2_w = nn.Parameter(net.value_head[6].weight.to(dtype), requires_grad=False)
+            self.val_fc2_b = nn.Parameter(net.value_head[6].bias.to(dtype), requires_grad=False)
+
+    @torch.no_grad()
+    def forward(self, x, priors_out=None, values_out=None):
+        """x: [B,17,N,N] any dtype -> (priors fp32 [B,A], values fp32 [B])."""
+        x = x.to(self.dtype).contiguous(memory_format=self.mf)
+        x = F.relu_(F.conv2d(x, self.w[0], self.b[0], padding=self.stem_pad))
+        for i in range(self.n_blocks):
+            y = F.relu_(F.conv2d(x, self.w[1 + 2 * i], self.b[1 + 2 * i], padding=1))
+            y = F.conv2d(y, self.w[2 + 2 * i], self.b[2 + 2 * i], padding=1)
+            x = F.relu_(y.add_(x))
+        h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
+        B = h.shape[0]
+        pol = h[:, :2].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)  # NCHW flatten order (nn.Flatten)
+        val = h[:, 2:].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)
+        logits = F.linear(pol, self.pol_fc_w, self.pol_fc_b)
+        v = torch.tanh(F.linear(F.relu_(F.linear(val, self.val_fc1_w, self.val_fc1_b)), self.val_fc2_w, self.val_fc2_b))
+        pri = torch.softmax(logits.float(), dim=-1)
+        v = v.float().squeeze(1)
+        if priors_out is not None:
+            priors_out.copy_(pri)
+            values_out.copy_(v)
+            return priors_out, values_out
+        return pri, v

@@ -34,3 +34,162 @@ def game_stats_from_row(row, game: str, komi: float = 7.5, resign_threshold: flo
         stats["marked_resign_player"] = "B" if mp == 1 else "W" if mp == -1 else None
         stats["resign_threshold"] = resign_threshold
     return stats
+
+
+# =====================================================================================================
+# Batched self-play actor
+# =====================================================================================================
+import time  # noqa: E402
+
+import torch  # noqa: E402
+
+from .. import _abi  # noqa: E402
+from .engine import Engine, EngineConfig  # noqa: E402
+from .network import AlphaZeroNet, InferenceNet  # noqa: E402
+from .replay import Transition  # noqa: E402
+
+_FEAT_OF = {torch.float32: _abi.FEAT_F32, torch.bfloat16: _abi.FEAT_BF16, torch.float16: _abi.FEAT_F16}
+
+
+class SelfPlayActor:
+    """G concurrent self-play games on one GPU: replaces G `run_selfplay_actor_loop` processes
+    (pipeline.py:166-286).  One round = engine kernel (expand/backup of the previous leaf batch, end-of-move
+    work, selection of the next P leaves per game, observation planes) + one network forward on G*P rows.
+    Nothing returns to the host during a round; finished games are collected with `harvest()`."""
+
+    def __init__(self, network: AlphaZeroNet, *, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8,
+                 c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
+                 resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.bfloat16,
+                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False):
+        from .. import _lib
+
+        self.binding = binding or _lib.load(require_gpu=True)
+        self.device = torch.device(device)
+        self.game, self.komi, self.resign_threshold = game, komi, resign_threshold
+        self.net_dtype = net_dtype
+        self.use_graph = use_graph and self.device.type == "cuda"
+        self.cfg = EngineConfig(
+            game=game, board_size=board_size, num_games=num_games, num_parallel=num_parallel, num_simulations=num_simulations,
+            c_puct_base=c_puct_base, c_puct_init=c_puct_init, warm_up_steps=warm_up_steps, komi=komi, num_to_win=num_to_win,
+            resign_threshold=resign_threshold, check_resign_after_steps=check_resign_after_steps,
+            disable_resign_ratio=disable_resign_ratio, root_noise=root_noise, deterministic=deterministic,
+            feature_dtype=_FEAT_OF[net_dtype], training_steps=training_steps, seed=seed, rank=rank,
+            device_index=self.device.index or 0)
+        self.engine = Engine(self.binding, self.cfg, device=self.device)
+        self.engine.reset_games()
+        self._graph = None
+        self.rounds = 0
+        self.set_network(network, training_steps)
+
+    # -- weights ---------------------------------------------------------------------------------------
+    def set_network(self, network: AlphaZeroNet, training_steps=0):
+        """Checkpoint hot-swap (pipeline.py:232-239): new weights take effect at the next round."""
+        self.infer = InferenceNet(network, dtype=self.net_dtype).to(self.device)
+        self.training_steps = training_steps
+        self._graph = None
+
+    def _forward(self):
+        e = self.engine
+        self.infer(e.features, e.priors, e.values)
+
+    def _capture(self):
+        e = self.engine
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(3):  # let MIOpen pick its kernels before capture
+                self._forward()
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._forward()
+        self._graph = g
+
+    # -- rounds ----------------------------------------------------------------------------------------
+    def run_round(self, ev_pair=None):
+        e = self.engine
+        if ev_pair is not None:
+            ev_pair[0].record()
+        e.round()
+        if ev_pair is not None:
+            ev_pair[1].record()
+        if self.use_graph:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        else:
+            self._forward()
+        if ev_pair is not None and len(ev_pair) > 2:
+            ev_pair[2].record()
+        self.rounds += 1
+
+    def run_rounds(self, n):
+        for _ in range(n):
+            self.run_round()
+
+    # -- output ----------------------------------------------------------------------------------------
+    def harvest_tensors(self):
+        return self.engine.harvest()
+
+    def harvest(self):
+        """Finished games as the reference actor emits them: [(game_seq: list[Transition], stats: dict)]
+        (pipeline.py:283, :356-380).  pi_prob is float64 for Go and float32 for Gomoku like the reference."""
+        states, pi, z, games = self.engine.harvest()
+        if len(games) == 0:
+            return []
+        states, pi, z = states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+        out = []
+        for row in games:
+            s0, ln = int(row[0]), int(row[1])
+            pis = pi[s0:s0 + ln].astype(np.float64) if self.game == "go" else pi[s0:s0 + ln]
+            seq = [Transition(state=states[s0 + i].copy(), pi_prob=pis[i].copy(), value=float(z[s0 + i])) for i in range(ln)]
+            stats = game_stats_from_row(row, self.game, self.komi, self.resign_threshold)
+            stats["training_steps"] = self.training_steps  # tag of the weights in use (pipeline.py:271, :492)
+            out.append((seq, stats))
+        return out
+
+    def counters(self, reset=False):
+        return self.engine.counters(reset)
+
+
+def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_simulations, num_parallel, c_puct_base, c_puct_init,
+                            warm_up_steps, check_resign_after_steps, disable_resign_ratio, save_sgf_dir=None, save_sgf_interval=0,
+                            logs_dir=None, load_ckpt=None, log_level="INFO", var_ckpt=None, var_resign_threshold=None,
+                            ckpt_event=None, stop_event=None, num_games=4096, net_dtype=torch.bfloat16, harvest_every=64):
+    """Same role and argument list as the reference actor entry point (pipeline.py:166-189), extended by
+    `num_games`: one call drives `num_games` games on `device` and puts (game_seq, stats) tuples on
+    `data_queue` exactly as `num_games` reference actors would."""
+    import os
+
+    game = "go" if env.has_pass_move else "gomoku"
+    training_steps = 0
+    if load_ckpt is not None and os.path.exists(load_ckpt):  # pipeline.py:208-212
+        st = torch.load(load_ckpt, map_location="cpu", weights_only=False)
+        network.load_state_dict(st["network"])
+        training_steps = st["training_steps"]
+    thr = var_resign_threshold.value if (var_resign_threshold is not None and env.has_resign_move) else -1.0
+    actor = SelfPlayActor(network, game=game, board_size=env.board_size, num_games=num_games, num_simulations=num_simulations,
+                          num_parallel=num_parallel, c_puct_base=c_puct_base, c_puct_init=c_puct_init, warm_up_steps=warm_up_steps,
+                          check_resign_after_steps=check_resign_after_steps, disable_resign_ratio=disable_resign_ratio,
+                          resign_threshold=thr, komi=getattr(env, "komi", 7.5), num_to_win=getattr(env, "num_to_win", 5),
+                          seed=seed, rank=rank, device=device, net_dtype=net_dtype, training_steps=training_steps)
+    last_ckpt, t_last = None, time.time()
+    while stop_event is None or not stop_event.is_set():
+        if ckpt_event is not None and ckpt_event.is_set():
+            continue
+        if var_ckpt is not None:
+            new_ckpt = var_ckpt.value.decode("utf-8") if isinstance(var_ckpt.value, bytes) else str(var_ckpt.value)
+            if new_ckpt != "" and new_ckpt != last_ckpt and os.path.exists(new_ckpt):  # pipeline.py:232-239
+                st = torch.load(new_ckpt, map_location="cpu", weights_only=False)
+                network.load_state_dict(st["network"])
+                actor.set_network(network, st["training_steps"])
+                last_ckpt = new_ckpt
+        actor.run_rounds(harvest_every)
+        finished = actor.harvest()
+        now = time.time()
+        for seq, stats in finished:
+            stats["time_per_game"] = round((now - t_last) * num_games / max(1, len(finished)), 4)
+            data_queue.put((seq, stats))
+        if finished:
+            t_last = now

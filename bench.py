@@ -1,0 +1,205 @@
+"""bench.py -- self-play moves/sec of the batched engine (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 9x9 Go, G = 4096
+concurrent games per GPU, 200 sims/move with the reference budget semantics (root.N >= sims + P,
+inherited visits count: mcts_v2.py:568), num_parallel P = 8, 10-block x 128-filter AlphaZeroNet
+(random Kaiming init, torch.manual_seed(1)), Dirichlet root noise, sub-tree reuse, resign disabled.
+One "step" = one engine round over all games: expand/backup of the previous G*P leaf batch, end-of-move
+work, selection of the next P leaves per game, observation planes, and the network forward on G*P rows.
+All inputs live in HBM; nothing crosses PCIe inside the timed region except the periodic harvest counts.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
+
+
+def net_flops_per_eval(n, A, blocks, filters, fc, gomoku):
+    """2*MAC of the convolutions and linear layers."""
+    s = (n + 4) if gomoku else n
+    f = 2 * 17 * filters * 9 * s * s + blocks * 2 * (2 * filters * filters * 9 * s * s)
+    f += 2 * filters * 3 * s * s + 2 * (2 * s * s) * A + 2 * (s * s) * fc + 2 * fc
+    return float(f)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--games", type=int, default=4096)
+    ap.add_argument("--board", type=int, default=9)
+    ap.add_argument("--game", default="go")
+    ap.add_argument("--sims", type=int, default=200)
+    ap.add_argument("--parallel", type=int, default=8)
+    ap.add_argument("--blocks", type=int, default=10)
+    ap.add_argument("--filters", type=int, default=128)
+    ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
+    ap.add_argument("--harvest-every", type=int, default=50)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="0 = all host cores (capped at 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from alpha_zero_amd.core.gather import gather_samples
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    n, game = args.board, args.game
+    A = n * n + (1 if game == "go" else 0)
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, n, n), A, args.blocks, args.filters, args.filters, gomoku=(game != "go"))
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.net_dtype]
+    torch.backends.cudnn.benchmark = True
+    actor = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
+                          warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=dt,
+                          use_graph=not args.no_graph)
+    eng = actor.engine
+
+    if args.stagger > 0:  # mixed game phases from the first timed round (documented in DESIGN.md "Measurement")
+        rng = np.random.Generator(np.random.PCG64(1234 + rank))
+        plies = rng.integers(0, args.stagger + 1, size=args.games)
+        out = eng.env_step(None)
+        for t in range(int(plies.max())):
+            legal = out["legal"][:, : n * n].astype(bool)
+            r = rng.random(legal.shape) * legal
+            acts = np.where((plies > t) & legal.any(axis=1) & (out["scalars"][:, 5] == 0), r.argmax(axis=1), -2).astype(np.int32)
+            out = eng.env_step(acts)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def harvest_and_gather():
+        st, pi, z, games = actor.harvest_tensors()
+        res = gather_samples(st, pi, z, games, dst=0)
+        return 0 if res is None else int(res[0].shape[0])
+
+    for i in range(args.warmup):
+        actor.run_round()
+        if (i + 1) % args.harvest_every == 0:
+            harvest_and_gather()
+    barrier()
+    harvest_and_gather()
+    actor.counters(reset=True)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    samples_at_root = 0
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        actor.run_round(evs[i])
+        if (i + 1) % args.harvest_every == 0:
+            samples_at_root += harvest_and_gather()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cnt = actor.counters()
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in evs]))
+    nn_ms = float(np.mean([b.elapsed_time(c) for _, b, c in evs]))
+
+    moves = float(cnt["moves"])
+    tot = torch.tensor([moves, float(cnt["sims"]), float(cnt["leaves"])], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed_max = float(tmax.item())
+    total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        # ---- roofline of the dominant hand-written kernel: the fused round kernel (HBM bound) ----------
+        e_bytes = {"bf16": 2, "fp16": 2, "fp32": 4}[args.net_dtype]
+        W = (n * n + 63) // 64
+        steps = max(1, args.steps)
+        expanded = cnt["leaves"] - cnt["dup_leaves"] + cnt["root_evals"]
+        alg_bytes = (cnt["node_visits"] * 12 * A                 # select: N, W, P rows of every visited node
+                     + expanded * (12 * A + 4 * A + 4)           # expand: write P, init N, W; read priors + value
+                     + cnt["backup_edges"] * 16                  # backup / virtual loss: N, W read-modify-write per edge
+                     + (cnt["leaves"] + cnt["root_evals"]) * (17 * n * n * e_bytes + 16 * W * 8)  # feature planes + 8-board history
+                     ) / steps
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "round_kernel_pmc.json")
+        if os.path.exists(prof):
+            try:
+                pj = json.load(open(prof))
+                if pj.get("games") == args.games and pj.get("board") == n:
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "k_game<OpRound> (expand/backup + end-of-move + select + features)", "bound": "hbm",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4)}
+        flops_eval = net_flops_per_eval(n, A, args.blocks, args.filters, args.filters, game != "go")
+        nn_tflops = flops_eval * args.games * args.parallel / (nn_ms * 1e-3) / 1e12
+        nn_roof = {"kernel": "policy/value ResNet forward on G*P rows (PyTorch-ROCm, MFMA)", "bound": "mfma",
+                   "achieved": round(nn_tflops, 2), "peak": MFMA_PEAK_TFLOPS[args.net_dtype], "unit": "TFLOP/s",
+                   "frac": round(nn_tflops / MFMA_PEAK_TFLOPS[args.net_dtype], 5), "avg_forward_ms": round(nn_ms, 3),
+                   "batch_fill": round((cnt["leaves"] + cnt["root_evals"]) / (steps * args.games * args.parallel), 4)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import baseline
+
+            cores = args.cpu_cores or min(os.cpu_count() or 1, 256)
+            cpu = baseline.run(cores, seconds=args.cpu_seconds, game=game, n=n, sims=args.sims, P=args.parallel, blocks=args.blocks,
+                               filters=args.filters, stagger=args.stagger)
+            cpu["value"] = round(cpu["value"], 3)
+            cpu["per_core"] = round(cpu["per_core"], 4)
+        line = {
+            "metric": "self-play moves/sec (whole node), 9x9 Go @ 200 sims/move" if (game == "go" and n == 9 and args.sims == 200)
+            else f"self-play moves/sec (whole node), {n}x{n} {game} @ {args.sims} sims/move",
+            "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
+                                   f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",
+                       "games_per_gpu": args.games, "stagger_plies": args.stagger, "hip_graph_forward": not args.no_graph,
+                       "parallelism": f"games sharded x{world}, sample gather to rank 0"},
+            "sims_per_sec": round(total_sims / elapsed_max, 1), "evals_per_sec": round(total_evals / elapsed_max, 1),
+            "sims_per_move": round(total_sims / max(1.0, total_moves), 2),
+            "select_nodes_per_sim": round(cnt["node_visits"] / max(1, cnt["sims"]), 3),
+            "backup_nodes_per_sim": round(cnt["backup_edges"] / max(1, cnt["sims"]), 3),
+            "samples_gathered": samples_at_root, "roofline": roofline, "nn_roofline": nn_roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

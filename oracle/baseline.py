@@ -1,0 +1,76 @@
+"""CPU self-play baseline for bench.py -- TEST/BENCH INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Same algorithmic structure as the reference actor (alpha_zero/core/pipeline.py:166-382 +
+core/mcts_v2.py:485-657): one spawned process per actor, one torch thread each
+(training_go.py:10-19), per-simulation env deep copy, dense NumPy per-node statistics, P-leaf
+virtual-loss batching, sub-tree reuse, fp32 PyTorch-CPU network with softmax + .numpy() per leaf batch.
+It is the oracle (oracle/mcts.py, oracle/actor.py, oracle/rules.c), which reproduces the reference
+bit-exactly; its env is C instead of Python, which makes it slightly FASTER than the reference
+(calibration in DESIGN.md), i.e. a conservative baseline.
+"""
+import multiprocessing as mp
+import os
+import time
+
+
+def _worker(args):
+    (idx, game, n, sims, P, blocks, filters, seconds, stagger, seed) = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    import torch
+
+    torch.set_num_threads(1)
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from oracle import mcts
+    from oracle.envs import OracleGoEnv, OracleGomokuEnv
+
+    torch.manual_seed(1)
+    A = n * n + (1 if game == "go" else 0)
+    net = AlphaZeroNet((17, n, n), A, blocks, filters, filters, gomoku=(game != "go")).eval()
+    np.random.seed(seed + idx)
+    rng = np.random.Generator(np.random.PCG64(seed + idx))
+
+    @torch.no_grad()
+    def eval_position(state, batched=False):  # pipeline.py:91-123
+        if not batched:
+            state = state[None, ...]
+        x = torch.from_numpy(state).to(dtype=torch.float32)
+        logits, v = net(x)
+        pi = torch.softmax(logits, dim=-1).cpu().numpy()
+        v = np.squeeze(v.cpu().numpy(), axis=1).tolist()
+        pi = [pi[i] for i in range(pi.shape[0])]
+        return (pi, v) if batched else (pi[0], v[0])
+
+    moves = 0
+    t0 = time.time()
+    deadline = t0 + seconds
+    while time.time() < deadline:
+        env = OracleGoEnv(n) if game == "go" else OracleGomokuEnv(n)
+        env.reset()
+        for _ in range(int(rng.integers(0, stagger + 1))):  # same staggered start as the GPU run
+            legal = np.flatnonzero(np.asarray(env.legal_actions)[: n * n])
+            if len(legal) == 0 or env.is_game_over():
+                break
+            env.step(int(legal[rng.integers(len(legal))]))
+        root, done = None, env.is_game_over()
+        while not done and time.time() < deadline:
+            kw = dict(env=env, eval_func=eval_position, root_node=root, c_puct_base=19652.0, c_puct_init=1.25, num_simulations=sims,
+                      root_noise=True, warm_up=not (env.steps > 16))
+            if P > 1:
+                mv, pi, rq, cq, root = mcts.parallel_uct_search(num_parallel=P, **kw)
+            else:
+                mv, pi, rq, cq, root = mcts.uct_search(**kw)
+            _, _, done, _ = env.step(mv)
+            moves += 1
+    return moves, time.time() - t0
+
+
+def run(cores, seconds=20.0, game="go", n=9, sims=200, P=8, blocks=10, filters=128, stagger=60, seed=1):
+    ctx = mp.get_context("spawn")
+    args = [(i, game, n, sims, P, blocks, filters, seconds, stagger, seed) for i in range(cores)]
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_worker, args)
+    total = sum(m / t for m, t in res)
+    return dict(value=total, unit="moves/s", cores=cores, kind="port", per_core=total / cores,
+                sample=f"{cores} actor processes x {seconds:.0f}s, {game} {n}x{n}, {sims} sims, P={P}, {blocks}x{filters} fp32 net, "
+                       f"{sum(m for m, _ in res)} moves")

@@ -1,0 +1,89 @@
+"""Batched actor + sample gather, CPU tier (host twin engine, fp32 torch-CPU network, gloo)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+import engine_util as eu
+from alpha_zero_amd.core.network import AlphaZeroNet
+from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+
+def _actor(game="go", n=5, G=8, sims=16, P=4, **kw):
+    torch.manual_seed(1)
+    A = n * n + (1 if game == "go" else 0)
+    net = AlphaZeroNet((17, n, n), A, 1, 8, 8, gomoku=(game != "go"))
+    return SelfPlayActor(net, game=game, board_size=n, num_games=G, num_simulations=sims, num_parallel=P, warm_up_steps=4,
+                         device="cpu", net_dtype=torch.float32, use_graph=False, binding=eu.hosttwin_binding(), **kw)
+
+
+def test_actor_emits_reference_shaped_games():
+    a = _actor()
+    got = []
+    for _ in range(200):
+        a.run_rounds(10)
+        got += a.harvest()
+        if len(got) >= 12:
+            break
+    assert len(got) >= 12
+    for seq, stats in got:
+        assert stats["game_length"] == len(seq) and 0 < len(seq) <= 50
+        assert set(stats) == {"game_length", "game_result", "num_passes", "is_resign_disabled", "is_marked_for_resign", "is_could_won",
+                              "marked_resign_player", "resign_threshold", "training_steps"}
+        z = np.array([t.value for t in seq])
+        black = np.array([t.state[16, 0, 0] for t in seq])
+        assert seq[0].state.shape == (17, 5, 5) and seq[0].state.dtype == np.int8 and seq[0].pi_prob.shape == (26,)
+        assert seq[0].pi_prob.dtype == np.float64 and abs(seq[0].pi_prob.sum() - 1) < 1e-5
+        res = stats["game_result"]
+        # z is +1 for the winner's samples, -1 for the loser's (pipeline.py:349-354)
+        if res.startswith("B+"):
+            assert np.all(z[black == 1] == 1) and np.all(z[black == 0] == -1)
+        elif res.startswith("W+"):
+            assert np.all(z[black == 1] == -1) and np.all(z[black == 0] == 1)
+        # colours alternate and the first position is the empty board with black to move
+        assert black[0] == 1 and not seq[0].state[:16].any()
+    c = a.counters()
+    assert c["games"] >= 12 and c["moves"] > 0 and c["stalls"] == 0
+
+
+def test_actor_gomoku_and_weight_swap():
+    a = _actor(game="gomoku", n=7, G=4, sims=12, P=2)
+    a.run_rounds(30)
+    net2 = AlphaZeroNet((17, 7, 7), 49, 1, 8, 8, gomoku=True)
+    a.set_network(net2, training_steps=1000)
+    got = []
+    for _ in range(300):
+        a.run_rounds(10)
+        got += a.harvest()
+        if len(got) >= 4:
+            break
+    assert len(got) >= 4
+    for seq, stats in got:
+        assert stats["training_steps"] == 1000 and set(stats) == {"game_length", "game_result", "training_steps"}
+        assert seq[0].pi_prob.dtype == np.float32
+        assert stats["game_result"] in ("B+1.0", "W+1.0", "DRAW")
+
+
+def test_sample_gather_two_ranks_gloo(tmp_path):
+    """N > 1 data path: finished-game tensors of every rank arrive on rank 0 in rank order (gloo, world_size 2)."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gather_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
+    assert all(p.wait(timeout=300) == 0 for p in procs)
+    out = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    games = out["games"]
+    assert len(games) >= 2 and out["states"].shape[0] == out["z"].shape[0] == out["pi"].shape[0] == games[:, 1].sum()
+    # starts are rebased: games tile the sample range without overlap
+    order = np.argsort(games[:, 0])
+    assert games[order[0], 0] == 0 and np.all(games[order][1:, 0] == np.cumsum(games[order][:-1, 1]))
+    assert set(np.unique(games[:, 15] >> 20)) == {0, 1}
+    # each rank's samples are byte-identical to what that rank harvested locally
+    for r in range(2):
+        loc = np.load(os.path.join(str(tmp_path), f"local{r}.npz"))
+        mine = games[(games[:, 15] >> 20) == r]
+        assert len(mine) == len(loc["games"])
+        for row, lrow in zip(mine[np.argsort(mine[:, 0])], loc["games"][np.argsort(loc["games"][:, 0])]):
+            assert np.array_equal(out["states"][row[0]:row[0] + row[1]], loc["states"][lrow[0]:lrow[0] + lrow[1]])
+            assert np.array_equal(out["z"][row[0]:row[0] + row[1]], loc["z"][lrow[0]:lrow[0] + lrow[1]])
