@@ -49,7 +49,7 @@ class Binding:
             "azsp_create": [P(AzspConfig), P(V)], "azsp_destroy": [V], "azsp_geometry": [V, P(AzspGeometry)],
             "azsp_set_tables": [V, V, V, V, I], "azsp_set_injection": [V, V, V, I], "azsp_reset_games": [V, V],
             "azsp_env_step": [V, V, V, V, V, V, V], "azsp_set_state": [V, I, V, V, I, I, I, I, I, I, V],
-            "azsp_begin_move": [V, V, V], "azsp_select": [V, V, V, V], "azsp_expand_backup": [V, V, V, V],
+            "azsp_begin_move": [V, V, I, V], "azsp_select": [V, V, V, V], "azsp_expand_backup": [V, V, V, V],
             "azsp_round": [V, V, V, V, V, V], "azsp_get_status": [V, V, V, V], "azsp_get_search": [V, I, I, V, V, V, V],
             "azsp_commit_move": [V, V, V], "azsp_harvest": [V, V, V, V, I, V, I, P(I), P(I), V],
             "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],

@@ -162,9 +162,9 @@ class Engine:
                                            int(bool(last_was_pass)), int(caps[0]), int(caps[1]), self._stream()), "azsp_set_state")
 
     # -- search ---------------------------------------------------------------------------------------
-    def begin_move(self, noise=None):
+    def begin_move(self, noise=None, warm_up=-1):
         n = np.ascontiguousarray(noise, dtype=np.float64).reshape(self.G, self.A) if noise is not None else None
-        self._ck(self.b.dll.azsp_begin_move(self.h, n.ctypes.data if n is not None else None, self._stream()), "azsp_begin_move")
+        self._ck(self.b.dll.azsp_begin_move(self.h, n.ctypes.data if n is not None else None, int(warm_up), self._stream()), "azsp_begin_move")
 
     def select(self):
         self._ck(self.b.dll.azsp_select(self.h, self.features.data_ptr(), self.valid.data_ptr(), self._stream()), "azsp_select")

@@ -77,7 +77,7 @@ template <int W> struct GameRec {
     double out_root_q, out_child_q;
     int root_N;
     int root, n_free, status, root_fresh, root_noisy, ply, n_leaves, root_eval_pending;
-    int uid, num_passes, marked_player, resign_disabled, cur_buf, out_move, noise_pending, noise_ready, games_done, pad0_;
+    int uid, num_passes, marked_player, resign_disabled, cur_buf, out_move, noise_pending, noise_ready, games_done, warm_override;
     int16_t leaf_node[AZ_MAXP];
     uint8_t leaf_depth[AZ_MAXP];
 };
@@ -842,7 +842,7 @@ template <class Wv, int N, int GAME> struct Engine {
     // Policy + (batched mode) move choice.  In drop-in mode (stop_after_move) the caller samples the
     // move itself from the published pi, exactly like mcts_v2.py:433-434 does with np.random.choice.
     AZ_HD void search_done() {
-        const bool warm = !(gr.env.steps > c.warm_up_steps);  // pipeline.py:320
+        const bool warm = gr.warm_override >= 0 ? (gr.warm_override != 0) : !(gr.env.steps > c.warm_up_steps);  // pipeline.py:320
         double* pi64 = pi_slot();
         search_policy(warm, pi64);
         const float* rn = rowN(gr.root);

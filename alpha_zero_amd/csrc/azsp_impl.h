@@ -24,6 +24,7 @@ struct OpReset {
             e.gr.games_done = 0;
             e.gr.cur_buf = 0;
             e.gr.noise_ready = 0;
+            e.gr.warm_override = -1;
             int* sh = e.m.stg_hdr + (size_t)e.g * 2 * SH_COUNT;
             sh[SH_STATE] = AZB_FREE;
             sh[SH_COUNT + SH_STATE] = AZB_FREE;
@@ -48,8 +49,12 @@ struct OpRound {
     }
 };
 struct OpBeginMove {
+    int warm;
     template <class E> AZ_HD void operator()(E& e) const {
-        if (E::Wave::first()) e.gr.noise_ready = 1;
+        if (E::Wave::first()) {
+            e.gr.noise_ready = 1;
+            e.gr.warm_override = warm;
+        }
         E::Wave::sync();
     }
 };
@@ -592,11 +597,12 @@ int azsp_set_state(void* e, int32_t slot, const int8_t* board, const int8_t* his
     return az_run(h, op, stream);
 }
 
-int azsp_begin_move(void* e, const double* noise, void* stream) {
+int azsp_begin_move(void* e, const double* noise, int32_t warm_up, void* stream) {
     AzHandle* h = (AzHandle*)e;
     if (!h) return AZSP_EINVAL;
     if (noise && azb::h2d((void*)h->mem.inj_noise, noise, sizeof(double) * (size_t)h->cfg.G * h->A, stream)) return AZSP_EDEVICE;
-    return az_run(h, OpBeginMove(), stream);
+    OpBeginMove op = {warm_up};
+    return az_run(h, op, stream);
 }
 
 int azsp_select(void* e, void* feat, uint8_t* valid, void* stream) {

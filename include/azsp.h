@@ -144,8 +144,9 @@ int azsp_env_step(void* engine, const int32_t* actions_dev, int8_t* board_dev, i
 int azsp_set_state(void* engine, int32_t slot, const int8_t* board_host, const int8_t* hist_host, int32_t to_play,
                    int32_t steps, int32_t ko, int32_t last_was_pass, int32_t caps_black, int32_t caps_white, void* stream);
 
-/* Drop-in mode: hand the Dirichlet draw of this search to the engine (noise_host double[G][A] or NULL). */
-int azsp_begin_move(void* engine, const double* noise_host, void* stream);
+/* Drop-in mode: hand the Dirichlet draw of this search to the engine (noise_host double[G][A] or NULL) and the
+ * `warm_up` flag of uct_search (1: temperature 1.0, 0: temperature 0.1, -1: derive from env.steps <= warm_up_steps). */
+int azsp_begin_move(void* engine, const double* noise_host, int32_t warm_up, void* stream);
 
 int azsp_select(void* engine, void* features_dev, uint8_t* valid_dev, void* stream);
 int azsp_expand_backup(void* engine, const float* priors_dev, const float* values_dev, void* stream);

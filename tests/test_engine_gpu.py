@@ -86,3 +86,24 @@ def test_gpu_env_vs_oracle_random_playouts_4096_games():
             assert np.array_equal(env.board, board[g])
             assert np.array_equal(env.legal_actions.astype(np.int8), legal[g])
             assert env.ko == sc[g, 0] and env.caps == (sc[g, 1], sc[g, 2]) and env.steps == sc[g, 3]
+
+
+# ---- Python boundary on the GPU: env classes, uct_search drop-ins, Dihedral-8 -------------------------
+import dropin_checks as dc  # noqa: E402
+
+
+def test_gpu_env_classes():
+    dc.check_env_surface("gpu")
+
+
+@pytest.mark.parametrize("name", ["go9_p8_s200", "go5_p8_s64", "gomoku13_p1_s100", "gomoku7_p8_s64", "go5_p1_s40_det"])
+def test_gpu_uct_search_dropin_matches_reference(name):
+    dc.check_dropin_search("gpu", name, max_moves=8)
+
+
+def test_gpu_search_errors():
+    dc.check_search_errors("gpu")
+
+
+def test_gpu_dihedral():
+    dc.check_dihedral("gpu")
