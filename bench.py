@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = all host cores (capped at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen exhaustive find) for the convs")
+    ap.add_argument("--split-round", action="store_true", help="diagnostic: launch expand/backup and select as two kernels and time each")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,7 +79,7 @@ def main():
     torch.manual_seed(1)
     net = AlphaZeroNet((17, n, n), A, args.blocks, args.filters, args.filters, gomoku=(game != "go"))
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.net_dtype]
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     actor = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
                           warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=dt,
                           use_graph=not args.no_graph)
@@ -138,6 +140,20 @@ def main():
     elapsed_max = float(tmax.item())
     total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
 
+    if args.split_round and rank == 0:
+        ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ta = tb = 0.0
+        for _ in range(20):
+            ea[0].record()
+            eng.expand_backup()
+            ea[1].record()
+            eng.select()
+            ea[2].record()
+            actor._graph.replay() if actor._graph is not None else actor._forward()
+            torch.cuda.synchronize(dev)
+            ta += ea[0].elapsed_time(ea[1]) / 20
+            tb += ea[1].elapsed_time(ea[2]) / 20
+        print(json.dumps({"split_round_ms": {"expand_backup_endmove": round(ta, 4), "select_features": round(tb, 4)}}), flush=True)
     if rank == 0:
         # ---- roofline of the dominant hand-written kernel: the fused round kernel (HBM bound) ----------
         e_bytes = {"bf16": 2, "fp16": 2, "fp32": 4}[args.net_dtype]
