@@ -5,8 +5,10 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
-rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 24"))
-print(f"{'calls':>7} {'total_ms':>11} {'avg_us':>11} {'%':>7}  kernel")
+rows = list(cur.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc limit 24"))
+grand = list(cur.execute("select sum(duration) from kernels"))[0][0]
+rows = [(n, c, t, a, 100.0 * t / grand) for n, c, t, a in rows]
+print(f"{'calls':>7} {'total_ms':>11} {'avg_us':>11} {'%':>7}  kernel   (durations from the kernel-dispatch table, ns)")
 for name, calls, tot, avg, pct in rows:
     short = name if len(name) < 150 else name[:110] + " ... " + name[-30:]
     print(f"{calls:7d} {tot / 1e6:11.3f} {avg / 1e3:11.3f} {pct:7.3f}  {short}")
