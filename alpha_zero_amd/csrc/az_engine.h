@@ -133,9 +133,24 @@ struct Philox {
     }
 };
 
-template <int W> struct Scratch {
-    u64 planes[16][W];
-    int path[AZ_PATH_CAP];
+#define AZ_LDS_NODES 1024  // parent table of the re-root pass lives in LDS up to this pool size
+
+#define AZ_FREE_PREFETCH 64
+
+template <int W, int AP, int HW> struct Scratch {
+    u64 planes[16][W];          // observation planes being assembled / history shift buffer
+    int path[AZ_PATH_CAP];      // (node << 16) | move per edge of the current descent
+    double pi[AP];              // search policy of the move being finished
+    double cdf[AP];             // its running sum (np.cumsum order)
+    float tmpf[AP];             // float32 policy terms (Gomoku)
+    int16_t parent[AZ_LDS_NODES];
+    // the node record being examined by the current descent, staged from HBM in one burst
+    float rN[AP], rW[AP], rP[AP];
+    double rP64[AP];            // float64 root priors (noisy root only)
+    int16_t rC[AP];
+    u64 hdrw[HW];               // its header (position, parent, move, expanded)
+    int16_t freetop[AZ_FREE_PREFETCH];
+    int free_base;              // freetop[i] == free_stack[free_base + i]
 };
 
 template <class Wv, int N, int GAME> struct Engine {
@@ -151,13 +166,14 @@ template <class Wv, int N, int GAME> struct Engine {
     static constexpr int EPL = (AP + 63) / 64;
     typedef EnvState<W> S;
     typedef GameRec<W> GR;
-    typedef Scratch<W> SC;
     struct Hdr {
         S st;
         int16_t parent, move;
         uint8_t expanded, pad_[3];
     };
     static constexpr int HDR = ((int)sizeof(Hdr) + 127) / 128 * 128;
+    static constexpr int HW = ((int)sizeof(Hdr) + 7) / 8;
+    typedef Scratch<W, AP, HW> SC;
     static constexpr int REC = (HDR + 3 * AP * 4 + AP * 2 + 127) / 128 * 128;
     static constexpr int GREC = ((int)sizeof(GR) + 127) / 128 * 128;
 
@@ -197,7 +213,8 @@ template <class Wv, int N, int GAME> struct Engine {
             fail(AZ_ERR_NODES);
             return 0;
         }
-        const int idx = m.free_stack[(size_t)g * c.max_nodes + gr.n_free - 1];
+        const int pos = gr.n_free - 1, rel = pos - sc.free_base;
+        const int idx = (rel >= 0 && rel < AZ_FREE_PREFETCH) ? (int)sc.freetop[rel] : (int)m.free_stack[(size_t)g * c.max_nodes + pos];
         if (Wv::first()) gr.n_free -= 1;
         Wv::sync();
         cnt[AZC_NODES_CREATED]++;
@@ -233,9 +250,6 @@ template <class Wv, int N, int GAME> struct Engine {
         if (Wv::first()) {
             R::reset(gr.env, GAME);
             if (GAME == AZ_GOMOKU) gr.env.flags = 0;
-            for (int k = 0; k < 8; ++k)
-                for (int q = 0; q < 2; ++q)
-                    for (int w = 0; w < W; ++w) gr.hist[k][q][w] = 0;
             gr.ply = 0;
             gr.num_passes = 0;
             gr.marked_player = -1;
@@ -253,6 +267,10 @@ template <class Wv, int N, int GAME> struct Engine {
             gr.resign_disabled = rd;
             gr.status = AZS_NEED_ROOT;
         }
+        Wv::lanes([&](int lane) {
+            u64* flat = &gr.hist[0][0][0];
+            for (int t = lane; t < 16 * W; t += AZ_WAVE) flat[t] = 0;
+        });
         Wv::sync();
         free_all_nodes();
         stage_begin();
@@ -292,12 +310,31 @@ template <class Wv, int N, int GAME> struct Engine {
     }
 
     // ---- PUCT selection (mcts_v2.py:99-109, :142-185) -----------------------------------------
-    AZ_HD int puct_argmax(int node, bool at_root, int n_self) {
-        const S& s = hdr(node).st;
+    // Stage one whole node record (header + N/W/P/child rows, + the float64 root priors) into LDS: all loads of the
+    // burst are in flight together, so a tree level costs ONE HBM/L2 round trip instead of one per dependent field.
+    AZ_HD void stage_node(int node, bool with_root_p) {
         const float* rn = rowN(node);
         const float* rw = rowW(node);
         const float* rp = rowP(node);
+        const int16_t* rc = rowC(node);
+        const u64* hw = (const u64*)rec(node);
         const double* rp64 = rootP();
+        Wv::lanes([&](int lane) {
+            if (lane < HW) sc.hdrw[lane] = hw[lane];
+            for (int a = lane; a < AP; a += AZ_WAVE) {
+                sc.rN[a] = rn[a];
+                sc.rW[a] = rw[a];
+                sc.rP[a] = rp[a];
+                sc.rC[a] = rc[a];
+                if (with_root_p) sc.rP64[a] = rp64[a];
+            }
+        });
+        Wv::sync();
+    }
+    AZ_HD const Hdr& staged_hdr() const { return *(const Hdr*)sc.hdrw; }
+
+    AZ_HD int puct_argmax(bool at_root, int n_self) {
+        const S& s = staged_hdr().st;
         int ti = n_self < c.tab_len ? n_self : c.tab_len - 1;
         const bool fresh = at_root && gr.root_fresh;
         const double pbc64 = fresh ? m.pbc_py[ti] : m.pbc_np[ti];
@@ -309,15 +346,15 @@ template <class Wv, int N, int GAME> struct Engine {
             for (int j = 0; j < EPL; ++j) {
                 const int a = lane + 64 * j;
                 if (a >= A || !action_legal(s, a)) continue;
-                const float n = rn[a], w = rw[a];
+                const float n = sc.rN[a], w = sc.rW[a];
                 const float q = w / (n > 0.0f ? n : 1.0f);
                 const float r = sq32 / (1.0f + n);
                 double sco;
                 if (noisy) {
-                    const double u = (pbc64 * rp64[a]) * (double)r;  // float64 priors at the noisy root
+                    const double u = (pbc64 * sc.rP64[a]) * (double)r;  // float64 priors at the noisy root
                     sco = (double)(-q) + u;
                 } else {
-                    const float u = (pbc32 * rp[a]) * r;
+                    const float u = (pbc32 * sc.rP[a]) * r;
                     sco = (double)(-q + u);
                 }
                 if (bi < 0 || sco > best) {
@@ -329,60 +366,63 @@ template <class Wv, int N, int GAME> struct Engine {
     }
 
     // One descent from the root.  Returns 0 = leaf reached (unexpanded, non-terminal), 1 = terminal.
-    AZ_HD int descend(int& node_out, int& depth_out) {
+    // On return `leaf_state` holds the leaf's position (used for the observation planes).
+    AZ_HD int descend(int& node_out, int& depth_out, S& leaf_state) {
         int node = gr.root, depth = 0, n_self = gr.root_N;
+        stage_node(node, gr.root_noisy != 0);
         for (;;) {
-            const int mv = puct_argmax(node, depth == 0, n_self);
+            const int mv = puct_argmax(depth == 0, n_self);
             if (depth >= AZ_PATH_CAP) {
                 fail(AZ_ERR_DEPTH);
                 node_out = node;
                 depth_out = depth;
+                leaf_state = staged_hdr().st;
                 return 1;
             }
-            int child = rowC(node)[mv];
-            if (child < 0) {  // lazy child creation (mcts_v2.py:182-183); its position is computed once
+            int child = sc.rC[mv];
+            n_self = (int)sc.rN[mv];
+            if (Wv::first()) sc.path[depth] = (node << 16) | mv;
+            depth++;
+            if (child < 0) {  // lazy child creation (mcts_v2.py:182-183); its position is computed once, here
                 child = alloc_node();
-                Hdr& h = hdr(child);
                 S ns;
-                R::template step<GAME>(hdr(node).st, mv, c.rc, ns);
+                R::template step<GAME>(staged_hdr().st, mv, c.rc, ns);
                 if (Wv::first()) {
+                    Hdr& h = hdr(child);
                     h.st = ns;
                     h.parent = (int16_t)node;
                     h.move = (int16_t)mv;
                     h.expanded = 0;
                     rowC(node)[mv] = (int16_t)child;
                 }
+                leaf_state = ns;
+                node_out = child;
+                depth_out = depth;
                 Wv::sync();
+                return (ns.flags & AZF_TERMINAL) ? 1 : 0;
             }
-            if (Wv::first()) sc.path[depth] = (node << 16) | mv;
-            n_self = (int)rowN(node)[mv];
-            depth++;
             node = child;
-            const Hdr& h = hdr(node);
-            if (h.st.flags & AZF_TERMINAL) {
+            stage_node(node, false);
+            const Hdr& h = staged_hdr();
+            if ((h.st.flags & AZF_TERMINAL) || !h.expanded) {
+                leaf_state = h.st;
                 node_out = node;
                 depth_out = depth;
                 Wv::sync();
-                return 1;
-            }
-            if (!h.expanded) {
-                node_out = node;
-                depth_out = depth;
-                Wv::sync();
-                return 0;
+                return (h.st.flags & AZF_TERMINAL) ? 1 : 0;
             }
         }
     }
 
     // ---- observation planes (base.py:228-259) -------------------------------------------------
     // board k plies back from `leaf`: the leaf, its ancestors up to the root, then the real-game history
-    AZ_HD void gather_planes(int leaf, int depth, int me) {
+    AZ_HD void gather_planes(int leaf, int depth, int me, const S* leaf_state = nullptr) {
         Wv::lanes([&](int lane) {
             for (int t = lane; t < 16 * W; t += AZ_WAVE) {
                 const int w = t % W, pc = t / W, k = pc >> 1, col = (pc & 1) ? 1 - me : me;
                 u64 v;
                 if (depth < 0) v = gr.hist[k][col][w];  // the real position: the history ring itself
-                else if (k == 0) v = hdr(leaf).st.stones[col][w];
+                else if (k == 0) v = leaf_state ? leaf_state->stones[col][w] : hdr(leaf).st.stones[col][w];
                 else if (k <= depth) v = hdr(sc.path[depth - k] >> 16).st.stones[col][w];
                 else v = gr.hist[k - depth][col][w];
                 sc.planes[pc][w] = v;
@@ -414,6 +454,8 @@ template <class Wv, int N, int GAME> struct Engine {
     // ---- select phase -------------------------------------------------------------------------
     AZ_HD void select(void* feat, unsigned char* valid) {
         unsigned char* vrow = valid + (size_t)g * c.P;
+        if (Wv::first()) sc.free_base = -(1 << 30);  // no staged free-stack window yet
+        Wv::sync();
         if (gr.status == AZS_NEED_ROOT) {
             // mcts_v2.py:364-368: the root position itself is evaluated first
             if (gr.root < 0) {
@@ -444,18 +486,29 @@ template <class Wv, int N, int GAME> struct Engine {
         int nleaf = 0;
         if (gr.status == AZS_SEARCH && !gr.noise_pending) {
             int attempts = 0;
+            {  // the next pops of the free stack, staged once per round
+                const int base = gr.n_free - AZ_FREE_PREFETCH;
+                const int16_t* fs = m.free_stack + (size_t)g * c.max_nodes;
+                Wv::lanes([&](int lane) {
+                    const int i = base + lane;
+                    if (i >= 0) sc.freetop[lane] = fs[i];
+                });
+                if (Wv::first()) sc.free_base = base;
+                Wv::sync();
+            }
             // mcts_v2.py:572: up to P leaves in at most 2P attempts, one after another (each descent
             // sees the virtual losses of the previous ones); uct_search (:378-418) is the P == 1 case
             const int max_att = c.parallel_mode ? 2 * c.P : 1;
             while (nleaf < c.P && attempts < max_att) {
                 attempts++;
                 int node, depth;
-                const int term = descend(node, depth);
+                S leaf;
+                const int term = descend(node, depth, leaf);
                 cnt[AZC_SIMS]++;
                 if (term) {
                     // mcts_v2.py:407-411 / :604-608: back up -reward, node stays unexpanded
                     cnt[AZC_TERMINAL_HITS]++;
-                    path_update(sc.path, depth, (float)(-(int)hdr(node).st.reward), true, true);
+                    path_update(sc.path, depth, (float)(-(int)leaf.reward), true, true);
                     if (!c.parallel_mode && gr.root_N < c.budget) attempts = 0;  // uct_search keeps looping (:378)
                     if (!c.parallel_mode && gr.root_N >= c.budget) break;
                     continue;
@@ -469,8 +522,8 @@ template <class Wv, int N, int GAME> struct Engine {
                     gr.leaf_node[nleaf] = (int16_t)node;
                     gr.leaf_depth[nleaf] = (uint8_t)depth;
                 }
-                const int me = hdr(node).st.to_play;
-                gather_planes(node, depth, me);
+                const int me = leaf.to_play;
+                gather_planes(node, depth, me, &leaf);
                 write_features(feat, nleaf, me);
                 nleaf++;
                 cnt[AZC_LEAVES]++;
@@ -561,12 +614,16 @@ template <class Wv, int N, int GAME> struct Engine {
         if (!c.inject) {
             // Dirichlet(alpha) over ALL actions = normalised Gamma(alpha) draws (:259-260)
             const u64 key = c.seed + (u64)c.rank;
-            double part = 0.0;
-            Wv::lanes([&](int lane) {
-                for (int a = lane; a < A; a += AZ_WAVE) rp64[a] = gamma_sample(c.alpha, key, (u32)g, (u32)gr.uid, ((u32)gr.ply << 12) | (u32)a);
+            const double part = Wv::sum_f64([&](int lane) -> double {
+                double acc = 0.0;
+                for (int a = lane; a < A; a += AZ_WAVE) {
+                    const double gsample = gamma_sample(c.alpha, key, (u32)g, (u32)gr.uid, ((u32)gr.ply << 12) | (u32)a);
+                    rp64[a] = gsample;
+                    acc += gsample;
+                }
+                return acc;
             });
             Wv::sync();
-            for (int a = 0; a < A; ++a) part += rp64[a];
             total = part > 0.0 ? part : 1.0;
         }
         Wv::lanes([&](int lane) {
@@ -611,34 +668,34 @@ template <class Wv, int N, int GAME> struct Engine {
         return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
     }
 
-    // generate_search_policy (mcts_v2.py:265-298) into pi64[A] (scratch = rootP row is free to reuse
-    // only AFTER the search, so the policy is written to the move log / staging directly).
-    AZ_HD void search_policy(bool warm, double* pi64) {
+    // generate_search_policy (mcts_v2.py:265-298) into the wave's LDS row sc.pi[A] (and the move log when enabled).
+    AZ_HD void search_policy(bool warm, double* log_pi) {
         const S& s = hdr(gr.root).st;
         const float* rn = rowN(gr.root);
         if (GAME == AZ_GO) {
-            // legal(int64) * child_N(float32) -> float64; n**5 and the sum are exact integers in float64
-            Wv::lanes([&](int lane) {
+            // legal(int64) * child_N(float32) -> float64; n**5 and the sum are exact integers in float64, so the
+            // summation order is irrelevant and a wave reduction is bit-identical to np.sum
+            const double sum = Wv::sum_f64([&](int lane) -> double {
+                double part = 0.0;
                 for (int a = lane; a < A; a += AZ_WAVE) {
                     double x = action_legal(s, a) ? (double)rn[a] : 0.0;
                     if (!warm) {
                         const double x2 = x * x;
                         x = x2 * x2 * x;
                     }
-                    pi64[a] = x;
+                    sc.pi[a] = x;
+                    part += x;
                 }
+                return part;
             });
             Wv::sync();
-            double sum = 0.0;
-            for (int a = 0; a < A; ++a) sum += pi64[a];
             if (sum > 0.0) {
                 Wv::lanes([&](int lane) {
-                    for (int a = lane; a < A; a += AZ_WAVE) pi64[a] = pi64[a] / sum;
+                    for (int a = lane; a < A; a += AZ_WAVE) sc.pi[a] = sc.pi[a] / sum;
                 });
             }
         } else {
-            // legal(int8) * child_N(float32) stays float32 (Gomoku)
-            float* tmp = (float*)pi64;  // A floats fit in the first half of the A doubles
+            // legal(int8) * child_N(float32) stays float32 (Gomoku); np.sum order = pairwise_sum_f32
             Wv::lanes([&](int lane) {
                 for (int a = lane; a < A; a += AZ_WAVE) {
                     float x = action_legal(s, a) ? rn[a] : 0.0f;
@@ -646,26 +703,40 @@ template <class Wv, int N, int GAME> struct Engine {
                         const double d = (double)x, d2 = d * d;
                         x = (float)(d2 * d2 * d);
                     }
-                    tmp[a] = x;
+                    sc.tmpf[a] = x;
                 }
             });
             Wv::sync();
-            const float sum = pairwise_sum_f32(tmp, A);
-            // widen in place from the top so no element is overwritten before it is read
-            if (Wv::first())
-                for (int a = A - 1; a >= 0; --a) {
-                    const float x = tmp[a];
-                    pi64[a] = (double)(sum > 0.0f ? x / sum : x);
+            const float sum = pairwise_sum_f32(sc.tmpf, A);
+            Wv::lanes([&](int lane) {
+                for (int a = lane; a < A; a += AZ_WAVE) {
+                    const float x = sc.tmpf[a];
+                    sc.pi[a] = (double)(sum > 0.0f ? x / sum : x);
                 }
+            });
         }
         Wv::sync();
+        if (log_pi) {
+            Wv::lanes([&](int lane) {
+                for (int a = lane; a < A; a += AZ_WAVE) log_pi[a] = sc.pi[a];
+            });
+        }
     }
 
-    // np.random.choice(p=pi): cdf = cumsum(p) (sequential, float64), cdf /= cdf[-1], first i with cdf[i] > u
-    AZ_HD int sample_move(const double* pi64, bool warm) {
+    // np.random.choice(p=pi): cdf = cumsum(p) (sequential, float64), cdf /= cdf[-1], searchsorted(cdf, u, 'right').
+    // The cumulative sums are formed once, in order, in LDS; fl(cdf[a] / total) is monotone in a, so the first index
+    // whose quotient exceeds u is found by bisection with the very same divisions NumPy performs.
+    AZ_HD int sample_move(bool warm) {
         const S& s = hdr(gr.root).st;
-        double tot = 0.0;
-        for (int a = 0; a < A; ++a) tot += pi64[a];
+        if (Wv::first()) {
+            double acc = 0.0;
+            for (int a = 0; a < A; ++a) {
+                acc += sc.pi[a];
+                sc.cdf[a] = acc;
+            }
+        }
+        Wv::sync();
+        const double tot = sc.cdf[A - 1];
         const double* inj = c.inject ? m.inj_unif + ((size_t)g * c.inj_moves + (gr.ply < c.inj_moves ? gr.ply : c.inj_moves - 1)) * AZ_INJ_K : nullptr;
         int mv = -1;
         for (int t = 0; t < 64; ++t) {
@@ -676,25 +747,23 @@ template <class Wv, int N, int GAME> struct Engine {
                 Philox::gen(c.seed + (u64)c.rank, (u32)g, (u32)gr.uid, ((u32)gr.ply << 12) | 0xFFFu, 0x1000u + (u32)t, r);
                 u = Philox::u01(r[0], r[1]);
             }
-            double acc = 0.0;
-            mv = A - 1;
-            for (int a = 0; a < A; ++a) {
-                acc += pi64[a];
-                if (acc / tot > u) {
-                    mv = a;
-                    break;
-                }
+            int lo = 0, hi = A;  // first a in [0, A) with cdf[a]/tot > u, else A
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (sc.cdf[mid] / tot > u) hi = mid;
+                else lo = mid + 1;
             }
+            mv = lo < A ? lo : A - 1;
             // mcts_v2.py:433 / :640: redraw while pass during warm-up, or illegal
             const bool bad = (warm && GAME == AZ_GO && mv == NP) || !action_legal(s, mv);
             if (!bad) return mv;
         }
-        // the reference would loop forever here; fall back to the most visited legal point
+        // the reference would loop forever here
         fail(AZ_ERR_SAMPLE);
         return mv;
     }
 
-    AZ_HD void record_sample(const double* pi64) {
+    AZ_HD void record_sample() {
         int* sh = m.stg_hdr + ((size_t)g * 2 + gr.cur_buf) * SH_COUNT;
         const int k = sh[SH_LEN];
         if (k >= c.stage_cap) {
@@ -711,7 +780,7 @@ template <class Wv, int N, int GAME> struct Engine {
                 const int w = t % W, pc = t / W, kk = pc >> 1, col = (pc & 1) ? 1 - me : me;
                 pl[t] = gr.hist[kk][col][w];
             }
-            for (int a = lane; a < A; a += AZ_WAVE) pi[a] = (float)pi64[a];
+            for (int a = lane; a < A; a += AZ_WAVE) pi[a] = (float)sc.pi[a];
         });
         if (Wv::first()) {
             m.stg_meta[idx] = me == 0 ? 1 : 0;
@@ -721,13 +790,18 @@ template <class Wv, int N, int GAME> struct Engine {
     }
 
     AZ_HD void push_history(const S& s) {
-        if (Wv::first()) {
-            for (int k = 7; k > 0; --k)
-                for (int q = 0; q < 2; ++q)
-                    for (int w = 0; w < W; ++w) gr.hist[k][q][w] = gr.hist[k - 1][q][w];
-            for (int q = 0; q < 2; ++q)
-                for (int w = 0; w < W; ++w) gr.hist[0][q][w] = s.stones[q][w];
-        }
+        // hist[k] <- hist[k-1], hist[0] <- new board (base.py deque.appendleft); 16*W words moved lane-parallel via LDS
+        u64* flat = &gr.hist[0][0][0];
+        Wv::lanes([&](int lane) {
+            for (int t = lane; t < 16 * W; t += AZ_WAVE) {
+                const int w = t % W, kq = t / W, k = kq >> 1, q = kq & 1;
+                sc.planes[kq][w] = k == 0 ? s.stones[q][w] : flat[t - 2 * W];
+            }
+        });
+        Wv::sync();
+        Wv::lanes([&](int lane) {
+            for (int t = lane; t < 16 * W; t += AZ_WAVE) flat[t] = sc.planes[t / W][t % W];
+        });
         Wv::sync();
     }
 
@@ -737,38 +811,42 @@ template <class Wv, int N, int GAME> struct Engine {
         const float cn = rowN(old_root)[mv], cw = rowW(old_root)[mv];
         int16_t* fs = m.free_stack + (size_t)g * c.max_nodes;
         const int mn = c.max_nodes;
-        // nodes currently in use = everything not on the free stack; mark them via a scratch pass:
-        // a node is kept iff walking up its parents reaches `child` before reaching the old root.
+        const bool lds = mn <= AZ_LDS_NODES;
+        // A node is kept iff walking up its parents reaches `child` before the old root.  Unused nodes carry
+        // parent == -2.  The parent links are first gathered into LDS (one strided load per node, all in flight
+        // together); the walks then run at LDS latency instead of one dependent global load per hop.
+        if (lds) {
+            for (int base = 0; base < mn; base += AZ_WAVE)
+                Wv::lanes([&](int lane) {
+                    const int i = base + lane;
+                    if (i < mn) sc.parent[i] = hdr(i).parent;
+                });
+            Wv::sync();
+        }
         int nfree = gr.n_free;
-        // 1) collect "in use" flags: build a bitmap in LDS-free fashion by testing membership lazily:
-        //    free-stack entries are exactly the unused nodes, so first invalidate them.
-        //    We re-create the stack from scratch: [previously free nodes] + [newly dropped nodes].
-        // parents of free nodes are garbage, so tag free nodes by parent = -2 when they are released.
         for (int base = 0; base < mn; base += AZ_WAVE) {
             const u64 drop = Wv::ballot([&](int lane) -> bool {
                 const int i = base + lane;
                 if (i >= mn) return false;
-                int p = hdr(i).parent;
-                if (p == -2) return false;  // already free
+                int p = lds ? (int)sc.parent[i] : (int)hdr(i).parent;
+                if (p == -2) return false;  // not in use
                 int cur = i;
                 for (int hops = 0; hops < mn; ++hops) {
                     if (cur == child) return false;  // kept
                     if (cur == old_root || p < 0) return true;
                     cur = p;
-                    p = hdr(cur).parent;
+                    p = lds ? (int)sc.parent[cur] : (int)hdr(cur).parent;
                 }
                 return true;
             });
+            Wv::sync();
             Wv::lanes([&](int lane) {
                 if ((drop >> lane) & 1ull) {
                     const int pos = nfree + __builtin_popcountll(drop & ((1ull << lane) - 1ull));
                     fs[pos] = (int16_t)(base + lane);
+                    hdr(base + lane).parent = -2;
+                    if (lds) sc.parent[base + lane] = -2;  // later walks stop here (p < 0 => dropped)
                 }
-            });
-            Wv::sync();
-            // tag after the whole chunk was classified (walks of later chunks stop at p < 0 / -2 anyway)
-            Wv::lanes([&](int lane) {
-                if ((drop >> lane) & 1ull) hdr(base + lane).parent = -2;
             });
             nfree += __builtin_popcountll(drop);
             Wv::sync();
@@ -843,8 +921,7 @@ template <class Wv, int N, int GAME> struct Engine {
     // move itself from the published pi, exactly like mcts_v2.py:433-434 does with np.random.choice.
     AZ_HD void search_done() {
         const bool warm = gr.warm_override >= 0 ? (gr.warm_override != 0) : !(gr.env.steps > c.warm_up_steps);  // pipeline.py:320
-        double* pi64 = pi_slot();
-        search_policy(warm, pi64);
+        search_policy(warm, (c.log_moves || c.stop_after_move) ? pi_slot() : nullptr);
         const float* rn = rowN(gr.root);
         if (c.log_moves || c.stop_after_move) {
             float* ln = m.log_childN + ((size_t)g * c.log_cap + log_slot()) * A;
@@ -870,9 +947,9 @@ template <class Wv, int N, int GAME> struct Engine {
                     }
             });
         } else {
-            mv = sample_move(pi64, warm);
+            mv = sample_move(warm);
         }
-        commit_actor(mv, pi64);
+        commit_actor(mv);
     }
 
     // best_child_Q = -Q(chosen child) in float32 (:446); 0.0 when the move has no child node (:425)
@@ -924,7 +1001,7 @@ template <class Wv, int N, int GAME> struct Engine {
     }
 
     // Batched actor step (pipeline.py:323-346): sample, resignation rule, env step, re-root / game end.
-    AZ_HD void commit_actor(int mv, const double* pi64) {
+    AZ_HD void commit_actor(int mv) {
         int child;
         const double rq = root_q();
         const double cq = child_q_of(mv, child);
@@ -935,7 +1012,7 @@ template <class Wv, int N, int GAME> struct Engine {
             Wv::sync();
             return;
         }
-        record_sample(pi64);
+        record_sample();
         const int mover = gr.env.to_play;
         bool resign = false;
         if (GAME == AZ_GO && c.has_resign && gr.env.steps > c.check_resign_after) {

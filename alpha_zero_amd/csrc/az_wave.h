@@ -70,6 +70,13 @@ struct WaveDev {
         return min_i32(cand);
     }
     static AZ_D int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    // Sum over lanes of a double (butterfly: every lane ends with the same value).
+    template <class F> static AZ_D double sum_f64(F&& f) {
+        double v = f(lane());
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
     template <class F> static AZ_D int sum_i32(F&& f) {
         int v = f(lane());
 #pragma unroll
@@ -107,6 +114,17 @@ struct WaveHost {
         return bi;
     }
     static int bcast0(int v) { return v; }
+    template <class F> static double sum_f64(F&& f) {
+        // same butterfly order as the device so that non-integer sums (production noise) agree as well
+        double v[AZ_WAVE];
+        for (int l = 0; l < AZ_WAVE; ++l) v[l] = f(l);
+        for (int o = 32; o > 0; o >>= 1) {
+            double w[AZ_WAVE];
+            for (int l = 0; l < AZ_WAVE; ++l) w[l] = v[l] + v[l ^ o];
+            for (int l = 0; l < AZ_WAVE; ++l) v[l] = w[l];
+        }
+        return v[0];
+    }
     template <class F> static int sum_i32(F&& f) {
         int v = 0;
         for (int l = 0; l < AZ_WAVE; ++l) v += f(l);

@@ -11,7 +11,7 @@ static hipError_t g_last = hipSuccess;
 
 template <int N, int GAME, class Op>
 __global__ void __launch_bounds__(256) k_game(const AzCfg c, const AzMem m, const Op op) {
-    __shared__ Scratch<Geo<N>::W> sc[4];
+    __shared__ typename Engine<WaveDev, N, GAME>::SC sc[4];
     const int wave = (int)(threadIdx.x >> 6);
     const int g = (int)blockIdx.x * 4 + wave;
     if (g >= c.G) return;

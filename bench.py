@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = all host cores (capped at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (MIOpen exhaustive find) for the convs")
+    ap.add_argument("--no-miopen-find", action="store_true", help="disable torch.backends.cudnn.benchmark (MIOpen find) for the convs")
     ap.add_argument("--split-round", action="store_true", help="diagnostic: launch expand/backup and select as two kernels and time each")
     args = ap.parse_args()
 
@@ -79,7 +79,7 @@ def main():
     torch.manual_seed(1)
     net = AlphaZeroNet((17, n, n), A, args.blocks, args.filters, args.filters, gomoku=(game != "go"))
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.net_dtype]
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
     actor = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
                           warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=dt,
                           use_graph=not args.no_graph)

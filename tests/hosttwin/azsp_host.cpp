@@ -18,7 +18,7 @@ int set_device(int) { return 0; }
 const char* backend_error() { return "host twin"; }
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void*) {
     for (int g = 0; g < c.G; ++g) {
-        Scratch<Geo<N>::W> sc;
+        typename Engine<WaveHost, N, GAME>::SC sc;
         Engine<WaveHost, N, GAME> e(c, m, g, sc);
         op(e);
     }
