@@ -49,8 +49,20 @@ template <int N> struct BBOps {
     static AZ_HD bool any(B a) { u64 m = 0; for (int i = 0; i < W; ++i) m |= a.w[i]; return m != 0; }
     static AZ_HD bool eq(B a, B b) { u64 m = 0; for (int i = 0; i < W; ++i) m |= a.w[i] ^ b.w[i]; return m == 0; }
     static AZ_HD int count(B a) { int c = 0; for (int i = 0; i < W; ++i) c += __builtin_popcountll(a.w[i]); return c; }
-    static AZ_HD bool test(const B& a, int p) { return (a.w[p >> 6] >> (p & 63)) & 1ull; }
-    static AZ_HD B bit(int p) { B r = zero(); r.w[p >> 6] = 1ull << (p & 63); return r; }
+    // No dynamic indexing of the word array: a runtime index would push the (register-resident) bitboard to scratch.
+    static AZ_HD bool test(const B& a, int p) {
+        const int wi = p >> 6;
+        u64 word = 0;
+        for (int i = 0; i < W; ++i) word = (i == wi) ? a.w[i] : word;
+        return (word >> (p & 63)) & 1ull;
+    }
+    static AZ_HD B bit(int p) {
+        const int wi = p >> 6;
+        const u64 m = 1ull << (p & 63);
+        B r;
+        for (int i = 0; i < W; ++i) r.w[i] = (i == wi) ? m : 0ull;
+        return r;
+    }
     static AZ_HD int first(B a) {  // lowest set bit, -1 if none
         for (int i = 0; i < W; ++i)
             if (a.w[i]) return 64 * i + __builtin_ctzll(a.w[i]);

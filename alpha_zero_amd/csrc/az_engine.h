@@ -63,7 +63,7 @@ struct AzMem {
     double* log_pi;          // [G][log_cap][A]
     float* log_childN;       // [G][log_cap][A]
     double* log_q;           // [G][log_cap][4]  root_q, child_q, root_N before search (unused), move
-    u64* counters;           // [AZC_COUNT]
+    u64* counters;           // [G][AZC_COUNT]  per-game rows (no atomics: 4096 waves hammering 12 shared words cost ~0.6 ms per launch)
     int* err;                // [1]
 };
 
@@ -100,7 +100,29 @@ struct AzAtomic {
         return o;
 #endif
     }
+    static AZ_D u64 cas_u64(u64* p, u64 expect, u64 desired) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)desired);
 #else
+        const u64 o = *p;
+        if (o == expect) *p = desired;
+        return o;
+#endif
+    }
+    static AZ_D u64 load_u64(u64* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        return *p;
+#endif
+    }
+#else
+    static inline u64 cas_u64(u64* p, u64 expect, u64 desired) {
+        const u64 o = *p;
+        if (o == expect) *p = desired;
+        return o;
+    }
+    static inline u64 load_u64(u64* p) { return *p; }
     static inline void add(u64* p, u64 v) { *p += v; }
     static inline int fetch_add_i32(int* p, int v) {
         const int o = *p;
@@ -149,6 +171,7 @@ template <int W, int AP, int HW> struct Scratch {
     double rP64[AP];            // float64 root priors (noisy root only)
     int16_t rC[AP];
     u64 hdrw[HW];               // its header (position, parent, move, expanded)
+    u64 leafst[2][W];           // the leaf's stones while its observation planes are assembled
     int16_t freetop[AZ_FREE_PREFETCH];
     int free_base;              // freetop[i] == free_stack[free_base + i]
 };
@@ -203,18 +226,23 @@ template <class Wv, int N, int GAME> struct Engine {
     }
 
     AZ_HD bool action_legal(const S& s, int a) const {
-        if (a < NP) return (s.legal[a >> 6] >> (a & 63)) & 1ull;
+        if (a < NP) {
+            const int wi = a >> 6;
+            u64 word = 0;
+            for (int i = 0; i < W; ++i) word = (i == wi) ? s.legal[i] : word;
+            return (word >> (a & 63)) & 1ull;
+        }
         return GAME == AZ_GO && !(s.flags & AZF_TERMINAL);  // go_engine.py:441 pass is always legal
     }
 
     // ---- node pool --------------------------------------------------------------------------
     AZ_HD int alloc_node() {
-        if (gr.n_free <= 0) {
+        if (Wv::uni(gr.n_free) <= 0) {
             fail(AZ_ERR_NODES);
             return 0;
         }
-        const int pos = gr.n_free - 1, rel = pos - sc.free_base;
-        const int idx = (rel >= 0 && rel < AZ_FREE_PREFETCH) ? (int)sc.freetop[rel] : (int)m.free_stack[(size_t)g * c.max_nodes + pos];
+        const int pos = Wv::uni(gr.n_free) - 1, rel = pos - Wv::uni(sc.free_base);
+        const int idx = Wv::uni((rel >= 0 && rel < AZ_FREE_PREFETCH) ? (int)sc.freetop[rel] : (int)m.free_stack[(size_t)g * c.max_nodes + pos]);
         if (Wv::first()) gr.n_free -= 1;
         Wv::sync();
         cnt[AZC_NODES_CREATED]++;
@@ -336,16 +364,20 @@ template <class Wv, int N, int GAME> struct Engine {
     AZ_HD int puct_argmax(bool at_root, int n_self) {
         const S& s = staged_hdr().st;
         int ti = n_self < c.tab_len ? n_self : c.tab_len - 1;
-        const bool fresh = at_root && gr.root_fresh;
-        const double pbc64 = fresh ? m.pbc_py[ti] : m.pbc_np[ti];
+        const bool fresh = at_root && Wv::uni(gr.root_fresh);
+        const double pbc64 = Wv::uni(fresh ? m.pbc_py[ti] : m.pbc_np[ti]);
         const float pbc32 = (float)pbc64;
-        const float sq32 = m.sqrt32[ti];
-        const bool noisy = at_root && gr.root_noisy;
+        const float sq32 = Wv::uni(m.sqrt32[ti]);
+        const bool noisy = at_root && Wv::uni(gr.root_noisy);
+        u64 lg[W];
+        for (int i = 0; i < W; ++i) lg[i] = Wv::uni(s.legal[i]);
+        const bool pass_ok = GAME == AZ_GO && !(Wv::uni((int)s.flags) & AZF_TERMINAL);
         cnt[AZC_NODE_VISITS]++;
         return Wv::argmax_first([&](int lane, double& best, int& bi) {
             for (int j = 0; j < EPL; ++j) {
-                const int a = lane + 64 * j;
-                if (a >= A || !action_legal(s, a)) continue;
+                const int a = lane + 64 * j;  // word index of point a is j, its bit is the lane
+                if (a >= A) continue;
+                if (!(a < NP ? (j < W && ((lg[j < W ? j : 0] >> lane) & 1ull) != 0) : pass_ok)) continue;
                 const float n = sc.rN[a], w = sc.rW[a];
                 const float q = w / (n > 0.0f ? n : 1.0f);
                 const float r = sq32 / (1.0f + n);
@@ -368,8 +400,8 @@ template <class Wv, int N, int GAME> struct Engine {
     // One descent from the root.  Returns 0 = leaf reached (unexpanded, non-terminal), 1 = terminal.
     // On return `leaf_state` holds the leaf's position (used for the observation planes).
     AZ_HD int descend(int& node_out, int& depth_out, S& leaf_state) {
-        int node = gr.root, depth = 0, n_self = gr.root_N;
-        stage_node(node, gr.root_noisy != 0);
+        int node = Wv::uni(gr.root), depth = 0, n_self = Wv::uni(gr.root_N);
+        stage_node(node, Wv::uni(gr.root_noisy) != 0);
         for (;;) {
             const int mv = puct_argmax(depth == 0, n_self);
             if (depth >= AZ_PATH_CAP) {
@@ -379,8 +411,8 @@ template <class Wv, int N, int GAME> struct Engine {
                 leaf_state = staged_hdr().st;
                 return 1;
             }
-            int child = sc.rC[mv];
-            n_self = (int)sc.rN[mv];
+            int child = Wv::uni((int)sc.rC[mv]);
+            n_self = Wv::uni((int)sc.rN[mv]);
             if (Wv::first()) sc.path[depth] = (node << 16) | mv;
             depth++;
             if (child < 0) {  // lazy child creation (mcts_v2.py:182-183); its position is computed once, here
@@ -404,12 +436,13 @@ template <class Wv, int N, int GAME> struct Engine {
             node = child;
             stage_node(node, false);
             const Hdr& h = staged_hdr();
-            if ((h.st.flags & AZF_TERMINAL) || !h.expanded) {
-                leaf_state = h.st;
+            const int hflags = Wv::uni((int)h.st.flags), hexp = Wv::uni((int)h.expanded);
+            if ((hflags & AZF_TERMINAL) || !hexp) {
+                leaf_state = R::uni_state(h.st);
                 node_out = node;
                 depth_out = depth;
                 Wv::sync();
-                return (h.st.flags & AZF_TERMINAL) ? 1 : 0;
+                return (hflags & AZF_TERMINAL) ? 1 : 0;
             }
         }
     }
@@ -417,12 +450,18 @@ template <class Wv, int N, int GAME> struct Engine {
     // ---- observation planes (base.py:228-259) -------------------------------------------------
     // board k plies back from `leaf`: the leaf, its ancestors up to the root, then the real-game history
     AZ_HD void gather_planes(int leaf, int depth, int me, const S* leaf_state = nullptr) {
+        if (leaf_state) {  // register-resident position -> LDS, so that the per-lane plane pick is an LDS index, not scratch
+            if (Wv::first())
+                for (int q = 0; q < 2; ++q)
+                    for (int w = 0; w < W; ++w) sc.leafst[q][w] = leaf_state->stones[q][w];
+            Wv::sync();
+        }
         Wv::lanes([&](int lane) {
             for (int t = lane; t < 16 * W; t += AZ_WAVE) {
                 const int w = t % W, pc = t / W, k = pc >> 1, col = (pc & 1) ? 1 - me : me;
                 u64 v;
                 if (depth < 0) v = gr.hist[k][col][w];  // the real position: the history ring itself
-                else if (k == 0) v = leaf_state ? leaf_state->stones[col][w] : hdr(leaf).st.stones[col][w];
+                else if (k == 0) v = leaf_state ? sc.leafst[col][w] : hdr(leaf).st.stones[col][w];
                 else if (k <= depth) v = hdr(sc.path[depth - k] >> 16).st.stones[col][w];
                 else v = gr.hist[k - depth][col][w];
                 sc.planes[pc][w] = v;
@@ -456,7 +495,8 @@ template <class Wv, int N, int GAME> struct Engine {
         unsigned char* vrow = valid + (size_t)g * c.P;
         if (Wv::first()) sc.free_base = -(1 << 30);  // no staged free-stack window yet
         Wv::sync();
-        if (gr.status == AZS_NEED_ROOT) {
+        const int status = Wv::uni(gr.status);
+        if (status == AZS_NEED_ROOT) {
             // mcts_v2.py:364-368: the root position itself is evaluated first
             if (gr.root < 0) {
                 const int r = alloc_node();
@@ -484,7 +524,7 @@ template <class Wv, int N, int GAME> struct Engine {
             return;
         }
         int nleaf = 0;
-        if (gr.status == AZS_SEARCH && !gr.noise_pending) {
+        if (status == AZS_SEARCH && !Wv::uni(gr.noise_pending)) {
             int attempts = 0;
             {  // the next pops of the free stack, staged once per round
                 const int base = gr.n_free - AZ_FREE_PREFETCH;
@@ -509,8 +549,8 @@ template <class Wv, int N, int GAME> struct Engine {
                     // mcts_v2.py:407-411 / :604-608: back up -reward, node stays unexpanded
                     cnt[AZC_TERMINAL_HITS]++;
                     path_update(sc.path, depth, (float)(-(int)leaf.reward), true, true);
-                    if (!c.parallel_mode && gr.root_N < c.budget) attempts = 0;  // uct_search keeps looping (:378)
-                    if (!c.parallel_mode && gr.root_N >= c.budget) break;
+                    if (!c.parallel_mode && Wv::uni(gr.root_N) < c.budget) attempts = 0;  // uct_search keeps looping (:378)
+                    if (!c.parallel_mode && Wv::uni(gr.root_N) >= c.budget) break;
                     continue;
                 }
                 if (c.parallel_mode) path_update(sc.path, depth, 1.0f, false, false);  // add_virtual_loss :453-467
@@ -555,8 +595,8 @@ template <class Wv, int N, int GAME> struct Engine {
     }
     AZ_HD void apply_outputs(const float* priors, const float* values) {
         const size_t row0 = (size_t)g * c.P;
-        if (gr.root_eval_pending) {
-            expand_node(gr.root, priors + row0 * A);
+        if (Wv::uni(gr.root_eval_pending)) {
+            expand_node(Wv::uni(gr.root), priors + row0 * A);
             if (Wv::first()) {
                 gr.root_N = 1;  // backup(root, value) on DummyNode slots: 0.0 + 1, 0.0 + value
                 gr.root_W = (double)values[row0];
@@ -569,12 +609,12 @@ template <class Wv, int N, int GAME> struct Engine {
             Wv::sync();
             return;
         }
-        const int nl = gr.n_leaves;
+        const int nl = Wv::uni(gr.n_leaves);
         for (int s = 0; s < nl; ++s) {
-            const int node = gr.leaf_node[s], depth = gr.leaf_depth[s];
+            const int node = Wv::uni((int)gr.leaf_node[s]), depth = Wv::uni((int)gr.leaf_depth[s]);
             const int* lp = leaf_path(s);
             if (c.parallel_mode) path_update(lp, depth, -1.0f, false, false);  // revert_virtual_loss :470-482
-            if (hdr(node).expanded) {  // picked twice in one round: evaluation wasted (:621-622)
+            if (Wv::uni((int)hdr(node).expanded)) {  // picked twice in one round: evaluation wasted (:621-622)
                 cnt[AZC_DUP_LEAVES]++;
                 continue;
             }
@@ -1056,21 +1096,30 @@ template <class Wv, int N, int GAME> struct Engine {
 
     // ---- one engine round for this game ---------------------------------------------------------
     AZ_HD void flush_counters() {
-        if (Wv::first())
+        if (Wv::first()) {
+            u64* row = m.counters + (size_t)g * AZC_COUNT;
             for (int i = 0; i < AZC_COUNT; ++i)
-                if (cnt[i]) AzAtomic::add(m.counters + i, cnt[i]);
+                if (cnt[i]) row[i] += cnt[i];
+        }
     }
-    // phase A+B: consume the evaluator's outputs, finish as many moves as the budget allows
-    AZ_HD void advance(const float* priors, const float* values) {
-        if (gr.status == AZS_WAIT_BUF) next_game();
-        if (gr.root_eval_pending || gr.n_leaves > 0) apply_outputs(priors, values);
+    // phase A: consume the evaluator's outputs
+    AZ_HD void backup_phase(const float* priors, const float* values) {
+        if (Wv::uni(gr.root_eval_pending) || Wv::uni(gr.n_leaves) > 0) apply_outputs(priors, values);
+    }
+    // phase B: finish as many moves as the budget allows (rare per round and per game)
+    AZ_HD void endmove_phase() {
+        if (Wv::uni(gr.status) == AZS_WAIT_BUF) next_game();
         for (int guard = 0; guard < 8; ++guard) {
-            if (gr.status != AZS_SEARCH) break;
-            if (gr.noise_pending && (!c.stop_after_move || gr.noise_ready)) apply_noise();
-            if (gr.noise_pending) break;  // drop-in mode: the noise vector arrives with begin_move
-            if (gr.root_N < c.budget) break;
+            if (Wv::uni(gr.status) != AZS_SEARCH) break;
+            if (Wv::uni(gr.noise_pending) && (!c.stop_after_move || Wv::uni(gr.noise_ready))) apply_noise();
+            if (Wv::uni(gr.noise_pending)) break;  // drop-in mode: the noise vector arrives with begin_move
+            if (Wv::uni(gr.root_N) < c.budget) break;
             search_done();
         }
+    }
+    AZ_HD void advance(const float* priors, const float* values) {
+        backup_phase(priors, values);
+        endmove_phase();
     }
     AZ_HD void round(const float* priors, const float* values, void* feat, unsigned char* valid) {
         advance(priors, values);

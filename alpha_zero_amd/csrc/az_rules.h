@@ -44,10 +44,28 @@ template <class Wv, int N> struct Rules {
     static constexpr int W = O::W;
     typedef EnvState<W> S;
 
-    static AZ_HD B ld(const u64* p) {
+    static AZ_HD B ld(const u64* p) {  // wave-uniform load of a bitboard (SGPRs on the device)
         B r;
-        for (int i = 0; i < W; ++i) r.w[i] = p[i];
+        for (int i = 0; i < W; ++i) r.w[i] = Wv::uni(p[i]);
         return r;
+    }
+    // a scalarised copy of a position: every field pinned to SGPRs
+    static AZ_HD S uni_state(const S& s) {
+        S o;
+        for (int q = 0; q < 2; ++q)
+            for (int i = 0; i < W; ++i) o.stones[q][i] = Wv::uni(s.stones[q][i]);
+        for (int i = 0; i < W; ++i) o.legal[i] = Wv::uni(s.legal[i]);
+        o.ko = (int16_t)Wv::uni((int)s.ko);
+        o.steps = (int16_t)Wv::uni((int)s.steps);
+        o.to_play = (uint8_t)Wv::uni((int)s.to_play);
+        o.flags = (uint8_t)Wv::uni((int)s.flags);
+        o.winner = (int8_t)Wv::uni((int)s.winner);
+        o.reward = (int8_t)Wv::uni((int)s.reward);
+        o.caps[0] = (uint16_t)Wv::uni((int)s.caps[0]);
+        o.caps[1] = (uint16_t)Wv::uni((int)s.caps[1]);
+        o.area[0] = (int16_t)Wv::uni((int)s.area[0]);
+        o.area[1] = (int16_t)Wv::uni((int)s.area[1]);
+        return o;
     }
     static AZ_HD void st(u64* p, const B& b) {
         for (int i = 0; i < W; ++i) p[i] = b.w[i];
@@ -95,7 +113,7 @@ template <class Wv, int N> struct Rules {
             }
             legal = O::bor(O::andnot(empty, cand), O::band(cand, O::nbr(okstones)));
         }
-        if (ko >= 0) legal.w[ko >> 6] &= ~(1ull << (ko & 63));  // :437-438
+        if (ko >= 0) legal = O::andnot(legal, O::bit(ko));  // :437-438
         return legal;
     }
 
@@ -124,9 +142,12 @@ template <class Wv, int N> struct Rules {
     }
 
     // GoEnv.step for a board point or pass (go.py:121-161).  `a` must be legal.
-    static AZ_HD void go_step(const S& s, int a, const RuleCfg& rc, S& o) {
+    static AZ_HD void go_step(const S& s_in, int a, const RuleCfg& rc, S& o) {
+        const S s = uni_state(s_in);
         const int c = s.to_play;
-        B own = ld(s.stones[c]), opp = ld(s.stones[1 - c]);
+        // colour-indexed fields are picked with selects (a runtime array index would spill the position to scratch)
+        const B sb = ld(s.stones[0]), sw = ld(s.stones[1]);
+        B own = c == 0 ? sb : sw, opp = c == 0 ? sw : sb;
         int ko = -1, ncap = 0;
         if (a != NP) {
             const B mb = O::bit(a);
@@ -144,10 +165,10 @@ template <class Wv, int N> struct Rules {
                 if (ncap == 1 && koish) ko = O::first(captured);  // :491-494
             }
         }
-        st(o.stones[c], own);
-        st(o.stones[1 - c], opp);
-        o.caps[c] = (uint16_t)(s.caps[c] + ncap);  // :496-499
-        o.caps[1 - c] = s.caps[1 - c];
+        st(o.stones[0], c == 0 ? own : opp);
+        st(o.stones[1], c == 0 ? opp : own);
+        o.caps[0] = (uint16_t)(s.caps[0] + (c == 0 ? ncap : 0));  // :496-499
+        o.caps[1] = (uint16_t)(s.caps[1] + (c == 0 ? 0 : ncap));
         o.ko = (int16_t)ko;  // pass clears ko (:448)
         o.steps = (int16_t)(s.steps + 1);
         o.to_play = (uint8_t)(1 - c);
@@ -188,12 +209,14 @@ template <class Wv, int N> struct Rules {
             ++n;
         }
     }
-    static AZ_HD void gomoku_step(const S& s, int a, const RuleCfg& rc, S& o) {
+    static AZ_HD void gomoku_step(const S& s_in, int a, const RuleCfg& rc, S& o) {
+        const S s = uni_state(s_in);
         const int c = s.to_play;
-        B own = O::bor(ld(s.stones[c]), O::bit(a));
-        const B opp = ld(s.stones[1 - c]);
-        st(o.stones[c], own);
-        st(o.stones[1 - c], opp);
+        const B sb = ld(s.stones[0]), sw = ld(s.stones[1]);
+        B own = O::bor(c == 0 ? sb : sw, O::bit(a));
+        const B opp = c == 0 ? sw : sb;
+        st(o.stones[0], c == 0 ? own : opp);
+        st(o.stones[1], c == 0 ? opp : own);
         st(o.legal, O::inv(O::bor(own, opp)));  // gomoku.py:63: only the played point changes; never cleared at the end
         o.ko = -1;
         o.steps = (int16_t)(s.steps + 1);

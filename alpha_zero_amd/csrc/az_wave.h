@@ -67,9 +67,21 @@ struct WaveDev {
         if (idx < 0) s = -1.0e300;
         double m = max_f64(s);
         int cand = (idx >= 0 && s == m) ? idx : 0x7fffffff;
-        return min_i32(cand);
+        return __builtin_amdgcn_readfirstlane(min_i32(cand));
     }
     static AZ_D int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+    // Tell the compiler that `v` is wave-uniform (it is, by construction: loaded through a uniform address or
+    // produced by a reduction): the value moves to SGPRs and everything computed from it runs on the scalar unit
+    // instead of being replicated in 64 VGPR lanes.  Memory loads are "divergent" to LLVM unless proven otherwise.
+    template <class T> static AZ_D T uni(T v) {
+        static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 16, "uni(): 4/8/16-byte values");
+        int w[sizeof(T) / 4];
+        __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+        for (unsigned i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+        __builtin_memcpy(&v, w, sizeof(T));
+        return v;
+    }
     // Sum over lanes of a double (butterfly: every lane ends with the same value).
     template <class F> static AZ_D double sum_f64(F&& f) {
         double v = f(lane());
@@ -114,6 +126,7 @@ struct WaveHost {
         return bi;
     }
     static int bcast0(int v) { return v; }
+    template <class T> static T uni(T v) { return v; }
     template <class F> static double sum_f64(F&& f) {
         // same butterfly order as the device so that non-integer sums (production noise) agree as well
         double v[AZ_WAVE];

@@ -33,18 +33,32 @@ struct OpReset {
         e.new_game();
     }
 };
-struct OpRound {
+// One engine round = three launches over all games (one wave per game each):
+//   OpBackup   expand + backup of the previous leaf batch                       (hot, light)
+//   OpEndMove  policy / move / sample / env step / re-root / noise for the games whose budget is met
+//              (about 1 game in 18 per round; heavy double-precision code lives only here)
+//   OpSelect   the next <= P descents per game + observation planes             (hot, the dominant kernel)
+// Keeping the rare, register-hungry end-of-move code out of the two hot kernels keeps them at 4 waves per SIMD.
+struct OpBackup {
     const float* priors;
     const float* values;
+    template <class E> AZ_HD void operator()(E& e) const {
+        e.backup_phase(priors, values);
+        e.flush_counters();
+    }
+};
+struct OpEndMove {
+    template <class E> AZ_HD void operator()(E& e) const {
+        e.endmove_phase();
+        e.flush_counters();
+    }
+};
+struct OpSelect {
     void* feat;
     unsigned char* valid;
-    int do_advance, do_select;
     template <class E> AZ_HD void operator()(E& e) const {
-        if (do_advance) e.advance(priors, values);
-        if (do_select) {
-            e.select(feat, valid);
-            e.cnt[AZC_ROUNDS]++;
-        }
+        e.select(feat, valid);
+        e.cnt[AZC_ROUNDS]++;
         e.flush_counters();
     }
 };
@@ -106,7 +120,8 @@ struct OpSetState {
         s.winner = -1;
         s.reward = 0;
         s.area[0] = s.area[1] = 0;
-        const typename E::B own = R::ld(s.stones[s.to_play]), opp = R::ld(s.stones[1 - s.to_play]);
+        const typename E::B sb = R::ld(s.stones[0]), sw = R::ld(s.stones[1]);
+        const typename E::B own = s.to_play == 0 ? sb : sw, opp = s.to_play == 0 ? sw : sb;
         const typename E::B legal = E::GAME_ID == AZ_GO ? R::go_legal(own, opp, s.ko) : O::inv(O::bor(own, opp));
         R::st(s.legal, legal);
         if (E::Wave::first()) {
@@ -210,14 +225,23 @@ struct OpHarvest {
             int* sh = e.m.stg_hdr + ((size_t)e.g * 2 + b) * SH_COUNT;
             if (sh[SH_STATE] != AZB_COMPLETE) continue;
             const int len = sh[SH_LEN];
-            int start = 0, gi = 0;
+            int start = -1, gi = 0;
             if (E::Wave::first()) {
-                start = AzAtomic::fetch_add_i32(out_counts, len);
-                gi = AzAtomic::fetch_add_i32(out_counts + 1, 1);
-                if (start + len > cap || gi >= max_games) {  // no room this time: roll back, keep the buffer
-                    AzAtomic::fetch_add_i32(out_counts, -len);
-                    AzAtomic::fetch_add_i32(out_counts + 1, -1);
-                    start = -1;
+                // all-or-nothing reservation of (samples, games) in ONE 64-bit word: no roll-back, so the
+                // output indices stay dense whatever the interleaving of the waves
+                u64* word = (u64*)out_counts;
+                u64 old = AzAtomic::load_u64(word);
+                for (;;) {
+                    const int ns = (int)(old & 0xffffffffu), ng = (int)(old >> 32);
+                    if (ns + len > cap || ng >= max_games) break;  // no room this time: keep the buffer
+                    const u64 want = ((u64)(ng + 1) << 32) | (u64)(ns + len);
+                    const u64 seen = AzAtomic::cas_u64(word, old, want);
+                    if (seen == old) {
+                        start = ns;
+                        gi = ng;
+                        break;
+                    }
+                    old = seen;
                 }
             }
             start = E::Wave::bcast0(start);
@@ -483,7 +507,7 @@ int azsp_create(const AzspConfig* p, void** out) {
     m.log_pi = az_new<double>(h, G * c.log_cap * h->A);
     m.log_childN = az_new<float>(h, G * c.log_cap * h->A);
     m.log_q = az_new<double>(h, G * c.log_cap * 4);
-    m.counters = az_new<u64>(h, AZC_COUNT);
+    m.counters = az_new<u64>(h, G * AZC_COUNT);
     m.err = az_new<int>(h, 4);
     h->d_status = az_new<int>(h, G * 8);
     h->d_q = az_new<double>(h, G * 2);
@@ -608,22 +632,23 @@ int azsp_begin_move(void* e, const double* noise, int32_t warm_up, void* stream)
 int azsp_select(void* e, void* feat, uint8_t* valid, void* stream) {
     AzHandle* h = (AzHandle*)e;
     if (!h || !feat || !valid) return AZSP_EINVAL;
-    OpRound op = {nullptr, nullptr, feat, valid, 0, 1};
+    OpSelect op = {feat, valid};
     return az_run(h, op, stream);
 }
 
 int azsp_expand_backup(void* e, const float* priors, const float* values, void* stream) {
     AzHandle* h = (AzHandle*)e;
     if (!h || !priors || !values) return AZSP_EINVAL;
-    OpRound op = {priors, values, nullptr, nullptr, 1, 0};
-    return az_run(h, op, stream);
+    OpBackup op = {priors, values};
+    int rc = az_run(h, op, stream);
+    if (rc) return rc;
+    return az_run(h, OpEndMove(), stream);
 }
 
 int azsp_round(void* e, const float* priors, const float* values, void* feat, uint8_t* valid, void* stream) {
-    AzHandle* h = (AzHandle*)e;
-    if (!h || !priors || !values || !feat || !valid) return AZSP_EINVAL;
-    OpRound op = {priors, values, feat, valid, 1, 1};
-    return az_run(h, op, stream);
+    int rc = azsp_expand_backup(e, priors, values, stream);
+    if (rc) return rc;
+    return azsp_select(e, feat, valid, stream);
 }
 
 int azsp_get_status(void* e, int32_t* status, double* q, void* stream) {
@@ -675,8 +700,13 @@ int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int3
 int azsp_counters(void* e, uint64_t* out, int32_t reset, void* stream) {
     AzHandle* h = (AzHandle*)e;
     if (!h || !out) return AZSP_EINVAL;
-    if (azb::d2h(out, h->mem.counters, sizeof(u64) * AZC_COUNT, stream)) return AZSP_EDEVICE;
-    if (reset && azb::zero(h->mem.counters, sizeof(u64) * AZC_COUNT, stream)) return AZSP_EDEVICE;
+    const size_t G = (size_t)h->cfg.G;
+    std::vector<u64> rows(G * AZC_COUNT);
+    if (azb::d2h(rows.data(), h->mem.counters, sizeof(u64) * G * AZC_COUNT, stream)) return AZSP_EDEVICE;
+    for (int i = 0; i < AZC_COUNT; ++i) out[i] = 0;
+    for (size_t g = 0; g < G; ++g)  // telemetry only: per-game rows are summed here instead of contended device atomics
+        for (int i = 0; i < AZC_COUNT; ++i) out[i] += rows[g * AZC_COUNT + i];
+    if (reset && azb::zero(h->mem.counters, sizeof(u64) * G * AZC_COUNT, stream)) return AZSP_EDEVICE;
     return AZSP_OK;
 }
 

@@ -175,7 +175,7 @@ def main():
                     traffic = pj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_game<OpRound> (expand/backup + end-of-move + select + features)", "bound": "hbm",
+        roofline = {"kernel": "k_game<OpSelect> (PUCT descents + virtual loss + observation planes)", "bound": "hbm",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4)}
         flops_eval = net_flops_per_eval(n, A, args.blocks, args.filters, args.filters, game != "go")
