@@ -158,6 +158,7 @@ struct Philox {
 #define AZ_LDS_NODES 1024  // parent table of the re-root pass lives in LDS up to this pool size
 
 #define AZ_FREE_PREFETCH 64
+typedef u64 __attribute__((may_alias)) u64a;  // word copies of typed records (no strict-aliasing assumptions)
 
 template <int W, int AP, int HW> struct Scratch {
     u64 planes[16][W];          // observation planes being assembled / history shift buffer
@@ -170,7 +171,7 @@ template <int W, int AP, int HW> struct Scratch {
     float rN[AP], rW[AP], rP[AP];
     double rP64[AP];            // float64 root priors (noisy root only)
     int16_t rC[AP];
-    u64 hdrw[HW];               // its header (position, parent, move, expanded)
+    u64a hdrw[HW];              // its header (position, parent, move, expanded); may_alias words, read back as Hdr
     u64 leafst[2][W];           // the leaf's stones while its observation planes are assembled
     int16_t freetop[AZ_FREE_PREFETCH];
     int free_base;              // freetop[i] == free_stack[free_base + i]
@@ -345,7 +346,7 @@ template <class Wv, int N, int GAME> struct Engine {
         const float* rw = rowW(node);
         const float* rp = rowP(node);
         const int16_t* rc = rowC(node);
-        const u64* hw = (const u64*)rec(node);
+        const u64a* hw = (const u64a*)rec(node);
         const double* rp64 = rootP();
         Wv::lanes([&](int lane) {
             if (lane < HW) sc.hdrw[lane] = hw[lane];

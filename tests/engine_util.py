@@ -27,7 +27,7 @@ def hosttwin_binding():
         deps = [src] + [os.path.join(ROOT, "alpha_zero_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "alpha_zero_amd", "csrc"))
                         if f.endswith(".h")] + [os.path.join(ROOT, "include", "azsp.h")]
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing", "-o", so, src])
         _twin = _abi.Binding(ctypes.CDLL(so), "hosttwin")
     return _twin
 
