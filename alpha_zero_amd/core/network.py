@@ -64,10 +64,14 @@ def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 class InferenceNet(nn.Module):
     """Frozen, BN-folded, channels-last copy of an AlphaZeroNet for the engine's leaf batches."""
 
-    def __init__(self, net: AlphaZeroNet, dtype=torch.bfloat16, channels_last=True):
+    def __init__(self, net: AlphaZeroNet, dtype=torch.bfloat16, channels_last=True, binding=None):
+        """binding: the libazsp Binding; when given (and the activations are channels-last on the GPU) every 3x3
+        convolution is followed by ONE fused kernel (azsp_bias_act: bias + residual + ReLU) instead of the separate
+        bias-add / add / clamp passes PyTorch would launch."""
         super().__init__()
         net = net.eval()
         self.dtype = dtype
+        self.binding = binding if channels_last else None
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.stem_pad = net.conv_block[0].padding[0]
         with torch.no_grad():
@@ -90,15 +94,31 @@ class InferenceNet(nn.Module):
             self.val_fc2_w = nn.Parameter(net.value_head[6].weight.to(dtype), requires_grad=False)
             self.val_fc2_b = nn.Parameter(net.value_head[6].bias.to(dtype), requires_grad=False)
 
+    def _epilogue(self, y, bias, res=None):
+        """relu(y + bias [+ res]) in place on a channels-last activation."""
+        if self.binding is not None and y.is_cuda and y.is_contiguous(memory_format=torch.channels_last) and y.shape[1] % 8 == 0:
+            import ctypes
+
+            B, C, H, W = y.shape
+            dt = {torch.float32: 1, torch.bfloat16: 2, torch.float16: 3}[y.dtype]
+            rc = self.binding.dll.azsp_bias_act(y.data_ptr(), bias.data_ptr(), res.data_ptr() if res is not None else None, B * H * W, C,
+                                                dt, 1, ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"azsp_bias_act failed with code {rc}")
+            return y
+        y.add_(bias.view(1, -1, 1, 1))
+        if res is not None:
+            y.add_(res)
+        return F.relu_(y)
+
     @torch.no_grad()
     def forward(self, x, priors_out=None, values_out=None):
         """x: [B,17,N,N] any dtype -> (priors fp32 [B,A], values fp32 [B])."""
         x = x.to(self.dtype).contiguous(memory_format=self.mf)
-        x = F.relu_(F.conv2d(x, self.w[0], self.b[0], padding=self.stem_pad))
+        x = self._epilogue(F.conv2d(x, self.w[0], None, padding=self.stem_pad), self.b[0])
         for i in range(self.n_blocks):
-            y = F.relu_(F.conv2d(x, self.w[1 + 2 * i], self.b[1 + 2 * i], padding=1))
-            y = F.conv2d(y, self.w[2 + 2 * i], self.b[2 + 2 * i], padding=1)
-            x = F.relu_(y.add_(x))
+            y = self._epilogue(F.conv2d(x, self.w[1 + 2 * i], None, padding=1), self.b[1 + 2 * i])
+            x = self._epilogue(F.conv2d(y, self.w[2 + 2 * i], None, padding=1), self.b[2 + 2 * i], x)
         h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
         B = h.shape[0]
         pol = h[:, :2].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)  # NCHW flatten order (nn.Flatten)

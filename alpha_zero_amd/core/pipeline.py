@@ -84,7 +84,7 @@ class SelfPlayActor:
     # -- weights ---------------------------------------------------------------------------------------
     def set_network(self, network: AlphaZeroNet, training_steps=0):
         """Checkpoint hot-swap (pipeline.py:232-239): new weights take effect at the next round."""
-        self.infer = InferenceNet(network, dtype=self.net_dtype).to(self.device)
+        self.infer = InferenceNet(network, dtype=self.net_dtype, binding=self.binding if self.device.type == "cuda" else None).to(self.device)
         self.training_steps = training_steps
         self._graph = None
 
@@ -107,21 +107,25 @@ class SelfPlayActor:
         self._graph = g
 
     # -- rounds ----------------------------------------------------------------------------------------
-    def run_round(self, ev_pair=None):
+    def run_round(self, evs=None):
+        """evs: optional 4 torch.cuda.Events recorded around (expand/backup + end-of-move), select, forward."""
         e = self.engine
-        if ev_pair is not None:
-            ev_pair[0].record()
-        e.round()
-        if ev_pair is not None:
-            ev_pair[1].record()
+        if evs is not None:
+            evs[0].record()
+        e.expand_backup()
+        if evs is not None:
+            evs[1].record()
+        e.select()
+        if evs is not None:
+            evs[2].record()
         if self.use_graph:
             if self._graph is None:
                 self._capture()
             self._graph.replay()
         else:
             self._forward()
-        if ev_pair is not None and len(ev_pair) > 2:
-            ev_pair[2].record()
+        if evs is not None:
+            evs[3].record()
         self.rounds += 1
 
     def run_rounds(self, n):

@@ -24,6 +24,11 @@ __global__ void __launch_bounds__(256) k_dihedral(const DihedralArgs a, long lon
         az_dihedral_elem(a, t);
 }
 
+__global__ void __launch_bounds__(256) k_bias_act(const BiasActArgs a) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.nvec; i += (long long)gridDim.x * blockDim.x)
+        az_bias_act_vec(a, i);
+}
+
 namespace azb {
 void* alloc(size_t n) {
     void* p = nullptr;
@@ -60,6 +65,12 @@ int launch_dihedral(const DihedralArgs& a, long long total, void* st) {
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_dihedral, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a, total);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_bias_act(const BiasActArgs& a, void* st) {
+    long long blocks = (a.nvec + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 blocks per CU
+    hipLaunchKernelGGL(k_bias_act, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a);
     return AZ_HIP(hipGetLastError());
 }
 }  // namespace azb

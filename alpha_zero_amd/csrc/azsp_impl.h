@@ -337,6 +337,91 @@ AZ_HD void az_dihedral_elem(const DihedralArgs& a, long long t) {
     }
 }
 
+// Fused conv epilogue: 8 consecutive channels (16 B of bf16/fp16, 32 B of fp32) per work item, fp32 math, one rounding.
+struct BiasActArgs {
+    void* y;
+    const void* bias;
+    const void* res;
+    long long nvec;  // rows * channels / 8
+    int channels, dtype, relu;
+};
+AZ_HD float az_bf16_to_f32(uint16_t h) {
+    union { u32 u; float f; } v;
+    v.u = (u32)h << 16;
+    return v.f;
+}
+AZ_HD uint16_t az_f32_to_bf16(float f) {  // round to nearest even
+    union { u32 u; float f; } v;
+    v.f = f;
+    const u32 r = v.u + 0x7fffu + ((v.u >> 16) & 1u);
+    return (uint16_t)(r >> 16);
+}
+AZ_HD float az_f16_to_f32(uint16_t h) {
+    union { u32 u; float f; } v;
+    const u32 sign = (u32)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+    if (exp == 0) {  // zero / subnormal: man * 2^-24
+        v.f = (float)man * (1.0f / 16777216.0f);
+        v.u |= sign;
+        return v.f;
+    }
+    v.u = sign | (exp == 31 ? 0x7f800000u : ((exp + 112u) << 23)) | (man << 13);
+    return v.f;
+}
+AZ_HD uint16_t az_f32_to_f16(float f) {  // round to nearest even, overflow -> inf
+    union { u32 u; float f; } v;
+    v.f = f;
+    const u32 sign = (v.u >> 16) & 0x8000u, x = v.u & 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (x < 0x38800000u) {  // subnormal half (or zero): units of 2^-24, round to nearest even via the fp32 adder
+        union { u32 u; float f; } t;
+        t.u = x;
+        t.f = t.f + 0.5f;   // aligns the 2^-24 grid with the fp32 mantissa lsb of values in [0.5, 1)
+        return (uint16_t)(sign | (t.u - 0x3f000000u));
+    }
+    const u32 r = x + 0xfffu + ((x >> 13) & 1u);
+    return (uint16_t)(sign | ((r - 0x38000000u) >> 13));
+}
+AZ_HD void az_bias_act_vec(const BiasActArgs& a, long long i) {
+    const long long e0 = i * 8;
+    const int c0 = (int)(e0 % a.channels);
+    float v[8];
+    if (a.dtype == AZSP_FEAT_BF16) {
+        const uint16_t* y = (const uint16_t*)a.y + e0;
+        const uint16_t* b = (const uint16_t*)a.bias + c0;
+        const uint16_t* r = a.res ? (const uint16_t*)a.res + e0 : nullptr;
+        struct alignas(16) V8 { uint16_t h[8]; };
+        const V8 yv = *(const V8*)y, bv = *(const V8*)b;
+        V8 rv = yv, ov;
+        if (r) rv = *(const V8*)r;
+        for (int k = 0; k < 8; ++k) {
+            v[k] = az_bf16_to_f32(yv.h[k]) + az_bf16_to_f32(bv.h[k]) + (r ? az_bf16_to_f32(rv.h[k]) : 0.0f);
+            if (a.relu && v[k] < 0.0f) v[k] = 0.0f;
+            ov.h[k] = az_f32_to_bf16(v[k]);
+        }
+        *(V8*)((uint16_t*)a.y + e0) = ov;
+    } else if (a.dtype == AZSP_FEAT_F16) {
+        struct alignas(16) V8 { uint16_t h[8]; };
+        const V8 yv = *(const V8*)((const uint16_t*)a.y + e0), bv = *(const V8*)((const uint16_t*)a.bias + c0);
+        V8 rv = yv, ov;
+        if (a.res) rv = *(const V8*)((const uint16_t*)a.res + e0);
+        for (int k = 0; k < 8; ++k) {
+            v[k] = az_f16_to_f32(yv.h[k]) + az_f16_to_f32(bv.h[k]) + (a.res ? az_f16_to_f32(rv.h[k]) : 0.0f);
+            if (a.relu && v[k] < 0.0f) v[k] = 0.0f;
+            ov.h[k] = az_f32_to_f16(v[k]);
+        }
+        *(V8*)((uint16_t*)a.y + e0) = ov;
+    } else {
+        float* y = (float*)a.y + e0;
+        const float* b = (const float*)a.bias + c0;
+        const float* r = a.res ? (const float*)a.res + e0 : nullptr;
+        for (int k = 0; k < 8; ++k) {
+            float t = y[k] + b[k] + (r ? r[k] : 0.0f);
+            if (a.relu && t < 0.0f) t = 0.0f;
+            y[k] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // engine handle
 // ------------------------------------------------------------------------------------------------
@@ -368,6 +453,7 @@ int set_device(int dev);
 const char* backend_error();
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream);
 int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
+int launch_bias_act(const BiasActArgs& a, void* stream);
 }  // namespace azb
 
 template <class T> static T* az_new(AzHandle* h, size_t count) {
@@ -719,6 +805,13 @@ int azsp_dihedral(const void* sin, void* sout, int32_t ses, const void* pin, voi
     const long long total = (long long)batch * ch * n * n + (long long)batch * A;
     if (total == 0) return AZSP_OK;
     return azb::launch_dihedral(a, total, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
+}
+
+int azsp_bias_act(void* y, const void* bias, const void* res, int64_t rows, int32_t channels, int32_t dtype, int32_t relu, void* stream) {
+    if (!y || !bias || rows < 0 || channels < 8 || channels % 8 != 0 || dtype < AZSP_FEAT_F32 || dtype > AZSP_FEAT_F16) return AZSP_EINVAL;
+    if (rows == 0) return AZSP_OK;
+    BiasActArgs a = {y, bias, res, (long long)rows * channels / 8, channels, dtype, relu};
+    return azb::launch_bias_act(a, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
 }
 
 }  // extern "C"

@@ -132,8 +132,7 @@ def main():
     barrier()
     harvest_and_gather()
     actor.counters(reset=True)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
     samples_at_root = 0
     barrier()
     t0 = time.perf_counter()
@@ -144,8 +143,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     cnt = actor.counters()
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in evs]))
-    nn_ms = float(np.mean([b.elapsed_time(c) for _, b, c in evs]))
+    bk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # expand/backup + end-of-move kernels
+    k_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))   # select kernel (the dominant hand-written kernel)
+    nn_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
 
     moves = float(cnt["moves"])
     tot = torch.tensor([moves, float(cnt["sims"]), float(cnt["leaves"])], dtype=torch.float64, device=dev)
@@ -178,11 +178,14 @@ def main():
         W = (n * n + 63) // 64
         steps = max(1, args.steps)
         expanded = cnt["leaves"] - cnt["dup_leaves"] + cnt["root_evals"]
-        alg_bytes = (cnt["node_visits"] * 12 * A                 # select: N, W, P rows of every visited node
-                     + expanded * (12 * A + 4 * A + 4)           # expand: write P, init N, W; read priors + value
-                     + cnt["backup_edges"] * 16                  # backup / virtual loss: N, W read-modify-write per edge
-                     + (cnt["leaves"] + cnt["root_evals"]) * (17 * n * n * e_bytes + 16 * W * 8)  # feature planes + 8-board history
-                     ) / steps
+        created = cnt["nodes_created"]
+        vloss_edges = cnt["backup_edges"] - (cnt["sims"] - cnt["leaves"] + expanded)  # informational
+        # select kernel, reference-equivalent dense layout: N, W, P rows of every visited node, the new
+        # node's position, virtual loss read-modify-write of W per path edge, the leaf's 17 planes + 8-board history
+        alg_bytes = (cnt["node_visits"] * 12 * A + created * 64 + cnt["leaves"] * (cnt["backup_edges"] / max(1, cnt["sims"])) * 8
+                     + (cnt["leaves"] + cnt["root_evals"]) * (17 * n * n * e_bytes + 16 * W * 8)) / steps
+        # expand/backup kernel: prior + value in, P/N/W rows out, N and W read-modify-write per path edge (+ vloss revert)
+        bk_bytes = (expanded * (12 * A + 4 * A + 4) + cnt["backup_edges"] * 16 + cnt["leaves"] * 8 * 4.5) / steps
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "round_kernel_pmc.json")
@@ -195,7 +198,9 @@ def main():
                 traffic = None
         roofline = {"kernel": "k_game<OpSelect> (PUCT descents + virtual loss + observation planes)", "bound": "hbm",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4)}
+                    "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4),
+                    "backup_kernels": {"avg_ms": round(bk_ms, 4), "alg_bytes_per_launch": round(bk_bytes),
+                                       "achieved_GBs": round(bk_bytes / (bk_ms * 1e-3) / 1e9, 2)}}
         flops_eval = net_flops_per_eval(n, A, args.blocks, args.filters, args.filters, game != "go")
         nn_tflops = flops_eval * args.games * args.parallel / (nn_ms * 1e-3) / 1e12
         nn_roof = {"kernel": "policy/value ResNet forward on G*P rows (PyTorch-ROCm, MFMA)", "bound": "mfma",

@@ -25,6 +25,7 @@
  *   azsp_harvest                      data_queue.put((game_seq, stats))         (core/pipeline.py:283, :349-380)
  *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
  *                                     (utils/transformation.py:34-110)
+ *   azsp_bias_act                     BatchNorm + residual add + ReLU after each convolution (core/network.py:42-82)
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
  * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
@@ -181,6 +182,13 @@ int azsp_counters(void* engine, uint64_t* counters_host, int32_t reset, void* st
 int azsp_dihedral(const void* states_in_dev, void* states_out_dev, int32_t state_elem_size, const void* pi_in_dev,
                   void* pi_out_dev, int32_t pi_elem_size, int32_t batch, int32_t channels, int32_t board_size,
                   int32_t num_actions, int32_t op, void* stream);
+
+/* Fused convolution epilogue for the leaf evaluator (core/network.py ResNetBlock, network.py:42-82 in eval mode with
+ * BatchNorm folded): y[r][c] = act(y[r][c] + bias[c] (+ residual[r][c])) in place, one pass over HBM instead of the
+ * separate bias / residual-add / ReLU kernels.  y, residual: [rows][channels] (channels-last activations), dtype
+ * AZSP_FEAT_F32 / _BF16 / _F16, channels % 8 == 0; accumulation in fp32, one rounding. */
+int azsp_bias_act(void* y_dev, const void* bias_dev, const void* residual_dev, int64_t rows, int32_t channels, int32_t dtype,
+                  int32_t relu, void* stream);
 
 #ifdef __cplusplus
 }
