@@ -10,7 +10,7 @@ ST_NEED_ROOT, ST_SEARCH, ST_MOVE_DONE, ST_IDLE, ST_WAIT_BUF = 0, 1, 2, 3, 4
 SYMBOLS = [
     "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
     "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
-    "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act",
+    "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act", "azsp_conv3x3",
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
@@ -53,7 +53,7 @@ class Binding:
             "azsp_round": [V, V, V, V, V, V], "azsp_get_status": [V, V, V, V], "azsp_get_search": [V, I, I, V, V, V, V],
             "azsp_commit_move": [V, V, V], "azsp_harvest": [V, V, V, V, I, V, I, P(I), P(I), V],
             "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],
-            "azsp_bias_act": [V, V, V, C.c_int64, I, I, I, V],
+            "azsp_bias_act": [V, V, V, C.c_int64, I, I, I, V], "azsp_conv3x3": [V, V, V, V, V, C.c_int64, I, I, I, V],
         }
         for k, a in sig.items():
             f = getattr(cdll, k)

@@ -72,6 +72,7 @@ class InferenceNet(nn.Module):
         net = net.eval()
         self.dtype = dtype
         self.binding = binding if channels_last else None
+        self.use_fused_conv = True
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.stem_pad = net.conv_block[0].padding[0]
         with torch.no_grad():
@@ -80,6 +81,11 @@ class InferenceNet(nn.Module):
                 convs.append(_fold(blk.conv_block1[0], blk.conv_block1[1]))
                 convs.append(_fold(blk.conv_block2[0], blk.conv_block2[1]))
             self.n_blocks = len(net.res_blocks)
+            # fused MFMA convolution (azsp_conv3x3): weights as [tap = ky*3+kx][cout][cin] bf16, bias fp32
+            self.filters = net.conv_block[0].out_channels
+            self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
+                                                     requires_grad=False) for w, _ in convs[1:]])
+            self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             pw, pb = _fold(net.policy_head[0], net.policy_head[1])
@@ -93,6 +99,25 @@ class InferenceNet(nn.Module):
             self.val_fc1_b = nn.Parameter(net.value_head[4].bias.to(dtype), requires_grad=False)
             self.val_fc2_w = nn.Parameter(net.value_head[6].weight.to(dtype), requires_grad=False)
             self.val_fc2_b = nn.Parameter(net.value_head[6].bias.to(dtype), requires_grad=False)
+
+    def _fused_conv_ok(self, x):
+        return (self.binding is not None and self.use_fused_conv and x.is_cuda and x.dtype == torch.bfloat16 and self.filters == 128
+                and x.shape[2] == 9 and x.shape[3] == 9 and x.is_contiguous(memory_format=torch.channels_last))
+
+    def _conv(self, x, i, res=None):
+        """relu(conv3x3(x) + bias [+ res]) of tower convolution i (0-based): one hand-written MFMA kernel when the shape is
+        supported, else the library convolution followed by the fused epilogue kernel."""
+        if self._fused_conv_ok(x):
+            import ctypes
+
+            y = torch.empty_like(x)
+            rc = self.binding.dll.azsp_conv3x3(x.data_ptr(), self.wp[i].data_ptr(), self.b32[i].data_ptr(), res.data_ptr() if res is not None else None,
+                                               y.data_ptr(), x.shape[0], x.shape[2], x.shape[1], 1,
+                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"azsp_conv3x3 failed with code {rc}")
+            return y
+        return self._epilogue(F.conv2d(x, self.w[1 + i], None, padding=1), self.b[1 + i], res)
 
     def _epilogue(self, y, bias, res=None):
         """relu(y + bias [+ res]) in place on a channels-last activation."""
@@ -117,8 +142,8 @@ class InferenceNet(nn.Module):
         x = x.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._epilogue(F.conv2d(x, self.w[0], None, padding=self.stem_pad), self.b[0])
         for i in range(self.n_blocks):
-            y = self._epilogue(F.conv2d(x, self.w[1 + 2 * i], None, padding=1), self.b[1 + 2 * i])
-            x = self._epilogue(F.conv2d(y, self.w[2 + 2 * i], None, padding=1), self.b[2 + 2 * i], x)
+            y = self._conv(x, 2 * i)
+            x = self._conv(y, 2 * i + 1, x)
         h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
         B = h.shape[0]
         pol = h[:, :2].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)  # NCHW flatten order (nn.Flatten)

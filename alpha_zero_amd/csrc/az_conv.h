@@ -1,0 +1,210 @@
+// az_conv.h -- fused 3x3 convolution of the leaf evaluator's residual tower for gfx950:
+//     y = relu(conv3x3(x, w) + bias [+ residual])      x, y, residual: [boards][9][9][128] bf16 (channels-last)
+// (reference: alpha_zero/core/network.py:42-82 ResNetBlock in eval mode, BatchNorm folded into w / bias).
+//
+// Implicit GEMM on the matrix cores, D[cout][position] = sum over 9 taps x 128 cin:
+//   * v_mfma_f32_32x32x16_bf16; A operand = weights W[tap][cout][cin], B operand = activations X[position][cin]
+//     (both fragments are 8 consecutive cin = one 16-B LDS read per lane).
+//   * one persistent 256-thread workgroup per CU, tile = 3 boards = 243 positions (padded to 256 columns);
+//     wave w owns columns [64w, 64w+64) x all 128 couts = 4x2 MFMA tiles = 128 accumulator registers.
+//   * the 3 boards sit in LDS once, zero-haloed (11x11), so the 9 taps are 9 shifted reads of the same tile:
+//     HBM sees every activation exactly once per convolution; weights stream per tap through a 2 x 32 KB LDS ring.
+//   * all LDS rows are 256 B; the 16-B chunk index is XOR-ed with (row & 15) so that 32 lanes reading one chunk
+//     column of 32 consecutive rows spread over all banks.
+//   * epilogue fused: bias + residual + ReLU + bf16 rounding on the accumulators, staged through LDS so that
+//     HBM is written (and the residual read) in full coalesced 16-B chunks.
+#pragma once
+#include <stdint.h>
+
+#define CV_C 128
+#define CV_S 9
+#define CV_TB 3
+#define CV_P2 (CV_S * CV_S)                   // 81
+#define CV_PS (CV_S + 2)                      // 11
+#define CV_PP (CV_PS * CV_PS)                 // 121
+#define CV_ROWB (CV_C * 2)                    // 256 bytes per position / per cout row
+#define CV_NPOS (CV_TB * CV_P2)               // 243
+#define CV_XS_BYTES (CV_TB * CV_PP * CV_ROWB) // 92,928
+#define CV_WBUF (CV_C * CV_ROWB)              // 32,768 per tap
+#define CV_WS_BYTES (2 * CV_WBUF)
+
+#if defined(__HIPCC__)
+typedef __attribute__((ext_vector_type(8))) __bf16 cv_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float cv_f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int cv_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int cv_u32x2;
+
+__device__ __forceinline__ unsigned cv_swz(unsigned row, unsigned chunk) { return row * CV_ROWB + ((chunk ^ (row & 15u)) << 4); }
+__device__ __forceinline__ unsigned cv_pack_bf16(float a, float b) {  // round to nearest even
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+    return ua | (ub << 16);
+}
+__device__ __forceinline__ float cv_bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float cv_bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+
+__global__ void __launch_bounds__(256, 1)
+k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
+                  const unsigned short* __restrict__ res, unsigned short* __restrict__ y, int nboards, int relu) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[CV_XS_BYTES + CV_WS_BYTES];
+    unsigned char* Xs = lds;
+    unsigned char* Ws = lds + CV_XS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+
+    // zero the whole activation tile once: interior rows are overwritten per tile, the halo stays zero
+    for (int i = tid * 16; i < CV_XS_BYTES; i += 256 * 16) *(cv_u32x4*)(Xs + i) = (cv_u32x4){0u, 0u, 0u, 0u};
+
+    // bias of the couts this lane produces: cout = mt*32 + 8*rq + 4*hi + e
+    float bq[4][4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bq[mt][rq][e] = bias[mt * 32 + 8 * rq + 4 * hi + e];
+
+    // this lane's two output columns (positions inside the tile) and their padded-board rows
+    int pos[2], prow[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int p = wave * 64 + nt * 32 + l31;
+        pos[nt] = p;
+        const int b = p / CV_P2, q = p - b * CV_P2, yy = q / CV_S, xx = q - yy * CV_S;
+        prow[nt] = p < CV_NPOS ? b * CV_PP + (yy + 1) * CV_PS + (xx + 1) : 0;  // padding columns read the zero halo row 0
+    }
+
+    const int ntiles = (nboards + CV_TB - 1) / CV_TB;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int rows = min(CV_TB, nboards - tile * CV_TB) * CV_P2;  // valid positions in this tile
+        const size_t gbase = (size_t)tile * CV_NPOS * CV_C;          // element offset of the tile in x / y / res
+        __syncthreads();  // previous tile fully stored; Xs / Ws free
+
+        // ---- activations: global -> registers -> LDS (zero-haloed 11x11 boards, swizzled chunks) ----
+        for (int idx = tid; idx < CV_NPOS * 16; idx += 256) {
+            const int r = idx >> 4, c = idx & 15;
+            cv_u32x4 v = (cv_u32x4){0u, 0u, 0u, 0u};
+            if (r < rows) v = *(const cv_u32x4*)(x + gbase + (size_t)r * CV_C + c * 8);
+            const int b = r / CV_P2, q = r - b * CV_P2, yy = q / CV_S, xx = q - yy * CV_S;
+            const unsigned pr = b * CV_PP + (yy + 1) * CV_PS + (xx + 1);
+            *(cv_u32x4*)(Xs + cv_swz(pr, c)) = v;
+        }
+
+        cv_f32x16 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
+
+        // weights of tap 0 -> registers (8 x 16 B per thread: 128 couts x 16 chunks)
+        cv_u32x4 wreg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wreg[i] = *(const cv_u32x4*)(w + (size_t)(tid + 256 * i) * 8);
+
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            unsigned char* Wb = Ws + (tap & 1) * CV_WBUF;
+            // registers -> LDS ring slot (last read two taps ago, before the previous barrier)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
+                *(cv_u32x4*)(Wb + cv_swz(r, c)) = wreg[i];
+            }
+            if (tap < 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wreg[i] = *(const cv_u32x4*)(w + (size_t)(tap + 1) * CV_C * CV_C + (size_t)(tid + 256 * i) * 8);
+            }
+            __syncthreads();
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * CV_PS + dx;
+            const unsigned pr0 = (unsigned)(prow[0] + (pos[0] < CV_NPOS ? shift : 0));
+            const unsigned pr1 = (unsigned)(prow[1] + (pos[1] < CV_NPOS ? shift : 0));
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const unsigned ch = (unsigned)(ks * 2 + hi);
+                cv_bf16x8 a[4], b[2];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *(const cv_bf16x8*)(Wb + cv_swz((unsigned)(mt * 32 + l31), ch));
+                b[0] = *(const cv_bf16x8*)(Xs + cv_swz(pr0, ch));
+                b[1] = *(const cv_bf16x8*)(Xs + cv_swz(pr1, ch));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // all MFMA operand reads done: Ws is free for the epilogue tile
+
+        // ---- epilogue: residual tile -> LDS (rows = positions, 256 B, swizzled), in-place update, coalesced store ----
+        unsigned char* Os = Ws;
+        if (res) {
+            for (int idx = tid; idx < CV_NPOS * 16; idx += 256) {
+                const int r = idx >> 4, c = idx & 15;
+                if (r < rows) *(cv_u32x4*)(Os + cv_swz(r, c)) = *(const cv_u32x4*)(res + gbase + (size_t)r * CV_C + c * 8);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int p = pos[nt];
+            if (p < rows) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        // D layout of mfma_f32_32x32x16: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+                        const unsigned cout0 = (unsigned)(mt * 32 + 8 * rq + 4 * hi);  // 4 consecutive couts = 8 bytes
+                        unsigned char* slot = Os + cv_swz((unsigned)p, cout0 >> 3) + ((cout0 & 7u) << 1);
+                        float v0 = acc[mt][nt][rq * 4 + 0] + bq[mt][rq][0], v1 = acc[mt][nt][rq * 4 + 1] + bq[mt][rq][1];
+                        float v2 = acc[mt][nt][rq * 4 + 2] + bq[mt][rq][2], v3 = acc[mt][nt][rq * 4 + 3] + bq[mt][rq][3];
+                        if (res) {
+                            const cv_u32x2 rr = *(const cv_u32x2*)slot;
+                            v0 += cv_bf16_lo(rr.x); v1 += cv_bf16_hi(rr.x); v2 += cv_bf16_lo(rr.y); v3 += cv_bf16_hi(rr.y);
+                        }
+                        if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+                        *(cv_u32x2*)slot = (cv_u32x2){cv_pack_bf16(v0, v1), cv_pack_bf16(v2, v3)};
+                    }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < CV_NPOS * 16; idx += 256) {
+            const int r = idx >> 4, c = idx & 15;
+            if (r < rows) *(cv_u32x4*)(y + gbase + (size_t)r * CV_C + c * 8) = *(const cv_u32x4*)(Os + cv_swz(r, c));
+        }
+    }
+}
+#endif  // __HIPCC__
+
+// Plain reference loop (host twin build only: lets the CPU tier exercise the ABI entry on tiny inputs).
+static inline float cv_h_bf16(unsigned short h) {
+    union { unsigned u; float f; } v;
+    v.u = (unsigned)h << 16;
+    return v.f;
+}
+static inline unsigned short cv_h_to_bf16(float f) {
+    union { unsigned u; float f; } v;
+    v.f = f;
+    return (unsigned short)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);
+}
+static inline void cv_host_conv3x3(const unsigned short* x, const unsigned short* w, const float* bias, const unsigned short* res,
+                                   unsigned short* y, int nboards, int S, int C, int relu) {
+    for (int b = 0; b < nboards; ++b)
+        for (int yy = 0; yy < S; ++yy)
+            for (int xx = 0; xx < S; ++xx)
+                for (int co = 0; co < C; ++co) {
+                    float acc = 0.0f;
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+                        if (sy < 0 || sx < 0 || sy >= S || sx >= S) continue;
+                        const unsigned short* xi = x + ((size_t)(b * S + sy) * S + sx) * C;
+                        const unsigned short* wi = w + ((size_t)tap * C + co) * C;
+                        for (int ci = 0; ci < C; ++ci) acc += cv_h_bf16(xi[ci]) * cv_h_bf16(wi[ci]);
+                    }
+                    const size_t o = ((size_t)(b * S + yy) * S + xx) * C + co;
+                    float v = acc + bias[co] + (res ? cv_h_bf16(res[o]) : 0.0f);
+                    if (relu && v < 0.0f) v = 0.0f;
+                    y[o] = cv_h_to_bf16(v);
+                }
+}

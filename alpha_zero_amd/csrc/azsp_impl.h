@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/azsp.h"
+#include "az_conv.h"
 #include "az_engine.h"
 
 #define AZ_FOR_EACH_VARIANT(X) \
@@ -454,6 +455,9 @@ const char* backend_error();
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream);
 int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
 int launch_bias_act(const BiasActArgs& a, void* stream);
+// returns 0 ok, 1 unsupported shape, -1 launch error
+int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
+                   void* stream);
 }  // namespace azb
 
 template <class T> static T* az_new(AzHandle* h, size_t count) {
@@ -812,6 +816,14 @@ int azsp_bias_act(void* y, const void* bias, const void* res, int64_t rows, int3
     if (rows == 0) return AZSP_OK;
     BiasActArgs a = {y, bias, res, (long long)rows * channels / 8, channels, dtype, relu};
     return azb::launch_bias_act(a, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
+}
+
+int azsp_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
+                 int32_t relu, void* stream) {
+    if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_conv3x3(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
 }  // extern "C"

@@ -26,6 +26,7 @@
  *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
  *                                     (utils/transformation.py:34-110)
  *   azsp_bias_act                     BatchNorm + residual add + ReLU after each convolution (core/network.py:42-82)
+ *   azsp_conv3x3                      a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
  * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
@@ -189,6 +190,13 @@ int azsp_dihedral(const void* states_in_dev, void* states_out_dev, int32_t state
  * AZSP_FEAT_F32 / _BF16 / _F16, channels % 8 == 0; accumulation in fp32, one rounding. */
 int azsp_bias_act(void* y_dev, const void* bias_dev, const void* residual_dev, int64_t rows, int32_t channels, int32_t dtype,
                   int32_t relu, void* stream);
+
+/* Fused 3x3 convolution of the residual tower (core/network.py:42-82, eval mode, BatchNorm folded):
+ * y = act(conv3x3(x, w) + bias [+ residual]) on channels-last bf16 activations [boards][S][S][C]; w_packed is
+ * [9 taps (ky*3+kx)][C out][C in] bf16, bias float[C].  MFMA implicit GEMM; supported on the device for S = 9, C = 128
+ * (returns AZSP_EINVAL otherwise so the caller can use its library convolution + azsp_bias_act). */
+int azsp_conv3x3(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
+                 int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
 
 #ifdef __cplusplus
 }

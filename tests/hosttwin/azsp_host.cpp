@@ -32,4 +32,8 @@ int launch_bias_act(const BiasActArgs& a, void*) {
     for (long long i = 0; i < a.nvec; ++i) az_bias_act_vec(a, i);
     return 0;
 }
+int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void*) {
+    cv_host_conv3x3((const unsigned short*)x, (const unsigned short*)w, bias, (const unsigned short*)res, (unsigned short*)y, (int)boards, S, C, relu);
+    return 0;
+}
 }  // namespace azb

@@ -67,3 +67,56 @@ def test_gpu_inference_net_fused_epilogue(golden_dir, dtype, tol_p, tol_v):
     pri, v = inf(d["x"].cuda())
     assert (pri.cpu() - torch.softmax(d["logits"], -1)).abs().max() <= tol_p
     assert (v.cpu() - d["value"].squeeze(1)).abs().max() <= tol_v
+
+
+def _conv_ref(x, w, b, res):
+    y = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), padding=1)
+    if res is not None:
+        y = y + res.float()
+    return torch.relu(y)
+
+
+def test_fused_conv_abi_host_twin():
+    """azsp_conv3x3 through the ABI (host twin: plain loop restatement) vs torch conv2d on a tiny case."""
+    import engine_util as eu
+
+    b = eu.hosttwin_binding()
+    g = torch.Generator().manual_seed(1)
+    C, S, B = 16, 5, 2
+    x = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.2).to(torch.bfloat16)
+    bias = torch.randn(C, generator=g)
+    wp = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
+    for r in (None, res):
+        y = torch.empty_like(x)
+        rc = b.dll.azsp_conv3x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, S, C, 1, None)
+        assert rc == 0
+        ref = _conv_ref(x, w, bias, r)
+        assert (y.float() - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 3, 7, 1000])
+def test_gpu_fused_conv3x3_matches_torch(boards):
+    """The MFMA kernel (9x9, 128 channels, bf16) vs an fp32 torch convolution of the same bf16 operands; tolerance = bf16
+    output rounding.  Asymmetric random weights catch any row/column or tap mix-up; partial last tiles are covered."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    g = torch.Generator().manual_seed(boards)
+    C, S = 128, 9
+    x = torch.randn(boards, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    res = torch.randn(boards, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    wp = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
+    for r in (None, res):
+        y = torch.empty_like(x)
+        rc = bnd.dll.azsp_conv3x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(),
+                                  boards, S, C, 1, None)
+        torch.cuda.synchronize()
+        assert rc == 0
+        ref = _conv_ref(x, w, bias, r)
+        err = (y.float() - ref).abs().max().item()
+        assert err <= 1.0 / 128 * max(1.0, ref.abs().max().item()), err

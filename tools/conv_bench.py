@@ -1,0 +1,52 @@
+"""Times the fused MFMA conv3x3 kernel against the library convolution + fused epilogue at the bench shape."""
+import ctypes
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from alpha_zero_amd import _lib
+
+b = _lib.load()
+B, C, S = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 128, 9
+g = torch.Generator().manual_seed(0)
+x = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+res = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+bias = torch.randn(C, generator=g).cuda()
+bias16 = bias.to(torch.bfloat16)
+wp = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
+y = torch.empty_like(x)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+torch.backends.cudnn.benchmark = True
+
+
+def mine(r):
+    b.dll.azsp_conv3x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, S, C, 1, st)
+
+
+def lib(r):
+    t = torch.nn.functional.conv2d(x, w, None, padding=1)
+    b.dll.azsp_bias_act(t.data_ptr(), bias16.data_ptr(), r.data_ptr() if r is not None else None, B * S * S, C, 2, 1, st)
+    return t
+
+
+flops = 2.0 * B * S * S * C * C * 9
+for name, f in (("fused_mfma", mine), ("miopen+epilogue", lib)):
+    for r in (None, res):
+        for _ in range(5):
+            f(r)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            f(r)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"{name:16s} residual={r is not None!s:5s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s")
+ref = lib(res).float()
+mine(res)
+torch.cuda.synchronize()
+print("max |fused - library|:", (y.float() - ref).abs().max().item())
