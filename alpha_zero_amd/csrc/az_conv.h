@@ -5,8 +5,8 @@
 // Implicit GEMM on the matrix cores, D[cout][position] = sum over 9 taps x 128 cin:
 //   * v_mfma_f32_32x32x16_bf16; A operand = weights W[tap][cout][cin], B operand = activations X[position][cin]
 //     (both fragments are 8 consecutive cin = one 16-B LDS read per lane).
-//   * one persistent 256-thread workgroup per CU, tile = 3 boards = 243 positions (padded to 256 columns);
-//     wave w owns columns [64w, 64w+64) x all 128 couts = 4x2 MFMA tiles = 128 accumulator registers.
+//   * one persistent 512-thread workgroup per CU, tile = 3 boards = 243 positions (padded to 256 columns);
+//     8 waves = 2 cout halves x 4 column quarters, each 2x2 MFMA tiles (64 accumulator registers), 2 waves per SIMD.
 //   * the 3 boards sit in LDS once, zero-haloed (11x11), so the 9 taps are 9 shifted reads of the same tile:
 //     HBM sees every activation exactly once per convolution; weights stream per tap through a 2 x 32 KB LDS ring.
 //   * all LDS rows are 256 B; the 16-B chunk index is XOR-ed with (row & 15) so that 32 lanes reading one chunk
@@ -44,92 +44,118 @@ __device__ __forceinline__ unsigned cv_pack_bf16(float a, float b) {  // round t
 __device__ __forceinline__ float cv_bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float cv_bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
-__global__ void __launch_bounds__(256, 1)
+#define CV_THREADS 512
+#define CV_XCH ((CV_NPOS * 16 + CV_THREADS - 1) / CV_THREADS)  // 16-B activation chunks staged per thread (8)
+#define CV_WCH (CV_C * 16 / CV_THREADS)                        // 16-B weight chunks per thread per tap (4)
+
+// 8 waves = 2 (cout halves) x 4 (column quarters); two waves share each SIMD, so one wave's LDS fragment reads hide
+// behind the other's MFMAs.  Next tile's activations and this tile's residual are prefetched into registers while
+// the matrix cores run, so HBM latency never sits on the critical path.
+__global__ void __launch_bounds__(CV_THREADS, 2)
 k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
                   const unsigned short* __restrict__ res, unsigned short* __restrict__ y, int nboards, int relu) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[CV_XS_BYTES + CV_WS_BYTES];
     unsigned char* Xs = lds;
     unsigned char* Ws = lds + CV_XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int mh = wave & 1, nq = wave >> 1;  // cout half, column quarter
 
     // zero the whole activation tile once: interior rows are overwritten per tile, the halo stays zero
-    for (int i = tid * 16; i < CV_XS_BYTES; i += 256 * 16) *(cv_u32x4*)(Xs + i) = (cv_u32x4){0u, 0u, 0u, 0u};
-
-    // bias of the couts this lane produces: cout = mt*32 + 8*rq + 4*hi + e
-    float bq[4][4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bq[mt][rq][e] = bias[mt * 32 + 8 * rq + 4 * hi + e];
+    for (int i = tid * 16; i < CV_XS_BYTES; i += CV_THREADS * 16) *(cv_u32x4*)(Xs + i) = (cv_u32x4){0u, 0u, 0u, 0u};
 
     // this lane's two output columns (positions inside the tile) and their padded-board rows
     int pos[2], prow[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int p = wave * 64 + nt * 32 + l31;
+        const int p = nq * 64 + nt * 32 + l31;
         pos[nt] = p;
         const int b = p / CV_P2, q = p - b * CV_P2, yy = q / CV_S, xx = q - yy * CV_S;
         prow[nt] = p < CV_NPOS ? b * CV_PP + (yy + 1) * CV_PS + (xx + 1) : 0;  // padding columns read the zero halo row 0
     }
-
     const int ntiles = (nboards + CV_TB - 1) / CV_TB;
+    cv_u32x4 xreg[CV_XCH];
+    {   // first tile's activations
+        const int tile = blockIdx.x;
+        const int rows = tile < ntiles ? min(CV_TB, nboards - tile * CV_TB) * CV_P2 : 0;
+        const size_t gbase = (size_t)tile * CV_NPOS * CV_C;
+#pragma unroll
+        for (int i = 0; i < CV_XCH; ++i) {
+            xreg[i] = (cv_u32x4){0u, 0u, 0u, 0u};
+            if (((tid + CV_THREADS * i) >> 4) < rows) xreg[i] = *(const cv_u32x4*)(x + gbase + (size_t)(tid + CV_THREADS * i) * 8);
+        }
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int rows = min(CV_TB, nboards - tile * CV_TB) * CV_P2;  // valid positions in this tile
         const size_t gbase = (size_t)tile * CV_NPOS * CV_C;          // element offset of the tile in x / y / res
         __syncthreads();  // previous tile fully stored; Xs / Ws free
 
-        // ---- activations: global -> registers -> LDS (zero-haloed 11x11 boards, swizzled chunks) ----
-        for (int idx = tid; idx < CV_NPOS * 16; idx += 256) {
-            const int r = idx >> 4, c = idx & 15;
-            cv_u32x4 v = (cv_u32x4){0u, 0u, 0u, 0u};
-            if (r < rows) v = *(const cv_u32x4*)(x + gbase + (size_t)r * CV_C + c * 8);
+        // ---- activations: prefetched registers -> LDS (zero-haloed 11x11 boards, swizzled chunks) ----
+#pragma unroll
+        for (int i = 0; i < CV_XCH; ++i) {
+            const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
             const int b = r / CV_P2, q = r - b * CV_P2, yy = q / CV_S, xx = q - yy * CV_S;
-            const unsigned pr = b * CV_PP + (yy + 1) * CV_PS + (xx + 1);
-            *(cv_u32x4*)(Xs + cv_swz(pr, c)) = v;
+            if (r < CV_NPOS) *(cv_u32x4*)(Xs + cv_swz((unsigned)(b * CV_PP + (yy + 1) * CV_PS + (xx + 1)), (unsigned)c)) = xreg[i];
         }
 
-        cv_f32x16 acc[4][2];
+        cv_f32x16 acc[2][2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
 
-        // weights of tap 0 -> registers (8 x 16 B per thread: 128 couts x 16 chunks)
-        cv_u32x4 wreg[8];
+        // weights of tap 0 -> registers (4 x 16 B per thread: 128 couts x 16 chunks)
+        cv_u32x4 wreg[CV_WCH];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wreg[i] = *(const cv_u32x4*)(w + (size_t)(tid + 256 * i) * 8);
+        for (int i = 0; i < CV_WCH; ++i) wreg[i] = *(const cv_u32x4*)(w + (size_t)(tid + CV_THREADS * i) * 8);
+        cv_u32x4 rreg[CV_XCH];
 
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             unsigned char* Wb = Ws + (tap & 1) * CV_WBUF;
             // registers -> LDS ring slot (last read two taps ago, before the previous barrier)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + 256 * i, r = idx >> 4, c = idx & 15;
+            for (int i = 0; i < CV_WCH; ++i) {
+                const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
                 *(cv_u32x4*)(Wb + cv_swz(r, c)) = wreg[i];
             }
             if (tap < 8) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wreg[i] = *(const cv_u32x4*)(w + (size_t)(tap + 1) * CV_C * CV_C + (size_t)(tid + 256 * i) * 8);
+                for (int i = 0; i < CV_WCH; ++i)
+                    wreg[i] = *(const cv_u32x4*)(w + (size_t)(tap + 1) * CV_C * CV_C + (size_t)(tid + CV_THREADS * i) * 8);
+            }
+            if (tap == 2) {  // next tile's activations: in flight under the remaining taps
+                const int nxt = tile + gridDim.x;
+                const int nrows = nxt < ntiles ? min(CV_TB, nboards - nxt * CV_TB) * CV_P2 : 0;
+                const size_t nbase = (size_t)nxt * CV_NPOS * CV_C;
+#pragma unroll
+                for (int i = 0; i < CV_XCH; ++i) {
+                    xreg[i] = (cv_u32x4){0u, 0u, 0u, 0u};
+                    if (((tid + CV_THREADS * i) >> 4) < nrows) xreg[i] = *(const cv_u32x4*)(x + nbase + (size_t)(tid + CV_THREADS * i) * 8);
+                }
+            }
+            if (tap == 5 && res) {  // this tile's residual
+#pragma unroll
+                for (int i = 0; i < CV_XCH; ++i) {
+                    rreg[i] = (cv_u32x4){0u, 0u, 0u, 0u};
+                    if (((tid + CV_THREADS * i) >> 4) < rows) rreg[i] = *(const cv_u32x4*)(res + gbase + (size_t)(tid + CV_THREADS * i) * 8);
+                }
             }
             __syncthreads();
             const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * CV_PS + dx;
             const unsigned pr0 = (unsigned)(prow[0] + (pos[0] < CV_NPOS ? shift : 0));
             const unsigned pr1 = (unsigned)(prow[1] + (pos[1] < CV_NPOS ? shift : 0));
-#pragma unroll
+#pragma unroll 2
             for (int ks = 0; ks < 8; ++ks) {
                 const unsigned ch = (unsigned)(ks * 2 + hi);
-                cv_bf16x8 a[4], b[2];
+                cv_bf16x8 a[2], b[2];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a[mt] = *(const cv_bf16x8*)(Wb + cv_swz((unsigned)(mt * 32 + l31), ch));
+                for (int mt = 0; mt < 2; ++mt) a[mt] = *(const cv_bf16x8*)(Wb + cv_swz((unsigned)((2 * mh + mt) * 32 + l31), ch));
                 b[0] = *(const cv_bf16x8*)(Xs + cv_swz(pr0, ch));
                 b[1] = *(const cv_bf16x8*)(Xs + cv_swz(pr1, ch));
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < 2; ++mt) {
                     acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][0], 0, 0, 0);
                     acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][1], 0, 0, 0);
                 }
@@ -137,12 +163,13 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
         }
         __syncthreads();  // all MFMA operand reads done: Ws is free for the epilogue tile
 
-        // ---- epilogue: residual tile -> LDS (rows = positions, 256 B, swizzled), in-place update, coalesced store ----
+        // ---- epilogue: residual registers -> LDS (rows = positions, 256 B, swizzled), in-place update, coalesced store ----
         unsigned char* Os = Ws;
         if (res) {
-            for (int idx = tid; idx < CV_NPOS * 16; idx += 256) {
-                const int r = idx >> 4, c = idx & 15;
-                if (r < rows) *(cv_u32x4*)(Os + cv_swz(r, c)) = *(const cv_u32x4*)(res + gbase + (size_t)r * CV_C + c * 8);
+#pragma unroll
+            for (int i = 0; i < CV_XCH; ++i) {
+                const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
+                if (r < rows) *(cv_u32x4*)(Os + cv_swz(r, c)) = rreg[i];
             }
             __syncthreads();
         }
@@ -151,14 +178,15 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
             const int p = pos[nt];
             if (p < rows) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         // D layout of mfma_f32_32x32x16: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-                        const unsigned cout0 = (unsigned)(mt * 32 + 8 * rq + 4 * hi);  // 4 consecutive couts = 8 bytes
+                        const unsigned cout0 = (unsigned)((2 * mh + mt) * 32 + 8 * rq + 4 * hi);  // 4 consecutive couts = 8 bytes
                         unsigned char* slot = Os + cv_swz((unsigned)p, cout0 >> 3) + ((cout0 & 7u) << 1);
-                        float v0 = acc[mt][nt][rq * 4 + 0] + bq[mt][rq][0], v1 = acc[mt][nt][rq * 4 + 1] + bq[mt][rq][1];
-                        float v2 = acc[mt][nt][rq * 4 + 2] + bq[mt][rq][2], v3 = acc[mt][nt][rq * 4 + 3] + bq[mt][rq][3];
+                        const float4 bv = *(const float4*)(bias + cout0);  // L1-resident, 512 B in total
+                        float v0 = acc[mt][nt][rq * 4 + 0] + bv.x, v1 = acc[mt][nt][rq * 4 + 1] + bv.y;
+                        float v2 = acc[mt][nt][rq * 4 + 2] + bv.z, v3 = acc[mt][nt][rq * 4 + 3] + bv.w;
                         if (res) {
                             const cv_u32x2 rr = *(const cv_u32x2*)slot;
                             v0 += cv_bf16_lo(rr.x); v1 += cv_bf16_hi(rr.x); v2 += cv_bf16_lo(rr.y); v3 += cv_bf16_hi(rr.y);
@@ -169,9 +197,10 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
             }
         }
         __syncthreads();
-        for (int idx = tid; idx < CV_NPOS * 16; idx += 256) {
-            const int r = idx >> 4, c = idx & 15;
-            if (r < rows) *(cv_u32x4*)(y + gbase + (size_t)r * CV_C + c * 8) = *(const cv_u32x4*)(Os + cv_swz(r, c));
+#pragma unroll
+        for (int i = 0; i < CV_XCH; ++i) {
+            const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
+            if (r < rows) *(cv_u32x4*)(y + gbase + (size_t)idx * 8) = *(const cv_u32x4*)(Os + cv_swz(r, c));
         }
     }
 }
