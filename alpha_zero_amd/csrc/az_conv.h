@@ -7,10 +7,13 @@
 //     (both fragments are 8 consecutive cin = one 16-B LDS read per lane).
 //   * one persistent 512-thread workgroup per CU, tile = 3 boards = 243 positions (padded to 256 columns);
 //     8 waves = 2 cout halves x 4 column quarters, each 2x2 MFMA tiles (64 accumulator registers), 2 waves per SIMD.
-//   * the 3 boards sit in LDS once, zero-haloed (11x11), so the 9 taps are 9 shifted reads of the same tile:
-//     HBM sees every activation exactly once per convolution; weights stream per tap through a 2 x 32 KB LDS ring.
-//   * all LDS rows are 256 B; the 16-B chunk index is XOR-ed with (row & 15) so that 32 lanes reading one chunk
-//     column of 32 consecutive rows spread over all banks.
+//   * the 3 boards sit in LDS once (row = position, plus one all-zero row that off-board taps read), so the 9 taps
+//     are 9 shifted reads of the same tile: HBM sees every activation exactly once per convolution; weights stream
+//     per tap through a 2 x 32 KB LDS ring.
+//   * all LDS rows are 256 B; the 16-B chunk index is XOR-ed with (row & 15).  A 16-lane ds_read_b128 group always
+//     holds 16 rows that are distinct mod 16 (positions shifted by a per-tap constant), i.e. 16 distinct chunks =
+//     all 64 banks exactly once: conflict-free for every tap (measured before this layout: 40 % of LDS cycles were
+//     bank-conflict cycles with 11x11 halo-padded rows).
 //   * epilogue fused: bias + residual + ReLU + bf16 rounding on the accumulators, staged through LDS so that
 //     HBM is written (and the residual read) in full coalesced 16-B chunks.
 #pragma once
@@ -24,7 +27,8 @@
 #define CV_PP (CV_PS * CV_PS)                 // 121
 #define CV_ROWB (CV_C * 2)                    // 256 bytes per position / per cout row
 #define CV_NPOS (CV_TB * CV_P2)               // 243
-#define CV_XS_BYTES (CV_TB * CV_PP * CV_ROWB) // 92,928
+#define CV_ZROW CV_NPOS                        // LDS row 243 is all zeros: what an off-board tap reads
+#define CV_XS_BYTES ((CV_NPOS + 1) * CV_ROWB)  // 62,464: rows = the tile's positions (no halo padding) + the zero row
 #define CV_WBUF (CV_C * CV_ROWB)              // 32,768 per tap
 #define CV_WS_BYTES (2 * CV_WBUF)
 
@@ -44,6 +48,10 @@ __device__ __forceinline__ unsigned cv_pack_bf16(float a, float b) {  // round t
 __device__ __forceinline__ float cv_bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float cv_bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait
+// for the global prefetches (next tap's weights, next tile's activations, the residual) that were issued precisely so
+// that they stay in flight under the MFMAs; the compiler still inserts the counted vmcnt wait at their first use.
+#define CV_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define CV_THREADS 512
 #define CV_XCH ((CV_NPOS * 16 + CV_THREADS - 1) / CV_THREADS)  // 16-B activation chunks staged per thread (8)
 #define CV_WCH (CV_C * 16 / CV_THREADS)                        // 16-B weight chunks per thread per tap (4)
@@ -53,24 +61,25 @@ __device__ __forceinline__ float cv_bf16_hi(unsigned v) { return __uint_as_float
 // the matrix cores run, so HBM latency never sits on the critical path.
 __global__ void __launch_bounds__(CV_THREADS, 2)
 k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
-                  const unsigned short* __restrict__ res, unsigned short* __restrict__ y, int nboards, int relu) {
+                  const unsigned short* __restrict__ res, unsigned short* __restrict__ y, int nboards, int relu, int ablate) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[CV_XS_BYTES + CV_WS_BYTES];
     unsigned char* Xs = lds;
     unsigned char* Ws = lds + CV_XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int mh = wave & 1, nq = wave >> 1;  // cout half, column quarter
 
-    // zero the whole activation tile once: interior rows are overwritten per tile, the halo stays zero
-    for (int i = tid * 16; i < CV_XS_BYTES; i += CV_THREADS * 16) *(cv_u32x4*)(Xs + i) = (cv_u32x4){0u, 0u, 0u, 0u};
+    // the zero row (never overwritten)
+    if (tid < 16) *(cv_u32x4*)(Xs + CV_ZROW * CV_ROWB + tid * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
 
-    // this lane's two output columns (positions inside the tile) and their padded-board rows
-    int pos[2], prow[2];
+    // this lane's two output columns (positions inside the tile) and their board coordinates
+    int pos[2], py[2], px[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int p = nq * 64 + nt * 32 + l31;
         pos[nt] = p;
-        const int b = p / CV_P2, q = p - b * CV_P2, yy = q / CV_S, xx = q - yy * CV_S;
-        prow[nt] = p < CV_NPOS ? b * CV_PP + (yy + 1) * CV_PS + (xx + 1) : 0;  // padding columns read the zero halo row 0
+        const int b = p / CV_P2, q = p - b * CV_P2;
+        py[nt] = p < CV_NPOS ? q / CV_S : -100;  // padding columns: every tap is "off board" -> zero row
+        px[nt] = q - (q / CV_S) * CV_S;
     }
     const int ntiles = (nboards + CV_TB - 1) / CV_TB;
     cv_u32x4 xreg[CV_XCH];
@@ -87,14 +96,13 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int rows = min(CV_TB, nboards - tile * CV_TB) * CV_P2;  // valid positions in this tile
         const size_t gbase = (size_t)tile * CV_NPOS * CV_C;          // element offset of the tile in x / y / res
-        __syncthreads();  // previous tile fully stored; Xs / Ws free
+        CV_BARRIER();  // previous tile fully stored; Xs / Ws free
 
         // ---- activations: prefetched registers -> LDS (zero-haloed 11x11 boards, swizzled chunks) ----
 #pragma unroll
         for (int i = 0; i < CV_XCH; ++i) {
             const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
-            const int b = r / CV_P2, q = r - b * CV_P2, yy = q / CV_S, xx = q - yy * CV_S;
-            if (r < CV_NPOS) *(cv_u32x4*)(Xs + cv_swz((unsigned)(b * CV_PP + (yy + 1) * CV_PS + (xx + 1)), (unsigned)c)) = xreg[i];
+            if (r < CV_NPOS) *(cv_u32x4*)(Xs + cv_swz((unsigned)r, (unsigned)c)) = xreg[i];
         }
 
         cv_f32x16 acc[2][2];
@@ -120,7 +128,7 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                 const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
                 *(cv_u32x4*)(Wb + cv_swz(r, c)) = wreg[i];
             }
-            if (tap < 8) {
+            if (tap < 8 && !(ablate & 1)) {
 #pragma unroll
                 for (int i = 0; i < CV_WCH; ++i)
                     wreg[i] = *(const cv_u32x4*)(w + (size_t)(tap + 1) * CV_C * CV_C + (size_t)(tid + CV_THREADS * i) * 8);
@@ -142,37 +150,53 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                     if (((tid + CV_THREADS * i) >> 4) < rows) rreg[i] = *(const cv_u32x4*)(res + gbase + (size_t)(tid + CV_THREADS * i) * 8);
                 }
             }
-            __syncthreads();
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * CV_PS + dx;
-            const unsigned pr0 = (unsigned)(prow[0] + (pos[0] < CV_NPOS ? shift : 0));
-            const unsigned pr1 = (unsigned)(prow[1] + (pos[1] < CV_NPOS ? shift : 0));
-#pragma unroll 2
-            for (int ks = 0; ks < 8; ++ks) {
-                const unsigned ch = (unsigned)(ks * 2 + hi);
-                cv_bf16x8 a[2], b[2];
+            CV_BARRIER();
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * CV_S + dx;
+            const bool in0 = (unsigned)(py[0] + dy) < (unsigned)CV_S && (unsigned)(px[0] + dx) < (unsigned)CV_S;
+            const bool in1 = (unsigned)(py[1] + dy) < (unsigned)CV_S && (unsigned)(px[1] + dx) < (unsigned)CV_S;
+            const unsigned pr0 = in0 ? (unsigned)(pos[0] + shift) : (unsigned)CV_ZROW;
+            const unsigned pr1 = in1 ? (unsigned)(pos[1] + shift) : (unsigned)CV_ZROW;
+            if (ablate & 4) continue;
+            // fragment double buffer: the LDS reads of k-step ks+1 are in flight while the MFMAs of k-step ks issue
+            const unsigned arow0 = (unsigned)((2 * mh) * 32 + l31), arow1 = arow0 + 32u;
+            cv_bf16x8 a0[2], b0[2], a1[2], b1[2];
+            a0[0] = *(const cv_bf16x8*)(Wb + cv_swz(arow0, (unsigned)hi));
+            a0[1] = *(const cv_bf16x8*)(Wb + cv_swz(arow1, (unsigned)hi));
+            b0[0] = *(const cv_bf16x8*)(Xs + cv_swz(pr0, (unsigned)hi));
+            b0[1] = *(const cv_bf16x8*)(Xs + cv_swz(pr1, (unsigned)hi));
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) a[mt] = *(const cv_bf16x8*)(Wb + cv_swz((unsigned)((2 * mh + mt) * 32 + l31), ch));
-                b[0] = *(const cv_bf16x8*)(Xs + cv_swz(pr0, ch));
-                b[1] = *(const cv_bf16x8*)(Xs + cv_swz(pr1, ch));
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[0], acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[1], acc[mt][1], 0, 0, 0);
+            for (int kp = 0; kp < 4; ++kp) {
+                const unsigned ch1 = (unsigned)((2 * kp + 1) * 2 + hi), ch2 = (unsigned)((2 * kp + 2) * 2 + hi);
+                a1[0] = *(const cv_bf16x8*)(Wb + cv_swz(arow0, ch1));
+                a1[1] = *(const cv_bf16x8*)(Wb + cv_swz(arow1, ch1));
+                b1[0] = *(const cv_bf16x8*)(Xs + cv_swz(pr0, ch1));
+                b1[1] = *(const cv_bf16x8*)(Xs + cv_swz(pr1, ch1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b0[1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b0[0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b0[1], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kp < 3) {
+                    a0[0] = *(const cv_bf16x8*)(Wb + cv_swz(arow0, ch2));
+                    a0[1] = *(const cv_bf16x8*)(Wb + cv_swz(arow1, ch2));
+                    b0[0] = *(const cv_bf16x8*)(Xs + cv_swz(pr0, ch2));
+                    b0[1] = *(const cv_bf16x8*)(Xs + cv_swz(pr1, ch2));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b1[1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b1[1], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();  // all MFMA operand reads done: Ws is free for the epilogue tile
+        CV_BARRIER();  // all MFMA operand reads done: Ws is free for the epilogue tile
 
-        // ---- epilogue: residual registers -> LDS (rows = positions, 256 B, swizzled), in-place update, coalesced store ----
+        if (ablate & 2) continue;
+        // ---- epilogue: (acc + bias) -> bf16 -> LDS tile (rows = positions, 256 B, swizzled); then ONE coalesced pass adds the
+        //      residual (already sitting in registers in exactly that chunk layout), applies ReLU and writes HBM in 16-B chunks
         unsigned char* Os = Ws;
-        if (res) {
-#pragma unroll
-            for (int i = 0; i < CV_XCH; ++i) {
-                const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
-                if (r < rows) *(cv_u32x4*)(Os + cv_swz(r, c)) = rreg[i];
-            }
-            __syncthreads();
-        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int p = pos[nt];
@@ -187,20 +211,30 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                         const float4 bv = *(const float4*)(bias + cout0);  // L1-resident, 512 B in total
                         float v0 = acc[mt][nt][rq * 4 + 0] + bv.x, v1 = acc[mt][nt][rq * 4 + 1] + bv.y;
                         float v2 = acc[mt][nt][rq * 4 + 2] + bv.z, v3 = acc[mt][nt][rq * 4 + 3] + bv.w;
-                        if (res) {
-                            const cv_u32x2 rr = *(const cv_u32x2*)slot;
-                            v0 += cv_bf16_lo(rr.x); v1 += cv_bf16_hi(rr.x); v2 += cv_bf16_lo(rr.y); v3 += cv_bf16_hi(rr.y);
-                        }
-                        if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+                        if (!res && relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
                         *(cv_u32x2*)slot = (cv_u32x2){cv_pack_bf16(v0, v1), cv_pack_bf16(v2, v3)};
                     }
             }
         }
-        __syncthreads();
+        CV_BARRIER();
 #pragma unroll
         for (int i = 0; i < CV_XCH; ++i) {
             const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
-            if (r < rows) *(cv_u32x4*)(y + gbase + (size_t)idx * 8) = *(const cv_u32x4*)(Os + cv_swz(r, c));
+            if (r < rows) {
+                cv_u32x4 o = *(const cv_u32x4*)(Os + cv_swz(r, c));
+                if (res) {
+                    const cv_u32x4 rr = rreg[i];
+                    unsigned ow[4] = {o.x, o.y, o.z, o.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float lo = cv_bf16_lo(ow[k]) + cv_bf16_lo(rw[k]), hi2 = cv_bf16_hi(ow[k]) + cv_bf16_hi(rw[k]);
+                        if (relu) { lo = fmaxf(lo, 0.0f); hi2 = fmaxf(hi2, 0.0f); }
+                        ow[k] = cv_pack_bf16(lo, hi2);
+                    }
+                    o = (cv_u32x4){ow[0], ow[1], ow[2], ow[3]};
+                }
+                *(cv_u32x4*)(y + gbase + (size_t)idx * 8) = o;
+            }
         }
     }
 }
