@@ -61,7 +61,7 @@ __device__ __forceinline__ float cv_bf16_hi(unsigned v) { return __uint_as_float
 // the matrix cores run, so HBM latency never sits on the critical path.
 __global__ void __launch_bounds__(CV_THREADS, 2)
 k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
-                  const unsigned short* __restrict__ res, unsigned short* __restrict__ y, int nboards, int relu, int ablate) {
+                  const unsigned short* __restrict__ res, unsigned short* __restrict__ y, int nboards, int relu) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[CV_XS_BYTES + CV_WS_BYTES];
     unsigned char* Xs = lds;
     unsigned char* Ws = lds + CV_XS_BYTES;
@@ -128,7 +128,7 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                 const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
                 *(cv_u32x4*)(Wb + cv_swz(r, c)) = wreg[i];
             }
-            if (tap < 8 && !(ablate & 1)) {
+            if (tap < 8) {
 #pragma unroll
                 for (int i = 0; i < CV_WCH; ++i)
                     wreg[i] = *(const cv_u32x4*)(w + (size_t)(tap + 1) * CV_C * CV_C + (size_t)(tid + CV_THREADS * i) * 8);
@@ -156,7 +156,6 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
             const bool in1 = (unsigned)(py[1] + dy) < (unsigned)CV_S && (unsigned)(px[1] + dx) < (unsigned)CV_S;
             const unsigned pr0 = in0 ? (unsigned)(pos[0] + shift) : (unsigned)CV_ZROW;
             const unsigned pr1 = in1 ? (unsigned)(pos[1] + shift) : (unsigned)CV_ZROW;
-            if (ablate & 4) continue;
             // fragment double buffer: the LDS reads of k-step ks+1 are in flight while the MFMAs of k-step ks issue
             const unsigned arow0 = (unsigned)((2 * mh) * 32 + l31), arow1 = arow0 + 32u;
             cv_bf16x8 a0[2], b0[2], a1[2], b1[2];
@@ -193,7 +192,6 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
         }
         CV_BARRIER();  // all MFMA operand reads done: Ws is free for the epilogue tile
 
-        if (ablate & 2) continue;
         // ---- epilogue: (acc + bias) -> bf16 -> LDS tile (rows = positions, 256 B, swizzled); then ONE coalesced pass adds the
         //      residual (already sitting in registers in exactly that chunk layout), applies ReLU and writes HBM in 16-B chunks
         unsigned char* Os = Ws;
@@ -238,6 +236,7 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
         }
     }
 }
+
 #endif  // __HIPCC__
 
 // Plain reference loop (host twin build only: lets the CPU tier exercise the ABI entry on tiny inputs).

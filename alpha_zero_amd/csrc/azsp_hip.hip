@@ -87,7 +87,7 @@ int launch_conv3x3(const void* x, const void* w, const float* bias, const void* 
     const long long ntiles = (boards + CV_TB - 1) / CV_TB;
     const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);  // one persistent workgroup per CU
     hipLaunchKernelGGL(k_conv3x3_c128_s9, dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)st, (const unsigned short*)x, (const unsigned short*)w, bias,
-                       (const unsigned short*)res, (unsigned short*)y, (int)boards, relu, getenv("AZSP_CONV_ABLATE") ? atoi(getenv("AZSP_CONV_ABLATE")) : 0);
+                       (const unsigned short*)res, (unsigned short*)y, (int)boards, relu);
     return AZ_HIP(hipGetLastError());
 }
 }  // namespace azb
