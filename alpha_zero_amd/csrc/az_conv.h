@@ -14,8 +14,8 @@
 //     holds 16 rows that are distinct mod 16 (positions shifted by a per-tap constant), i.e. 16 distinct chunks =
 //     all 64 banks exactly once: conflict-free for every tap (measured before this layout: 40 % of LDS cycles were
 //     bank-conflict cycles with 11x11 halo-padded rows).
-//   * epilogue fused: bias + residual + ReLU + bf16 rounding on the accumulators, staged through LDS so that
-//     HBM is written (and the residual read) in full coalesced 16-B chunks.
+//   * epilogue fused: bias + residual + ReLU + one bf16 rounding straight on the accumulators (the D layout gives each
+//     lane 4 consecutive couts of its position = 8-byte slots of the channels-last row); no LDS round trip.
 #pragma once
 #include <stdint.h>
 
@@ -96,7 +96,7 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int rows = min(CV_TB, nboards - tile * CV_TB) * CV_P2;  // valid positions in this tile
         const size_t gbase = (size_t)tile * CV_NPOS * CV_C;          // element offset of the tile in x / y / res
-        CV_BARRIER();  // previous tile fully stored; Xs / Ws free
+        CV_BARRIER();  // every wave is done reading the previous tile's Xs / Ws
 
         // ---- activations: prefetched registers -> LDS (zero-haloed 11x11 boards, swizzled chunks) ----
 #pragma unroll
@@ -117,7 +117,7 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
         cv_u32x4 wreg[CV_WCH];
 #pragma unroll
         for (int i = 0; i < CV_WCH; ++i) wreg[i] = *(const cv_u32x4*)(w + (size_t)(tid + CV_THREADS * i) * 8);
-        cv_u32x4 rreg[CV_XCH];
+        cv_u32x2 rres[2][2][4];
 
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
@@ -143,12 +143,17 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                     if (((tid + CV_THREADS * i) >> 4) < nrows) xreg[i] = *(const cv_u32x4*)(x + nbase + (size_t)(tid + CV_THREADS * i) * 8);
                 }
             }
-            if (tap == 5 && res) {  // this tile's residual
+            if (tap == 5 && res) {  // this tile's residual, already in the accumulator layout: 4 consecutive couts = 8 B per slot
 #pragma unroll
-                for (int i = 0; i < CV_XCH; ++i) {
-                    rreg[i] = (cv_u32x4){0u, 0u, 0u, 0u};
-                    if (((tid + CV_THREADS * i) >> 4) < rows) rreg[i] = *(const cv_u32x4*)(res + gbase + (size_t)(tid + CV_THREADS * i) * 8);
-                }
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const unsigned cout0 = (unsigned)((2 * mh + mt) * 32 + 8 * rq + 4 * hi);
+                            rres[nt][mt][rq] = (cv_u32x2){0u, 0u};
+                            if (pos[nt] < rows) rres[nt][mt][rq] = *(const cv_u32x2*)(res + gbase + (size_t)pos[nt] * CV_C + cout0);
+                        }
             }
             CV_BARRIER();
             const int dy = tap / 3 - 1, dx = tap % 3 - 1, shift = dy * CV_S + dx;
@@ -157,6 +162,7 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
             const unsigned pr0 = in0 ? (unsigned)(pos[0] + shift) : (unsigned)CV_ZROW;
             const unsigned pr1 = in1 ? (unsigned)(pos[1] + shift) : (unsigned)CV_ZROW;
             // fragment double buffer: the LDS reads of k-step ks+1 are in flight while the MFMAs of k-step ks issue
+            // (a ring of depth 3 was measured 5 % slower: the loop is bound by LDS bandwidth shared by 8 waves, not by latency)
             const unsigned arow0 = (unsigned)((2 * mh) * 32 + l31), arow1 = arow0 + 32u;
             cv_bf16x8 a0[2], b0[2], a1[2], b1[2];
             a0[0] = *(const cv_bf16x8*)(Wb + cv_swz(arow0, (unsigned)hi));
@@ -190,11 +196,10 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        CV_BARRIER();  // all MFMA operand reads done: Ws is free for the epilogue tile
 
-        // ---- epilogue: (acc + bias) -> bf16 -> LDS tile (rows = positions, 256 B, swizzled); then ONE coalesced pass adds the
-        //      residual (already sitting in registers in exactly that chunk layout), applies ReLU and writes HBM in 16-B chunks
-        unsigned char* Os = Ws;
+        // ---- epilogue straight from the accumulators: D layout of mfma_f32_32x32x16 gives each lane, for its column
+        //      (position), 4 consecutive couts per register quad = one 8-byte slot of the channels-last row.  No LDS round
+        //      trip and no extra barrier; the 16-B pieces of a row are merged into full lines by the L2 before they reach HBM.
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int p = pos[nt];
@@ -203,40 +208,21 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
-                        // D layout of mfma_f32_32x32x16: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-                        const unsigned cout0 = (unsigned)((2 * mh + mt) * 32 + 8 * rq + 4 * hi);  // 4 consecutive couts = 8 bytes
-                        unsigned char* slot = Os + cv_swz((unsigned)p, cout0 >> 3) + ((cout0 & 7u) << 1);
+                        const unsigned cout0 = (unsigned)((2 * mh + mt) * 32 + 8 * rq + 4 * hi);
                         const float4 bv = *(const float4*)(bias + cout0);  // L1-resident, 512 B in total
                         float v0 = acc[mt][nt][rq * 4 + 0] + bv.x, v1 = acc[mt][nt][rq * 4 + 1] + bv.y;
                         float v2 = acc[mt][nt][rq * 4 + 2] + bv.z, v3 = acc[mt][nt][rq * 4 + 3] + bv.w;
-                        if (!res && relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
-                        *(cv_u32x2*)slot = (cv_u32x2){cv_pack_bf16(v0, v1), cv_pack_bf16(v2, v3)};
+                        if (res) {
+                            const cv_u32x2 rr = rres[nt][mt][rq];
+                            v0 += cv_bf16_lo(rr.x); v1 += cv_bf16_hi(rr.x); v2 += cv_bf16_lo(rr.y); v3 += cv_bf16_hi(rr.y);
+                        }
+                        if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f); }
+                        *(cv_u32x2*)(y + gbase + (size_t)p * CV_C + cout0) = (cv_u32x2){cv_pack_bf16(v0, v1), cv_pack_bf16(v2, v3)};
                     }
-            }
-        }
-        CV_BARRIER();
-#pragma unroll
-        for (int i = 0; i < CV_XCH; ++i) {
-            const int idx = tid + CV_THREADS * i, r = idx >> 4, c = idx & 15;
-            if (r < rows) {
-                cv_u32x4 o = *(const cv_u32x4*)(Os + cv_swz(r, c));
-                if (res) {
-                    const cv_u32x4 rr = rreg[i];
-                    unsigned ow[4] = {o.x, o.y, o.z, o.w}, rw[4] = {rr.x, rr.y, rr.z, rr.w};
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float lo = cv_bf16_lo(ow[k]) + cv_bf16_lo(rw[k]), hi2 = cv_bf16_hi(ow[k]) + cv_bf16_hi(rw[k]);
-                        if (relu) { lo = fmaxf(lo, 0.0f); hi2 = fmaxf(hi2, 0.0f); }
-                        ow[k] = cv_pack_bf16(lo, hi2);
-                    }
-                    o = (cv_u32x4){ow[0], ow[1], ow[2], ow[3]};
-                }
-                *(cv_u32x4*)(y + gbase + (size_t)idx * 8) = o;
             }
         }
     }
 }
-
 #endif  // __HIPCC__
 
 // Plain reference loop (host twin build only: lets the CPU tier exercise the ABI entry on tiny inputs).
