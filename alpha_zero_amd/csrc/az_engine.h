@@ -20,7 +20,9 @@
 #include <math.h>
 
 #define AZ_MAXP 32        // max leaves per game per round (num_parallel)
-#define AZ_PATH_CAP 64    // max tree depth handled lane-parallel (one lane per edge)
+#ifndef AZ_PATH_CAP
+#define AZ_PATH_CAP 64    // tree levels handled lane-parallel (one lane per edge); deeper paths walk the parent links
+#endif
 #define AZ_INJ_K 16       // injected sampling uniforms per move
 
 enum { AZS_NEED_ROOT = 0, AZS_SEARCH = 1, AZS_MOVE_DONE = 2, AZS_IDLE = 3, AZS_WAIT_BUF = 4 };
@@ -162,7 +164,8 @@ typedef u64 __attribute__((may_alias)) u64a;  // word copies of typed records (n
 
 template <int W, int AP, int HW> struct Scratch {
     u64 planes[16][W];          // observation planes being assembled / history shift buffer
-    int path[AZ_PATH_CAP];      // (node << 16) | move per edge of the current descent
+    int path[AZ_PATH_CAP];      // (node << 16) | move per edge of the current descent (first AZ_PATH_CAP levels)
+    int anc[8];                 // node id at level (depth & 7): the last 8 nodes of the descent, for the history planes
     double pi[AP];              // search policy of the move being finished
     double cdf[AP];             // its running sum (np.cumsum order)
     float tmpf[AP];             // float32 policy terms (Gomoku)
@@ -318,21 +321,43 @@ template <class Wv, int N, int GAME> struct Engine {
     // Edge d (0 = root's child) receives delta * (-1)^(depth-1-d); the root receives delta*(-1)^depth.
     // One lane per edge: edges of one path are distinct (parent,move) slots, and the same slot is
     // always handled by the same lane (its depth), so program order == reference order per slot.
-    AZ_HD void path_update(const int* path, int depth, float delta, bool flip, bool count) {
-        Wv::lanes([&](int lane) {
-            if (lane < depth) {
-                const int e = path[lane];
-                const int node = e >> 16, mv = e & 0xffff;
-                const float v = (flip && ((depth - 1 - lane) & 1)) ? -delta : delta;
-                float* w = rowW(node) + mv;
-                *w = *w + v;  // float32 += (mcts_v2.py:230 / :466 / :481)
-                if (count) {
-                    float* n = rowN(node) + mv;
-                    *n = *n + 1.0f;
+    AZ_HD void path_update(const int* path, int depth, int leaf, float delta, bool flip, bool count) {
+        if (depth <= AZ_PATH_CAP) {
+            Wv::lanes([&](int lane) {
+                if (lane < depth) {
+                    const int e = path[lane];
+                    const int node = e >> 16, mv = e & 0xffff;
+                    const float v = (flip && ((depth - 1 - lane) & 1)) ? -delta : delta;
+                    float* w = rowW(node) + mv;
+                    *w = *w + v;  // float32 += (mcts_v2.py:230 / :466 / :481)
+                    if (count) {
+                        float* n = rowN(node) + mv;
+                        *n = *n + 1.0f;
+                    }
                 }
+            });
+            root_add_W((double)((flip && (depth & 1)) ? -delta : delta));
+        } else {
+            // deeper than the lane-parallel path store (rare): walk the parent links from the leaf, exactly like the
+            // reference's `while isinstance(node, Node)` loop
+            float v = delta;
+            int node = leaf;
+            for (int hops = 0; hops < c.max_nodes; ++hops) {
+                const int parent = Wv::uni((int)hdr(node).parent), mv = Wv::uni((int)hdr(node).move);
+                if (parent < 0) break;
+                if (Wv::first()) {
+                    float* w = rowW(parent) + mv;
+                    *w = *w + v;
+                    if (count) {
+                        float* n = rowN(parent) + mv;
+                        *n = *n + 1.0f;
+                    }
+                }
+                if (flip) v = -v;
+                node = parent;
             }
-        });
-        root_add_W((double)((flip && (depth & 1)) ? -delta : delta));
+            root_add_W((double)v);
+        }
         if (count && Wv::first()) gr.root_N += 1;
         if (count) cnt[AZC_BACKUP_EDGES] += (u64)depth + 1;
         Wv::sync();
@@ -405,16 +430,12 @@ template <class Wv, int N, int GAME> struct Engine {
         stage_node(node, Wv::uni(gr.root_noisy) != 0);
         for (;;) {
             const int mv = puct_argmax(depth == 0, n_self);
-            if (depth >= AZ_PATH_CAP) {
-                fail(AZ_ERR_DEPTH);
-                node_out = node;
-                depth_out = depth;
-                leaf_state = staged_hdr().st;
-                return 1;
-            }
             int child = Wv::uni((int)sc.rC[mv]);
             n_self = Wv::uni((int)sc.rN[mv]);
-            if (Wv::first()) sc.path[depth] = (node << 16) | mv;
+            if (Wv::first()) {
+                if (depth < AZ_PATH_CAP) sc.path[depth] = (node << 16) | mv;
+                sc.anc[depth & 7] = node;
+            }
             depth++;
             if (child < 0) {  // lazy child creation (mcts_v2.py:182-183); its position is computed once, here
                 child = alloc_node();
@@ -463,7 +484,7 @@ template <class Wv, int N, int GAME> struct Engine {
                 u64 v;
                 if (depth < 0) v = gr.hist[k][col][w];  // the real position: the history ring itself
                 else if (k == 0) v = leaf_state ? sc.leafst[col][w] : hdr(leaf).st.stones[col][w];
-                else if (k <= depth) v = hdr(sc.path[depth - k] >> 16).st.stones[col][w];
+                else if (k <= depth) v = hdr(sc.anc[(depth - k) & 7]).st.stones[col][w];
                 else v = gr.hist[k - depth][col][w];
                 sc.planes[pc][w] = v;
             }
@@ -549,19 +570,19 @@ template <class Wv, int N, int GAME> struct Engine {
                 if (term) {
                     // mcts_v2.py:407-411 / :604-608: back up -reward, node stays unexpanded
                     cnt[AZC_TERMINAL_HITS]++;
-                    path_update(sc.path, depth, (float)(-(int)leaf.reward), true, true);
+                    path_update(sc.path, depth, node, (float)(-(int)leaf.reward), true, true);
                     if (!c.parallel_mode && Wv::uni(gr.root_N) < c.budget) attempts = 0;  // uct_search keeps looping (:378)
                     if (!c.parallel_mode && Wv::uni(gr.root_N) >= c.budget) break;
                     continue;
                 }
-                if (c.parallel_mode) path_update(sc.path, depth, 1.0f, false, false);  // add_virtual_loss :453-467
+                if (c.parallel_mode) path_update(sc.path, depth, node, 1.0f, false, false);  // add_virtual_loss :453-467
                 int* lp = leaf_path(nleaf);
                 Wv::lanes([&](int lane) {
-                    if (lane < depth) lp[lane] = sc.path[lane];
+                    if (lane < depth && lane < AZ_PATH_CAP) lp[lane] = sc.path[lane];
                 });
                 if (Wv::first()) {
                     gr.leaf_node[nleaf] = (int16_t)node;
-                    gr.leaf_depth[nleaf] = (uint8_t)depth;
+                    gr.leaf_depth[nleaf] = (uint8_t)(depth < 255 ? depth : 255);
                 }
                 const int me = leaf.to_play;
                 gather_planes(node, depth, me, &leaf);
@@ -614,13 +635,13 @@ template <class Wv, int N, int GAME> struct Engine {
         for (int s = 0; s < nl; ++s) {
             const int node = Wv::uni((int)gr.leaf_node[s]), depth = Wv::uni((int)gr.leaf_depth[s]);
             const int* lp = leaf_path(s);
-            if (c.parallel_mode) path_update(lp, depth, -1.0f, false, false);  // revert_virtual_loss :470-482
+            if (c.parallel_mode) path_update(lp, depth, node, -1.0f, false, false);  // revert_virtual_loss :470-482
             if (Wv::uni((int)hdr(node).expanded)) {  // picked twice in one round: evaluation wasted (:621-622)
                 cnt[AZC_DUP_LEAVES]++;
                 continue;
             }
             expand_node(node, priors + (row0 + s) * A);
-            path_update(lp, depth, values[row0 + s], true, true);
+            path_update(lp, depth, node, values[row0 + s], true, true);
         }
         if (Wv::first()) gr.n_leaves = 0;
         Wv::sync();

@@ -18,6 +18,19 @@ ROOT = os.path.dirname(HERE)
 _twin = None
 
 
+_twin_variants = {}
+
+
+def hosttwin_variant(tag, defines):
+    """A host twin compiled with extra -D flags (e.g. a tiny AZ_PATH_CAP to exercise the deep-path fallback)."""
+    if tag not in _twin_variants:
+        src = os.path.join(HERE, "hosttwin", "azsp_host.cpp")
+        so = os.path.join(HERE, "hosttwin", f"libazsp_hosttwin_{tag}.so")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-strict-aliasing"] + defines + ["-o", so, src])
+        _twin_variants[tag] = _abi.Binding(ctypes.CDLL(so), f"hosttwin_{tag}")
+    return _twin_variants[tag]
+
+
 def hosttwin_binding():
     """Builds (once) and loads the host twin -- test infrastructure, never used by the product."""
     global _twin
@@ -39,7 +52,9 @@ def gpu_binding():
 
 
 def backend(kind):
-    """kind: 'host' | 'gpu' -> (binding, torch device string)"""
+    """kind: 'host' | 'gpu' | 'host:cap2' -> (binding, torch device string)"""
+    if kind == "host:cap2":
+        return hosttwin_variant("cap2", ["-DAZ_PATH_CAP=2"]), "cpu"
     return (hosttwin_binding(), "cpu") if kind == "host" else (gpu_binding(), "cuda")
 
 

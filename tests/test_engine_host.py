@@ -32,6 +32,13 @@ def test_search_and_actor_match_reference(name):
     pc.check_mcts_golden("host", name)
 
 
+@pytest.mark.parametrize("name", ["go5_p8_s64", "go9_p8_s200", "gomoku7_p1_s40"])
+def test_deep_path_fallback_matches_reference(name):
+    """Paths deeper than AZ_PATH_CAP walk the parent links instead of the lane-parallel path store; with the cap
+    compiled down to 2 almost every backup / virtual loss takes that route and must still match the reference."""
+    pc.check_mcts_golden("host:cap2", name)
+
+
 def test_product_library_exports_every_abi_symbol():
     """libazsp.so (HIP build) must load on a CPU-only box and export all of include/azsp.h; no compute calls here."""
     from alpha_zero_amd import _abi, _lib
