@@ -188,7 +188,7 @@ def main():
         bk_bytes = (expanded * (12 * A + 4 * A + 4) + cnt["backup_edges"] * 16 + cnt["leaves"] * 8 * 4.5) / steps
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "round_kernel_pmc.json")
+        prof = os.path.join(ROOT, "profiles", "select_kernel_pmc.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
