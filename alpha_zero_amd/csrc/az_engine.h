@@ -162,6 +162,13 @@ struct Philox {
 #define AZ_FREE_PREFETCH 64
 typedef u64 __attribute__((may_alias)) u64a;  // word copies of typed records (no strict-aliasing assumptions)
 
+// One node record staged from HBM into LDS in one burst (header + N / W / P / child rows).
+template <int AP, int HW> struct StagedRec {
+    float rN[AP], rW[AP], rP[AP];
+    int16_t rC[AP];
+    u64a hdrw[HW];  // header (position, parent, move, expanded); may_alias words, read back as Hdr
+};
+
 template <int W, int AP, int HW> struct Scratch {
     u64 planes[16][W];          // observation planes being assembled / history shift buffer
     int path[AZ_PATH_CAP];      // (node << 16) | move per edge of the current descent (first AZ_PATH_CAP levels)
@@ -170,11 +177,13 @@ template <int W, int AP, int HW> struct Scratch {
     double cdf[AP];             // its running sum (np.cumsum order)
     float tmpf[AP];             // float32 policy terms (Gomoku)
     int16_t parent[AZ_LDS_NODES];
-    // the node record being examined by the current descent, staged from HBM in one burst
-    float rN[AP], rW[AP], rP[AP];
+    StagedRec<AP, HW> root;     // the root's record: staged ONCE per round, kept current in LDS while the P descents update it
+    StagedRec<AP, HW> cur;      // the record of the node the current descent is looking at (levels >= 1)
     double rP64[AP];            // float64 root priors (noisy root only)
-    int16_t rC[AP];
-    u64a hdrw[HW];              // its header (position, parent, move, expanded); may_alias words, read back as Hdr
+    float wpath[AZ_PATH_CAP];   // W and N of the chosen child at every level of the current descent, captured at selection
+    float npath[AZ_PATH_CAP];   //   time: virtual loss / terminal backup then need no read-modify-write round trip
+    u64 ancst[8][2][W];         // stones of the last 8 nodes of the descent (history planes without re-reading headers)
+    u64 hist[8][2][W];          // the real game's board history, staged once per round
     u64 leafst[2][W];           // the leaf's stones while its observation planes are assembled
     int16_t freetop[AZ_FREE_PREFETCH];
     int free_base;              // freetop[i] == free_stack[free_base + i]
@@ -366,7 +375,8 @@ template <class Wv, int N, int GAME> struct Engine {
     // ---- PUCT selection (mcts_v2.py:99-109, :142-185) -----------------------------------------
     // Stage one whole node record (header + N/W/P/child rows, + the float64 root priors) into LDS: all loads of the
     // burst are in flight together, so a tree level costs ONE HBM/L2 round trip instead of one per dependent field.
-    AZ_HD void stage_node(int node, bool with_root_p) {
+    typedef StagedRec<AP, HW> SR;
+    AZ_HD void stage_node(int node, SR& dst, bool with_root_p) {
         const float* rn = rowN(node);
         const float* rw = rowW(node);
         const float* rp = rowP(node);
@@ -374,21 +384,21 @@ template <class Wv, int N, int GAME> struct Engine {
         const u64a* hw = (const u64a*)rec(node);
         const double* rp64 = rootP();
         Wv::lanes([&](int lane) {
-            if (lane < HW) sc.hdrw[lane] = hw[lane];
+            if (lane < HW) dst.hdrw[lane] = hw[lane];
             for (int a = lane; a < AP; a += AZ_WAVE) {
-                sc.rN[a] = rn[a];
-                sc.rW[a] = rw[a];
-                sc.rP[a] = rp[a];
-                sc.rC[a] = rc[a];
+                dst.rN[a] = rn[a];
+                dst.rW[a] = rw[a];
+                dst.rP[a] = rp[a];
+                dst.rC[a] = rc[a];
                 if (with_root_p) sc.rP64[a] = rp64[a];
             }
         });
         Wv::sync();
     }
-    AZ_HD const Hdr& staged_hdr() const { return *(const Hdr*)sc.hdrw; }
+    static AZ_HD const Hdr& hdr_of(const SR& r) { return *(const Hdr*)r.hdrw; }
 
-    AZ_HD int puct_argmax(bool at_root, int n_self) {
-        const S& s = staged_hdr().st;
+    AZ_HD int puct_argmax(const SR& r, bool at_root, int n_self) {
+        const S& s = hdr_of(r).st;
         int ti = n_self < c.tab_len ? n_self : c.tab_len - 1;
         const bool fresh = at_root && Wv::uni(gr.root_fresh);
         const double pbc64 = Wv::uni(fresh ? m.pbc_py[ti] : m.pbc_np[ti]);
@@ -404,15 +414,15 @@ template <class Wv, int N, int GAME> struct Engine {
                 const int a = lane + 64 * j;  // word index of point a is j, its bit is the lane
                 if (a >= A) continue;
                 if (!(a < NP ? (j < W && ((lg[j < W ? j : 0] >> lane) & 1ull) != 0) : pass_ok)) continue;
-                const float n = sc.rN[a], w = sc.rW[a];
+                const float n = r.rN[a], w = r.rW[a];
                 const float q = w / (n > 0.0f ? n : 1.0f);
-                const float r = sq32 / (1.0f + n);
+                const float rr = sq32 / (1.0f + n);
                 double sco;
                 if (noisy) {
-                    const double u = (pbc64 * sc.rP64[a]) * (double)r;  // float64 priors at the noisy root
+                    const double u = (pbc64 * sc.rP64[a]) * (double)rr;  // float64 priors at the noisy root
                     sco = (double)(-q) + u;
                 } else {
-                    const float u = (pbc32 * sc.rP[a]) * r;
+                    const float u = (pbc32 * r.rP[a]) * rr;
                     sco = (double)(-q + u);
                 }
                 if (bi < 0 || sco > best) {
@@ -426,21 +436,29 @@ template <class Wv, int N, int GAME> struct Engine {
     // One descent from the root.  Returns 0 = leaf reached (unexpanded, non-terminal), 1 = terminal.
     // On return `leaf_state` holds the leaf's position (used for the observation planes).
     AZ_HD int descend(int& node_out, int& depth_out, S& leaf_state) {
-        int node = Wv::uni(gr.root), depth = 0, n_self = Wv::uni(gr.root_N);
-        stage_node(node, Wv::uni(gr.root_noisy) != 0);
+        const int root = Wv::uni(gr.root);
+        int node = root, depth = 0, n_self = Wv::uni(gr.root_N);
         for (;;) {
-            const int mv = puct_argmax(depth == 0, n_self);
-            int child = Wv::uni((int)sc.rC[mv]);
-            n_self = Wv::uni((int)sc.rN[mv]);
+            const SR& r = depth == 0 ? sc.root : sc.cur;  // the root record lives in LDS for the whole round
+            const int mv = puct_argmax(r, depth == 0, n_self);
+            int child = Wv::uni((int)r.rC[mv]);
+            n_self = Wv::uni((int)r.rN[mv]);
             if (Wv::first()) {
-                if (depth < AZ_PATH_CAP) sc.path[depth] = (node << 16) | mv;
+                if (depth < AZ_PATH_CAP) {
+                    sc.path[depth] = (node << 16) | mv;
+                    sc.wpath[depth] = r.rW[mv];
+                    sc.npath[depth] = r.rN[mv];
+                }
                 sc.anc[depth & 7] = node;
+                const S& hs = hdr_of(r).st;
+                for (int q = 0; q < 2; ++q)
+                    for (int w = 0; w < W; ++w) sc.ancst[depth & 7][q][w] = hs.stones[q][w];
             }
             depth++;
             if (child < 0) {  // lazy child creation (mcts_v2.py:182-183); its position is computed once, here
                 child = alloc_node();
                 S ns;
-                R::template step<GAME>(staged_hdr().st, mv, c.rc, ns);
+                R::template step<GAME>(hdr_of(r).st, mv, c.rc, ns);
                 if (Wv::first()) {
                     Hdr& h = hdr(child);
                     h.st = ns;
@@ -448,6 +466,7 @@ template <class Wv, int N, int GAME> struct Engine {
                     h.move = (int16_t)mv;
                     h.expanded = 0;
                     rowC(node)[mv] = (int16_t)child;
+                    if (node == root) sc.root.rC[mv] = (int16_t)child;
                 }
                 leaf_state = ns;
                 node_out = child;
@@ -456,8 +475,8 @@ template <class Wv, int N, int GAME> struct Engine {
                 return (ns.flags & AZF_TERMINAL) ? 1 : 0;
             }
             node = child;
-            stage_node(node, false);
-            const Hdr& h = staged_hdr();
+            stage_node(node, sc.cur, false);
+            const Hdr& h = hdr_of(sc.cur);
             const int hflags = Wv::uni((int)h.st.flags), hexp = Wv::uni((int)h.expanded);
             if ((hflags & AZF_TERMINAL) || !hexp) {
                 leaf_state = R::uni_state(h.st);
@@ -467,6 +486,37 @@ template <class Wv, int N, int GAME> struct Engine {
                 return (hflags & AZF_TERMINAL) ? 1 : 0;
             }
         }
+    }
+
+    // Select-phase path update (virtual loss / terminal backup) from the values captured during the descent: plain stores,
+    // no read-modify-write round trip.  The captured W / N ARE the memory contents (only this wave touches its game, and
+    // nothing else ran since the capture), so the float32 results are identical to the in-memory += of the reference.
+    AZ_HD void path_apply(int depth, int leaf, float delta, bool flip, bool count) {
+        if (depth > AZ_PATH_CAP) {  // rare deep path: parent-link walk in memory, then refresh the LDS copy of the root
+            path_update(sc.path, depth, leaf, delta, flip, count);
+            stage_node(Wv::uni(gr.root), sc.root, false);
+            return;
+        }
+        const int root = Wv::uni(gr.root);
+        Wv::lanes([&](int lane) {
+            if (lane < depth) {
+                const int e = sc.path[lane];
+                const int node = e >> 16, mv = e & 0xffff;
+                const float v = (flip && ((depth - 1 - lane) & 1)) ? -delta : delta;
+                const float w = sc.wpath[lane] + v;  // float32 += (mcts_v2.py:230 / :466)
+                rowW(node)[mv] = w;
+                if (node == root) sc.root.rW[mv] = w;
+                if (count) {
+                    const float n = sc.npath[lane] + 1.0f;
+                    rowN(node)[mv] = n;
+                    if (node == root) sc.root.rN[mv] = n;
+                }
+            }
+        });
+        root_add_W((double)((flip && (depth & 1)) ? -delta : delta));
+        if (count && Wv::first()) gr.root_N += 1;
+        if (count) cnt[AZC_BACKUP_EDGES] += (u64)depth + 1;
+        Wv::sync();
     }
 
     // ---- observation planes (base.py:228-259) -------------------------------------------------
@@ -484,8 +534,8 @@ template <class Wv, int N, int GAME> struct Engine {
                 u64 v;
                 if (depth < 0) v = gr.hist[k][col][w];  // the real position: the history ring itself
                 else if (k == 0) v = leaf_state ? sc.leafst[col][w] : hdr(leaf).st.stones[col][w];
-                else if (k <= depth) v = hdr(sc.anc[(depth - k) & 7]).st.stones[col][w];
-                else v = gr.hist[k - depth][col][w];
+                else if (k <= depth) v = sc.ancst[(depth - k) & 7][col][w];
+                else v = sc.hist[k - depth][col][w];
                 sc.planes[pc][w] = v;
             }
         });
@@ -532,7 +582,7 @@ template <class Wv, int N, int GAME> struct Engine {
                 }
                 Wv::sync();
             }
-            gather_planes(gr.root, 0, gr.env.to_play);
+            gather_planes(gr.root, -1, gr.env.to_play);  // the root IS the real position: hist[0..7]
             write_features(feat, 0, gr.env.to_play);
             Wv::lanes([&](int lane) {
                 if (lane < c.P) vrow[lane] = lane == 0 ? 1 : 0;
@@ -556,7 +606,14 @@ template <class Wv, int N, int GAME> struct Engine {
                     if (i >= 0) sc.freetop[lane] = fs[i];
                 });
                 if (Wv::first()) sc.free_base = base;
+                // the root record and the real game's history: staged once, then kept current in LDS
+                const u64* gh = &gr.hist[0][0][0];
+                u64* lh = &sc.hist[0][0][0];
+                Wv::lanes([&](int lane) {
+                    for (int t = lane; t < 16 * W; t += AZ_WAVE) lh[t] = gh[t];
+                });
                 Wv::sync();
+                stage_node(Wv::uni(gr.root), sc.root, Wv::uni(gr.root_noisy) != 0);
             }
             // mcts_v2.py:572: up to P leaves in at most 2P attempts, one after another (each descent
             // sees the virtual losses of the previous ones); uct_search (:378-418) is the P == 1 case
@@ -570,12 +627,12 @@ template <class Wv, int N, int GAME> struct Engine {
                 if (term) {
                     // mcts_v2.py:407-411 / :604-608: back up -reward, node stays unexpanded
                     cnt[AZC_TERMINAL_HITS]++;
-                    path_update(sc.path, depth, node, (float)(-(int)leaf.reward), true, true);
+                    path_apply(depth, node, (float)(-(int)leaf.reward), true, true);
                     if (!c.parallel_mode && Wv::uni(gr.root_N) < c.budget) attempts = 0;  // uct_search keeps looping (:378)
                     if (!c.parallel_mode && Wv::uni(gr.root_N) >= c.budget) break;
                     continue;
                 }
-                if (c.parallel_mode) path_update(sc.path, depth, node, 1.0f, false, false);  // add_virtual_loss :453-467
+                if (c.parallel_mode) path_apply(depth, node, 1.0f, false, false);  // add_virtual_loss :453-467
                 int* lp = leaf_path(nleaf);
                 Wv::lanes([&](int lane) {
                     if (lane < depth && lane < AZ_PATH_CAP) lp[lane] = sc.path[lane];
