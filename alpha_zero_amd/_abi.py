@@ -11,6 +11,7 @@ SYMBOLS = [
     "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
     "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
     "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act", "azsp_conv3x3",
+    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes",
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
@@ -54,11 +55,13 @@ class Binding:
             "azsp_commit_move": [V, V, V], "azsp_harvest": [V, V, V, V, I, V, I, P(I), P(I), V],
             "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],
             "azsp_bias_act": [V, V, V, C.c_int64, I, I, I, V], "azsp_conv3x3": [V, V, V, V, V, C.c_int64, I, I, I, V],
+            "azsp_conv3x3_tiled": [V, V, V, V, V, C.c_int64, I, I, I, V], "azsp_tile_layout": [V, V, C.c_int64, I, I, I, V],
         }
         for k, a in sig.items():
             f = getattr(cdll, k)
             f.argtypes, f.restype = a, C.c_int
         cdll.azsp_last_error.argtypes, cdll.azsp_last_error.restype = [V], C.c_char_p
+        cdll.azsp_tiled_bytes.argtypes, cdll.azsp_tiled_bytes.restype = [C.c_int64, I, I], C.c_int64
 
     def check(self, rc, handle=None, what=""):
         if rc != 0:

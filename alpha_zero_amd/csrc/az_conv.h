@@ -223,6 +223,246 @@ k_conv3x3_c128_s9(const unsigned short* __restrict__ x, const unsigned short* __
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-stationary kernel on the TILED activation layout (the layout the residual tower keeps between its layers):
+//     [tile = 3 boards][16 cin-chunks][243 positions][8 channels] bf16          (62,208 B per tile, CT_* below)
+// Measured on MI355X (tools/probes/lds_probe.hip): with ONE wave per SIMD an MFMA only overlaps with that wave's LDS
+// reads, not with its VALU instructions (every VALU op costs ~4.5 cycles of matrix-core time), so the k-loop below
+// contains no VALU instruction at all and the epilogue is kept to ~0.5 VALU per MFMA.
+//   * 4 waves per CU (one per SIMD); wave q owns couts [32q, 32q+32) and keeps its A fragments for all 9 taps x 8 k-steps
+//     in registers for the lifetime of the persistent workgroup: 64 fragments in AGPRs (read by the MFMA directly), 8 in
+//     VGPRs.  No weight traffic, no weight staging, no per-tap barriers.
+//   * LDS image of a tile: per cin-chunk a strip of 313 16-byte cells: 11 zero cells, then per board row 9 positions + 1
+//     zero cell, + 11 zero cells per board, i.e. cell(b, y, x) = 11 + 101 b + 10 y + x.  A tap (dy, dx) is the constant cell
+//     offset 10 dy + dx (off-board neighbours ARE zero cells), so every B-fragment address is one per-lane base + an
+//     immediate.  Zero cells are written once; LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, masked to the
+//     position cells) copies the compact global tile into the double buffer while the previous tile is multiplied.
+//   * which position a (column tile, lane) computes is a table (cw_map): the two 16-lane groups a ds_read_b128 is
+//     serviced in each hold cells that are distinct mod 16 = all 64 banks once, for every tap (a tap shifts all cells of
+//     a group alike).  The board pitch 101 makes that possible: no residue class has more than 16 of the 243 cells.
+//   * a tile's 8 column tiles run as 2 units of 4 (128 positions, 288 MFMAs); bias enters as the C operand of the first
+//     MFMA; epilogue = residual add, one bf16 rounding, ReLU on the packed result, 512 contiguous bytes per store.
+#define CT_ROWS CV_NPOS                     // 243 positions per tile
+#define CT_GBLK (CT_ROWS * 16)              // 3,888 B: one cin-chunk block of a tile in global memory
+#define CT_TILE (16 * CT_GBLK)              // 62,208 B per tile
+#define CT_CELL0 11                         // first position cell of board 0
+#define CT_BPITCH 101                       // cells from one board to the next
+#define CT_CELLS (CT_CELL0 + 2 * CT_BPITCH + 100)  // 313 cells per chunk strip
+#define CT_LBLK (CT_CELLS * 16)             // 5,008 B: chunk strip in LDS
+#define CT_LBUF (16 * CT_LBLK)              // 80,128 B per buffer
+
+// (column tile, lane & 31) -> position / LDS cell.  Group k (k = 2 * column tile + {0: lanes 0-3,12-15,20-27; 1: the others})
+// takes the k-th position cell of every residue class mod 16, so a group spans ~17 consecutive cells.
+struct CwMap {
+    unsigned short cell[256], pos[256];
+};
+constexpr CwMap cw_make_map() {
+    CwMap m{};
+    const int lanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int cnt[16] = {}, fill[16] = {};
+    bool used[16][16] = {};
+    for (int i = 0; i < 256; ++i) {
+        m.cell[i] = 0;
+        m.pos[i] = 0xffff;
+    }
+    for (int p = 0; p < CV_NPOS; ++p) {
+        const int b = p / CV_P2, q = p % CV_P2, cell = CT_CELL0 + CT_BPITCH * b + 10 * (q / CV_S) + q % CV_S;
+        const int r = cell & 15, k = cnt[r]++, slot = fill[k]++;
+        const int idx = (k >> 1) * 32 + lanes[k & 1][slot];
+        m.cell[idx] = (unsigned short)cell;
+        m.pos[idx] = (unsigned short)p;
+        used[k][r] = true;
+    }
+    // unused slots (13 of 256, all in the last groups): a second copy of a real position whose residue the group lacks; it
+    // computes and stores the same value as the primary copy, so no lane of the kernel is ever masked
+    for (int k = 0; k < 16; ++k)
+        for (int r = 0; r < 16 && fill[k] < 16; ++r) {
+            if (used[k][r]) continue;
+            for (int p = 0; p < CV_NPOS; ++p) {
+                const int b = p / CV_P2, q = p % CV_P2, cell = CT_CELL0 + CT_BPITCH * b + 10 * (q / CV_S) + q % CV_S;
+                if ((cell & 15) == r) {
+                    const int idx = (k >> 1) * 32 + lanes[k & 1][fill[k]++];
+                    m.cell[idx] = (unsigned short)cell;
+                    m.pos[idx] = (unsigned short)p;
+                    break;
+                }
+            }
+        }
+    return m;
+}
+static __device__ const CwMap cw_map = cw_make_map();
+#define CW_THREADS 256
+
+__device__ __forceinline__ void cw_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
+// MFMA with the A operand (weights) in an AGPR / a VGPR; inline asm so that the 256 weight AGPRs are read in place
+// instead of being copied to VGPRs before every use.
+__device__ __forceinline__ void cw_mfma_a(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(b));
+}
+__device__ __forceinline__ void cw_mfma_v(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(b));
+}
+__device__ __forceinline__ void cw_mfma_ac(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b, const cv_f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(wa), "v"(b), "v"(c));
+}
+__device__ __forceinline__ unsigned cw_pk_bf16(float a, float b) {  // one v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    const b2 r = __builtin_convertvector((f2){a, b}, b2);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ unsigned cw_pk_max_i16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <bool RES> __global__ void __launch_bounds__(CW_THREADS, 1)
+k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
+                const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * CT_LBUF];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    for (int i = tid; i < 2 * CT_LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+
+    cv_bf16x8 wf[72];  // this wave's 32 couts x 1152 (tap, cin): the A operand of every MFMA below
+#pragma unroll
+    for (int t = 0; t < 72; ++t)
+        wf[t] = *(const cv_bf16x8*)(w + ((size_t)((t >> 3) * CV_C + wave * 32 + l31)) * CV_C + ((t & 7) * 2 + hi) * 8);
+    cv_f32x16 bv;  // bias in the accumulator layout: the C operand of a unit's first MFMAs
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[rq * 4 + e] = bias[wave * 32 + 8 * rq + 4 * hi + e];
+    const unsigned lo16 = relu ? 0u : 0x80008000u;  // ReLU on packed bf16: signed-16 max with 0 (with the most negative value: identity)
+
+    // LDS-DMA plan: a chunk strip is 5 pieces of 64 cells; wave q moves piece q of every strip and piece 4 of strips
+    // q, q+4, q+8, q+12.  Only position cells are transferred; a lane's source is its position's 16 B in the compact tile.
+    auto cell_src = [&](int cell, bool& ok) -> unsigned {
+        const int k = cell - CT_CELL0, b = k / CT_BPITCH, r = k - b * CT_BPITCH, yy = r / 10, xx = r - yy * 10;
+        ok = k >= 0 && cell < CT_CELLS && b < CV_TB && yy < CV_S && xx < CV_S;
+        return (unsigned)((b * CV_P2 + yy * CV_S + xx) * 16);
+    };
+    bool dok_a, dok_b;
+    const unsigned dsrc_a = cell_src(wave * 64 + lane, dok_a), dsrc_b = cell_src(256 + lane, dok_b);
+    auto dma_tile = [&](int tile, int buf) {
+        if (tile >= ntiles) return;
+        const unsigned char* src = x + (size_t)tile * CT_TILE;
+        const unsigned dst = lds0 + (unsigned)(buf * CT_LBUF);
+        if (dok_a) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) cw_glds16(src + c * CT_GBLK + dsrc_a, dst + (unsigned)(c * CT_LBLK + wave * 1024));
+        }
+        if (dok_b) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int c = c4 * 4 + wave;
+                cw_glds16(src + c * CT_GBLK + dsrc_b, dst + (unsigned)(c * CT_LBLK + 4 * 1024));
+            }
+        }
+    };
+
+    // this lane's 8 output positions (column tile ct, column l31) from the map: LDS byte offset of the (-1, -1) neighbour of
+    // its cell in its own chunk half (low 16 bits) and its position (high 16 bits)
+    unsigned lmap[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+        lmap[ct] = (unsigned)((cw_map.cell[ct * 32 + l31] - CT_CELL0) * 16 + hi * CT_LBLK) | ((unsigned)cw_map.pos[ct * 32 + l31] << 16);  // offset < 2^16
+
+    dma_tile((int)blockIdx.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        // This wave's DMA pieces of the tile have landed: they are older than everything but the last unit's 16 stores,
+        // which may stay in flight (vmcnt retires in order).  After the barrier every wave's pieces have landed, and every
+        // wave is done reading the other buffer.
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        CV_BARRIER();
+        dma_tile(tile + (int)gridDim.x, buf ^ 1);
+        const unsigned char* Xs = lds + buf * CT_LBUF;
+        const unsigned char* rbase = RES ? res + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK : nullptr;
+        unsigned char* ybase = y + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned char* bp[4];
+            unsigned gq[4];  // byte offset of (position, this lane's 4-cout slot) inside a chunk block
+            cv_u32x2 rr[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned mj = lmap[u * 4 + j];
+                bp[j] = Xs + (mj & 0xffffu);
+                gq[j] = (mj >> 16) * 16u + (unsigned)(hi * 8);
+                if (RES) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) rr[j][rq] = *(const cv_u32x2*)(rbase + rq * CT_GBLK + gq[j]);
+                }
+            }
+            cv_f32x16 acc[4];
+            cv_bf16x8 bb[4][4];
+            auto load_step = [&](int s) {  // B fragments of k-step s: tap s / 8 = constant cell offset, cin chunks 2 (s % 8) + hi
+                const int tap = s >> 3, ks = s & 7;
+                const int off = ((tap / 3) * 10 + (tap % 3)) * 16 + ks * (2 * CT_LBLK);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bb[s & 3][j] = *(const cv_bf16x8*)(bp[j] + off);
+            };
+            load_step(0);
+            load_step(1);
+            load_step(2);
+#pragma unroll
+            for (int t = 0; t < 72; ++t) {
+                if (t + 3 < 72) load_step(t + 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
+                    else if (t < 64) cw_mfma_a(acc[j], wf[t], bb[t & 3][j]);
+                    else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // MFMA results -> VALU reads: the asm MFMAs are opaque to the hazard recogniser, so the wait states are explicit
+            // (the accumulators are operands so that no read of them can be scheduled above the nops)
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float v0 = acc[j][rq * 4 + 0], v1 = acc[j][rq * 4 + 1], v2 = acc[j][rq * 4 + 2], v3 = acc[j][rq * 4 + 3];
+                    if (RES) {
+                        const cv_u32x2 r2 = rr[j][rq];
+                        v0 += cv_bf16_lo(r2.x);
+                        v1 += cv_bf16_hi(r2.x);
+                        v2 += cv_bf16_lo(r2.y);
+                        v3 += cv_bf16_hi(r2.y);
+                    }
+                    *(cv_u32x2*)(ybase + rq * CT_GBLK + gq[j]) =
+                        (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(v0, v1), lo16), cw_pk_max_i16(cw_pk_bf16(v2, v3), lo16)};
+                }
+            }
+        }
+    }
+}
+
+// NHWC rows <-> tiled layout (tower entry / exit): one 16-B chunk per thread.
+__global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long nchunks, int to_tiled) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // index over (row, chunk) of the NHWC tensor
+    if (i >= nchunks) return;
+    const long long row = i >> 4;
+    const int c = (int)(i & 15);
+    const long long tile = row / CT_ROWS;
+    const int p = (int)(row - tile * CT_ROWS);
+    const size_t t_off = (size_t)tile * CT_TILE + (size_t)c * CT_GBLK + (size_t)p * 16, n_off = (size_t)i * 16;
+    if (to_tiled) *(cv_u32x4*)(dst + t_off) = *(const cv_u32x4*)(src + n_off);
+    else *(cv_u32x4*)(dst + n_off) = *(const cv_u32x4*)(src + t_off);
+}
 #endif  // __HIPCC__
 
 // Plain reference loop (host twin build only: lets the CPU tier exercise the ABI entry on tiny inputs).

@@ -90,4 +90,36 @@ int launch_conv3x3(const void* x, const void* w, const float* bias, const void* 
                        (const unsigned short*)res, (unsigned short*)y, (int)boards, relu);
     return AZ_HIP(hipGetLastError());
 }
+static int cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
+                         int relu, void* st) {
+    if (S != CV_S || C != CV_C) return 1;
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const long long ntiles = (boards + CV_TB - 1) / CV_TB;
+    const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);  // one persistent workgroup per CU
+    if (res)
+        hipLaunchKernelGGL(k_conv3x3_tiled<true>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                           (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
+    else
+        hipLaunchKernelGGL(k_conv3x3_tiled<false>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                           (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* st) {
+    if (S != CV_S || C != CV_C) return 1;
+    const long long nchunks = boards * CV_P2 * 16;
+    hipLaunchKernelGGL(k_tile_layout, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)src,
+                       (unsigned char*)dst, nchunks, to_tiled);
+    return AZ_HIP(hipGetLastError());
+}
 }  // namespace azb

@@ -458,6 +458,9 @@ int launch_bias_act(const BiasActArgs& a, void* stream);
 // returns 0 ok, 1 unsupported shape, -1 launch error
 int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                    void* stream);
+int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
+                         int relu, void* stream);
+int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
 }  // namespace azb
 
 template <class T> static T* az_new(AzHandle* h, size_t count) {
@@ -823,6 +826,26 @@ int azsp_conv3x3(const void* x, const void* w, const float* bias, const void* re
     if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int64_t azsp_tiled_bytes(int64_t boards, int32_t S, int32_t C) {
+    if (boards < 0 || S <= 0 || C <= 0 || C % 8) return -1;
+    return (boards + CV_TB - 1) / CV_TB * (int64_t)CV_TB * S * S * C * 2;
+}
+
+int azsp_tile_layout(const void* src, void* dst, int64_t boards, int32_t S, int32_t C, int32_t to_tiled, void* stream) {
+    if (!src || !dst || boards < 0 || boards > 0x7fffffff || S <= 0 || C <= 0 || C % 8) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_tile_layout(src, dst, (long long)boards, S, C, to_tiled, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
+                       int32_t relu, void* stream) {
+    if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -26,7 +26,8 @@
  *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
  *                                     (utils/transformation.py:34-110)
  *   azsp_bias_act                     BatchNorm + residual add + ReLU after each convolution (core/network.py:42-82)
- *   azsp_conv3x3                      a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
+ *   azsp_conv3x3 / azsp_conv3x3_tiled a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
+ *   azsp_tile_layout / azsp_tiled_bytes the tower's resident activation layout
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
  * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
@@ -197,6 +198,20 @@ int azsp_bias_act(void* y_dev, const void* bias_dev, const void* residual_dev, i
  * (returns AZSP_EINVAL otherwise so the caller can use its library convolution + azsp_bias_act). */
 int azsp_conv3x3(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                  int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+
+/* The residual tower's resident activation layout ("tiled"): [tile = 3 boards][C/8 channel chunks][3*S*S positions][8 ch]
+ * bf16, azsp_tiled_bytes(boards, S, C) bytes.  A tile is what one workgroup of azsp_conv3x3_tiled multiplies at a time:
+ * its LDS image equals its global image (flat LDS-DMA copy), fragment reads are conflict-free with immediate k offsets,
+ * and the epilogue stores 512 contiguous bytes per instruction.  azsp_tile_layout converts channels-last rows
+ * [boards][S][S][C] to (to_tiled = 1) / from (0) that layout at tower entry / exit.  Positions of boards past `boards`
+ * in the last tile are never read into a valid output. */
+int64_t azsp_tiled_bytes(int64_t boards, int32_t board_size, int32_t channels);
+int azsp_tile_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t to_tiled,
+                     void* stream);
+/* azsp_conv3x3 on the tiled layout (x, residual, y all tiled; same w_packed / bias): weight-stationary MFMA kernel, the
+ * filter bank stays in registers of a persistent workgroup.  S = 9, C = 128 on the device (AZSP_EINVAL otherwise). */
+int azsp_conv3x3_tiled(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
+                       int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // policy: every "kernel" is a loop over games, every wave section a loop over 64 lanes.  It lets the
 // CPU-only test tier exercise tree search, rules and the C ABI logic without a GPU.  The product
 // package never loads this library (alpha_zero_amd/_lib.py only accepts libazsp.so + a HIP device).
+#include <vector>
 #include <stdlib.h>
 
 #include "../../alpha_zero_amd/csrc/azsp_impl.h"
@@ -34,6 +35,33 @@ int launch_bias_act(const BiasActArgs& a, void*) {
 }
 int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void*) {
     cv_host_conv3x3((const unsigned short*)x, (const unsigned short*)w, bias, (const unsigned short*)res, (unsigned short*)y, (int)boards, S, C, relu);
+    return 0;
+}
+// tiled layout on the host: [tile][C/8][3*S*S][8] <-> channels-last rows, then the plain loop
+static void host_tile_layout(const unsigned short* src, unsigned short* dst, long long boards, int S, int C, int to_tiled) {
+    const long long rows = boards * S * S, trows = (long long)CV_TB * S * S, nch = C / 8;
+    for (long long r = 0; r < rows; ++r)
+        for (long long c = 0; c < nch; ++c) {
+            const long long tile = r / trows, p = r % trows;
+            const size_t t = ((size_t)(tile * nch + c) * trows + p) * 8, n = ((size_t)r * nch + c) * 8;
+            for (int e = 0; e < 8; ++e) {
+                if (to_tiled) dst[t + e] = src[n + e];
+                else dst[n + e] = src[t + e];
+            }
+        }
+}
+int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void*) {
+    host_tile_layout((const unsigned short*)src, (unsigned short*)dst, boards, S, C, to_tiled);
+    return 0;
+}
+int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
+                         int relu, void*) {
+    const size_t n = (size_t)boards * S * S * C;
+    std::vector<unsigned short> xn(n), rn(res ? n : 0), yn(n);
+    host_tile_layout((const unsigned short*)x, xn.data(), boards, S, C, 0);
+    if (res) host_tile_layout((const unsigned short*)res, rn.data(), boards, S, C, 0);
+    cv_host_conv3x3(xn.data(), (const unsigned short*)w, bias, res ? rn.data() : nullptr, yn.data(), (int)boards, S, C, relu);
+    host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
     return 0;
 }
 }  // namespace azb

@@ -26,6 +26,24 @@ def mine(r):
     b.dll.azsp_conv3x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, S, C, 1, st)
 
 
+def nhwc_rows(t):  # [B, C, S, S] channels-last tensor -> its [B*S*S, C] storage
+    return t.permute(0, 2, 3, 1).reshape(-1, C)
+
+
+nbytes = b.dll.azsp_tiled_bytes(B, S, C)
+xt, rt, yt = (torch.zeros(nbytes // 2, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+b.dll.azsp_tile_layout(x.data_ptr(), xt.data_ptr(), B, S, C, 1, st)
+b.dll.azsp_tile_layout(res.data_ptr(), rt.data_ptr(), B, S, C, 1, st)
+
+
+def tiled(r):
+    b.dll.azsp_conv3x3_tiled(xt.data_ptr(), wp.data_ptr(), bias.data_ptr(), rt.data_ptr() if r is not None else None, yt.data_ptr(), B, S, C, 1, st)
+
+
+def layout(r):
+    b.dll.azsp_tile_layout(x.data_ptr(), xt.data_ptr(), B, S, C, 1, st)
+
+
 def lib(r):
     t = torch.nn.functional.conv2d(x, w, None, padding=1)
     b.dll.azsp_bias_act(t.data_ptr(), bias16.data_ptr(), r.data_ptr() if r is not None else None, B * S * S, C, 2, 1, st)
@@ -33,7 +51,7 @@ def lib(r):
 
 
 flops = 2.0 * B * S * S * C * C * 9
-for name, f in (("fused_mfma", mine), ("miopen+epilogue", lib)):
+for name, f in (("tiled_ws", tiled), ("fused_mfma", mine), ("miopen+epilogue", lib), ("tile_layout", layout)):
     for r in (None, res):
         for _ in range(5):
             f(r)
@@ -50,3 +68,15 @@ ref = lib(res).float()
 mine(res)
 torch.cuda.synchronize()
 print("max |fused - library|:", (y.float() - ref).abs().max().item())
+for r in (None, res):
+    ref = lib(r).float()
+    tiled(r)
+    y2 = torch.empty_like(x)
+    b.dll.azsp_tile_layout(yt.data_ptr(), y2.data_ptr(), B, S, C, 0, st)
+    torch.cuda.synchronize()
+    d = (y2.float() - ref).abs()
+    print(f"tiled residual={r is not None}: max |tiled - library| = {d.max().item()}, mismatches > 0.13: {(d > 0.13).sum().item()}")
+x2 = torch.empty_like(x)
+b.dll.azsp_tile_layout(xt.data_ptr(), x2.data_ptr(), B, S, C, 0, st)
+torch.cuda.synchronize()
+print("layout round trip exact:", torch.equal(x2, x))
