@@ -73,6 +73,7 @@ class InferenceNet(nn.Module):
         self.dtype = dtype
         self.binding = binding if channels_last else None
         self.use_fused_conv = True
+        self.use_tiled_tower = True
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.stem_pad = net.conv_block[0].padding[0]
         with torch.no_grad():
@@ -136,14 +137,46 @@ class InferenceNet(nn.Module):
             y.add_(res)
         return F.relu_(y)
 
+    def _tower_tiled(self, x):
+        """The whole residual tower on the tiled activation layout (include/azsp.h: azsp_tile_layout /
+        azsp_conv3x3_tiled): the weight-stationary MFMA kernel, activations converted once on entry and once on exit."""
+        import ctypes
+
+        dll = self.binding.dll
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        B, C, S = x.shape[0], x.shape[1], x.shape[2]
+        n = dll.azsp_tiled_bytes(B, S, C) // 2
+        key = (n, x.device)
+        if getattr(self, "_tiled_key", None) != key:  # three rotating buffers: block input, middle, block output
+            self._tiled = [torch.zeros(n, dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+            self._tiled_key = key
+        a, m, o = self._tiled
+
+        def ck(rc, what):
+            if rc != 0:
+                raise RuntimeError(f"{what} failed with code {rc}")
+
+        ck(dll.azsp_tile_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_tile_layout")
+        for i in range(self.n_blocks):
+            ck(dll.azsp_conv3x3_tiled(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
+               "azsp_conv3x3_tiled")
+            ck(dll.azsp_conv3x3_tiled(m.data_ptr(), self.wp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
+                                      B, S, C, 1, st), "azsp_conv3x3_tiled")
+            a, o = o, a
+        ck(dll.azsp_tile_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_tile_layout")
+        return x
+
     @torch.no_grad()
     def forward(self, x, priors_out=None, values_out=None):
         """x: [B,17,N,N] any dtype -> (priors fp32 [B,A], values fp32 [B])."""
         x = x.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._epilogue(F.conv2d(x, self.w[0], None, padding=self.stem_pad), self.b[0])
-        for i in range(self.n_blocks):
-            y = self._conv(x, 2 * i)
-            x = self._conv(y, 2 * i + 1, x)
+        if self._fused_conv_ok(x) and self.use_tiled_tower:
+            x = self._tower_tiled(x)
+        else:
+            for i in range(self.n_blocks):
+                y = self._conv(x, 2 * i)
+                x = self._conv(y, 2 * i + 1, x)
         h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
         B = h.shape[0]
         pol = h[:, :2].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)  # NCHW flatten order (nn.Flatten)
