@@ -353,21 +353,23 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     };
     bool dok_a, dok_b;
     const unsigned dsrc_a = cell_src(wave * 64 + lane, dok_a), dsrc_b = cell_src(256 + lane, dok_b);
-    auto dma_tile = [&](int tile, int buf) {
-        if (tile >= ntiles) return;
-        const unsigned char* src = x + (size_t)tile * CT_TILE;
-        const unsigned dst = lds0 + (unsigned)(buf * CT_LBUF);
-        if (dok_a) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) cw_glds16(src + c * CT_GBLK + dsrc_a, dst + (unsigned)(c * CT_LBLK + wave * 1024));
-        }
-        if (dok_b) {
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const int c = c4 * 4 + wave;
-                cw_glds16(src + c * CT_GBLK + dsrc_b, dst + (unsigned)(c * CT_LBLK + 4 * 1024));
-            }
-        }
+    // One LDS-DMA piece of tile `src` into buffer `dstbuf`: piece i < 16 = this wave's 64-cell piece of chunk strip i,
+    // i >= 16 = the fifth (57-cell) piece of strip 4 (i - 16) + wave.  Lanes on zero cells are masked off inside the
+    // statement; a zero mask (no next tile) makes the whole piece a no-op.  No VALU instruction: scalar base + lane offset.
+    const unsigned long long mask_a = __builtin_amdgcn_ballot_w64(dok_a), mask_b = __builtin_amdgcn_ballot_w64(dok_b);
+    auto dma_piece = [&](const unsigned char* src, unsigned dstbuf, bool live, int i) {
+        const int c = i < 16 ? i : (i - 16) * 4 + wave;
+        const unsigned long long base = (unsigned long long)(src + (size_t)c * CT_GBLK);
+        const unsigned long long mask = live ? (i < 16 ? mask_a : mask_b) : 0ull;
+        const unsigned dst = dstbuf + (unsigned)(c * CT_LBLK + (i < 16 ? wave : 4) * 1024);
+        unsigned long long save;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+            "global_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+            : "=&s"(save), "=&s"(keep)
+            : "s"(mask), "s"(dst), "v"(i < 16 ? dsrc_a : dsrc_b), "s"(base)
+            : "memory");
     };
 
     // this lane's 8 output positions (column tile ct, column l31) from the map: LDS byte offset of the (-1, -1) neighbour of
@@ -377,57 +379,83 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     for (int ct = 0; ct < 8; ++ct)
         lmap[ct] = (unsigned)((cw_map.cell[ct * 32 + l31] - CT_CELL0) * 16 + hi * CT_LBLK) | ((unsigned)cw_map.pos[ct * 32 + l31] << 16);  // offset < 2^16
 
-    dma_tile((int)blockIdx.x, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    cv_bf16x8 bb[4][4];  // ring of B fragments: k-step s lives in slot s & 3
+    auto load_step = [&](const unsigned char* const (&bp)[4], int s) {  // tap s / 8 = constant cell offset, cin chunks 2 (s % 8) + hi
+        const int tap = s >> 3, ks = s & 7;
+        const int off = ((tap / 3) * 10 + (tap % 3)) * 16 + ks * (2 * CT_LBLK);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bb[s & 3][j] = *(const cv_bf16x8*)(bp[j] + off);
+    };
+
+    {   // first tile: all pieces at once, then the first fragments
+        const unsigned char* src = x + (size_t)blockIdx.x * CT_TILE;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) dma_piece(src, lds0, true, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CV_BARRIER();
+    }
+    {
+        const unsigned char* bp0[4] = {lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), lds + (lmap[2] & 0xffffu), lds + (lmap[3] & 0xffffu)};
+        load_step(bp0, 0);
+        load_step(bp0, 1);
+        load_step(bp0, 2);
+    }
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
-        // This wave's DMA pieces of the tile have landed: they are older than everything but the last unit's 16 stores,
-        // which may stay in flight (vmcnt retires in order).  After the barrier every wave's pieces have landed, and every
-        // wave is done reading the other buffer.
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        CV_BARRIER();
-        dma_tile(tile + (int)gridDim.x, buf ^ 1);
         const unsigned char* Xs = lds + buf * CT_LBUF;
+        const unsigned char* Xn = lds + (buf ^ 1) * CT_LBUF;
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const unsigned char* nsrc = x + (size_t)(has_next ? tile + (int)gridDim.x : tile) * CT_TILE;
+        const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * CT_LBUF);
         const unsigned char* rbase = RES ? res + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK : nullptr;
         unsigned char* ybase = y + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const unsigned char* bp[4];
-            unsigned gq[4];  // byte offset of (position, this lane's 4-cout slot) inside a chunk block
+            const unsigned char* bp[4];  // this unit's fragment bases
             cv_u32x2 rr[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned mj = lmap[u * 4 + j];
                 bp[j] = Xs + (mj & 0xffffu);
-                gq[j] = (mj >> 16) * 16u + (unsigned)(hi * 8);
                 if (RES) {
+                    const unsigned gq = (mj >> 16) * 16u + (unsigned)(hi * 8);
 #pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) rr[j][rq] = *(const cv_u32x2*)(rbase + rq * CT_GBLK + gq[j]);
+                    for (int rq = 0; rq < 4; ++rq) rr[j][rq] = *(const cv_u32x2*)(rbase + rq * CT_GBLK + gq);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
             cv_f32x16 acc[4];
-            cv_bf16x8 bb[4][4];
-            auto load_step = [&](int s) {  // B fragments of k-step s: tap s / 8 = constant cell offset, cin chunks 2 (s % 8) + hi
-                const int tap = s >> 3, ks = s & 7;
-                const int off = ((tap / 3) * 10 + (tap % 3)) * 16 + ks * (2 * CT_LBLK);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bb[s & 3][j] = *(const cv_bf16x8*)(bp[j] + off);
-            };
-            load_step(0);
-            load_step(1);
-            load_step(2);
-#pragma unroll
-            for (int t = 0; t < 72; ++t) {
-                if (t + 3 < 72) load_step(t + 3);
+            for (int t = 0; t < 72; ++t) {  // fragments of steps 0..2 are already in flight (issued before the previous epilogue)
+                if (t + 3 < 72) load_step(bp, t + 3);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
                     else if (t < 64) cw_mfma_a(acc[j], wf[t], bb[t & 3][j]);
                     else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
                 }
+                // the next tile's 20 DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the barrier
+                // at the end of the previous tile)
+                if (u == 0 && t % 3 == 1 && t / 3 < 20) dma_piece(nsrc, ndst, has_next, t / 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (u == 1) {
+                // Everything this wave has in flight is at least one unit old (DMA pieces, unit 0's stores, the residual): a
+                // free wait.  After the barrier all pieces of the next tile have landed and this buffer may be overwritten.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CV_BARRIER();
+            }
+            {   // the next unit's first fragments (unit 1 of this tile / unit 0 of the next tile in the other buffer) fly while
+                // the epilogue below runs
+                const unsigned char* bpn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bpn[j] = (u == 0 ? Xs : Xn) + (lmap[(1 - u) * 4 + j] & 0xffffu);
+                load_step(bpn, 0);
+                load_step(bpn, 1);
+                load_step(bpn, 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             // MFMA results -> VALU reads: the asm MFMAs are opaque to the hazard recogniser, so the wait states are explicit
             // (the accumulators are operands so that no read of them can be scheduled above the nops)
             asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
@@ -443,10 +471,12 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                         v2 += cv_bf16_lo(r2.y);
                         v3 += cv_bf16_hi(r2.y);
                     }
-                    *(cv_u32x2*)(ybase + rq * CT_GBLK + gq[j]) =
+                    const unsigned gq = (lmap[u * 4 + j] >> 16) * 16u + (unsigned)(hi * 8);  // (position, this lane's 4-cout slot) in a chunk block
+                    *(cv_u32x2*)(ybase + rq * CT_GBLK + gq) =
                         (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(v0, v1), lo16), cw_pk_max_i16(cw_pk_bf16(v2, v3), lo16)};
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

@@ -11,8 +11,9 @@ from alpha_zero_amd import _lib
 b = _lib.load()
 B, C, S = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 128, 9
 g = torch.Generator().manual_seed(0)
-x = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
-res = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+SCALE = float(os.environ.get('CONV_BENCH_SCALE', '1'))  # 0: all-zero activations (data-dependent power check)
+x = SCALE * torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+res = SCALE * torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
 w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
 bias = torch.randn(C, generator=g).cuda()
 bias16 = bias.to(torch.bfloat16)
