@@ -4,14 +4,14 @@ which only ever loads the HIP build and refuses to run without a GPU."""
 import ctypes as C
 
 GAME_GO, GAME_GOMOKU = 0, 1
-FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16 = 0, 1, 2, 3
+FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16, FEAT_BF16_TILED = 0, 1, 2, 3, 4
 ST_NEED_ROOT, ST_SEARCH, ST_MOVE_DONE, ST_IDLE, ST_WAIT_BUF = 0, 1, 2, 3, 4
 
 SYMBOLS = [
     "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
     "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
     "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act", "azsp_conv3x3",
-    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes",
+    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled",
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
@@ -56,6 +56,7 @@ class Binding:
             "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],
             "azsp_bias_act": [V, V, V, C.c_int64, I, I, I, V], "azsp_conv3x3": [V, V, V, V, V, C.c_int64, I, I, I, V],
             "azsp_conv3x3_tiled": [V, V, V, V, V, C.c_int64, I, I, I, V], "azsp_tile_layout": [V, V, C.c_int64, I, I, I, V],
+            "azsp_stem_tiled": [V, V, V, V, C.c_int64, I, I, I, V], "azsp_head_tiled": [V, V, V, V, V, C.c_int64, I, I, I, I, V],
         }
         for k, a in sig.items():
             f = getattr(cdll, k)

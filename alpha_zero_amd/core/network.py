@@ -89,8 +89,19 @@ class InferenceNet(nn.Module):
             self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
+            # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
+            sw = convs[0][0]
+            self.stem_ok = sw.shape[1] <= 32 and sw.shape[2] == 3 and sw.shape[3] == 3 and self.stem_pad == 1
+            if self.stem_ok:
+                swp = torch.zeros(9, sw.shape[0], 32)
+                swp[:, :, : sw.shape[1]] = sw.permute(2, 3, 0, 1).reshape(9, sw.shape[0], sw.shape[1])
+                self.stem_wp = nn.Parameter(swp.to(torch.bfloat16).contiguous(), requires_grad=False)
+                self.stem_b32 = nn.Parameter(convs[0][1].float().contiguous(), requires_grad=False)
             pw, pb = _fold(net.policy_head[0], net.policy_head[1])
             vw, vb = _fold(net.value_head[0], net.value_head[1])
+            self.npol, self.nval = pw.shape[0], vw.shape[0]
+            self.head_w32 = nn.Parameter(torch.cat([pw, vw], 0).reshape(pw.shape[0] + vw.shape[0], -1).float().contiguous(), requires_grad=False)
+            self.head_b32 = nn.Parameter(torch.cat([pb, vb], 0).float().contiguous(), requires_grad=False)
             # both 1x1 heads share one convolution (2 policy planes + 1 value plane)
             self.head_w = nn.Parameter(torch.cat([pw, vw], 0).to(dtype).contiguous(memory_format=self.mf), requires_grad=False)
             self.head_b = nn.Parameter(torch.cat([pb, vb], 0).to(dtype), requires_grad=False)
@@ -137,32 +148,78 @@ class InferenceNet(nn.Module):
             y.add_(res)
         return F.relu_(y)
 
-    def _tower_tiled(self, x):
-        """The whole residual tower on the tiled activation layout (include/azsp.h: azsp_tile_layout /
-        azsp_conv3x3_tiled): the weight-stationary MFMA kernel, activations converted once on entry and once on exit."""
-        import ctypes
-
-        dll = self.binding.dll
-        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        B, C, S = x.shape[0], x.shape[1], x.shape[2]
-        n = dll.azsp_tiled_bytes(B, S, C) // 2
-        key = (n, x.device)
+    def _tiled_buffers(self, B, S, C, device):
+        n = self.binding.dll.azsp_tiled_bytes(B, S, C) // 2
+        key = (n, device)
         if getattr(self, "_tiled_key", None) != key:  # three rotating buffers: block input, middle, block output
-            self._tiled = [torch.zeros(n, dtype=torch.bfloat16, device=x.device) for _ in range(3)]
+            self._tiled = [torch.zeros(n, dtype=torch.bfloat16, device=device) for _ in range(3)]
             self._tiled_key = key
-        a, m, o = self._tiled
+        return self._tiled
 
-        def ck(rc, what):
-            if rc != 0:
-                raise RuntimeError(f"{what} failed with code {rc}")
+    @staticmethod
+    def _ck(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with code {rc}")
 
-        ck(dll.azsp_tile_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_tile_layout")
+    def _blocks_tiled(self, a, m, o, B, S, C, st):
+        """All residual blocks on tiled buffers; returns the buffer holding the tower output."""
+        dll, ck = self.binding.dll, self._ck
         for i in range(self.n_blocks):
             ck(dll.azsp_conv3x3_tiled(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
                "azsp_conv3x3_tiled")
             ck(dll.azsp_conv3x3_tiled(m.data_ptr(), self.wp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
                                       B, S, C, 1, st), "azsp_conv3x3_tiled")
             a, o = o, a
+        return a
+
+    def supports_tiled_features(self, board_size, device):
+        """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled)."""
+        return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and self.filters == 128
+                and board_size == 9 and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
+
+    @torch.no_grad()
+    def forward_tiled(self, feat, rows, board_size, priors_out=None, values_out=None):
+        """feat: the engine's AZSP_FEAT_BF16_TILED feature tensor for `rows` leaf positions.  Stem, tower and the 1x1 head
+        convolutions run on the tiled layout in hand-written kernels; only the small fully connected layers are library GEMMs."""
+        import ctypes
+
+        dll, ck = self.binding.dll, self._ck
+        st = ctypes.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream)
+        B, S, C = rows, board_size, self.filters
+        a, m, o = self._tiled_buffers(B, S, C, feat.device)
+        ck(dll.azsp_stem_tiled(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_stem_tiled")
+        a = self._blocks_tiled(a, m, o, B, S, C, st)
+        if getattr(self, "_head_key", None) != (B, feat.device):
+            self._pol = torch.empty((B, self.npol * S * S), dtype=torch.bfloat16, device=feat.device)
+            self._val = torch.empty((B, self.nval * S * S), dtype=torch.bfloat16, device=feat.device)
+            self._head_key = (B, feat.device)
+        ck(dll.azsp_head_tiled(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), self._pol.data_ptr(), self._val.data_ptr(),
+                               B, S, C, self.npol, self.nval, st), "azsp_head_tiled")
+        return self._fc_heads(self._pol, self._val, priors_out, values_out)
+
+    def _fc_heads(self, pol, val, priors_out, values_out):
+        """Fully connected layers of both heads (core/network.py:136-156) on the flattened head planes."""
+        logits = F.linear(pol, self.pol_fc_w, self.pol_fc_b)
+        v = torch.tanh(F.linear(F.relu_(F.linear(val, self.val_fc1_w, self.val_fc1_b)), self.val_fc2_w, self.val_fc2_b))
+        pri = torch.softmax(logits.float(), dim=-1)
+        v = v.float().squeeze(1)
+        if priors_out is not None:
+            priors_out.copy_(pri)
+            values_out.copy_(v)
+            return priors_out, values_out
+        return pri, v
+
+    def _tower_tiled(self, x):
+        """The whole residual tower on the tiled activation layout (include/azsp.h: azsp_tile_layout /
+        azsp_conv3x3_tiled): the weight-stationary MFMA kernel, activations converted once on entry and once on exit."""
+        import ctypes
+
+        dll, ck = self.binding.dll, self._ck
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        B, C, S = x.shape[0], x.shape[1], x.shape[2]
+        a, m, o = self._tiled_buffers(B, S, C, x.device)
+        ck(dll.azsp_tile_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_tile_layout")
+        a = self._blocks_tiled(a, m, o, B, S, C, st)
         ck(dll.azsp_tile_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_tile_layout")
         return x
 
@@ -179,14 +236,6 @@ class InferenceNet(nn.Module):
                 x = self._conv(y, 2 * i + 1, x)
         h = F.relu_(F.conv2d(x, self.head_w, self.head_b))
         B = h.shape[0]
-        pol = h[:, :2].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)  # NCHW flatten order (nn.Flatten)
-        val = h[:, 2:].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)
-        logits = F.linear(pol, self.pol_fc_w, self.pol_fc_b)
-        v = torch.tanh(F.linear(F.relu_(F.linear(val, self.val_fc1_w, self.val_fc1_b)), self.val_fc2_w, self.val_fc2_b))
-        pri = torch.softmax(logits.float(), dim=-1)
-        v = v.float().squeeze(1)
-        if priors_out is not None:
-            priors_out.copy_(pri)
-            values_out.copy_(v)
-            return priors_out, values_out
-        return pri, v
+        pol = h[:, : self.npol].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)  # NCHW flatten order (nn.Flatten)
+        val = h[:, self.npol :].contiguous(memory_format=torch.contiguous_format).reshape(B, -1)
+        return self._fc_heads(pol, val, priors_out, values_out)

@@ -60,7 +60,9 @@ class SelfPlayActor:
     def __init__(self, network: AlphaZeroNet, *, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8,
                  c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
                  resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.bfloat16,
-                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False):
+                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None):
+        """tiled_features: None = use the evaluator's tiled input layout whenever the network / board shape has the hand-written
+        stem / tower / head kernels (9x9, 128 filters, bf16 on the GPU); False = always NCHW planes + library stem."""
         from .. import _lib
 
         self.binding = binding or _lib.load(require_gpu=True)
@@ -68,12 +70,14 @@ class SelfPlayActor:
         self.game, self.komi, self.resign_threshold = game, komi, resign_threshold
         self.net_dtype = net_dtype
         self.use_graph = use_graph and self.device.type == "cuda"
+        probe = InferenceNet(network, dtype=net_dtype, binding=self.binding if self.device.type == "cuda" else None)
+        self.tiled_features = probe.supports_tiled_features(board_size, self.device) if tiled_features is None else bool(tiled_features)
         self.cfg = EngineConfig(
             game=game, board_size=board_size, num_games=num_games, num_parallel=num_parallel, num_simulations=num_simulations,
             c_puct_base=c_puct_base, c_puct_init=c_puct_init, warm_up_steps=warm_up_steps, komi=komi, num_to_win=num_to_win,
             resign_threshold=resign_threshold, check_resign_after_steps=check_resign_after_steps,
             disable_resign_ratio=disable_resign_ratio, root_noise=root_noise, deterministic=deterministic,
-            feature_dtype=_FEAT_OF[net_dtype], training_steps=training_steps, seed=seed, rank=rank,
+            feature_dtype=_abi.FEAT_BF16_TILED if self.tiled_features else _FEAT_OF[net_dtype], training_steps=training_steps, seed=seed, rank=rank,
             device_index=self.device.index or 0)
         self.engine = Engine(self.binding, self.cfg, device=self.device)
         self.engine.reset_games()
@@ -90,7 +94,10 @@ class SelfPlayActor:
 
     def _forward(self):
         e = self.engine
-        self.infer(e.features, e.priors, e.values)
+        if e.features_tiled:
+            self.infer.forward_tiled(e.features, e.rows, e.N, e.priors, e.values)
+        else:
+            self.infer(e.features, e.priors, e.values)
 
     def _capture(self):
         e = self.engine

@@ -324,19 +324,24 @@ __device__ __forceinline__ unsigned cw_pk_max_i16(unsigned a, unsigned b) {
     return r;
 }
 
-template <bool RES> __global__ void __launch_bounds__(CW_THREADS, 1)
+// NCH = input-channel chunks of 8: 16 for the tower (128 -> 128), 4 for the stem (17 planes padded to 32 -> 128).
+template <bool RES, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
                 const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * CT_LBUF];
+    constexpr int KS = NCH / 2, NSTEP = 9 * KS;      // k-steps (16 cin) per tap, per unit
+    constexpr int LBUF = NCH * CT_LBLK;             // one LDS buffer: NCH chunk strips
+    constexpr int XTILE = NCH * CT_GBLK;            // input tile bytes (the output tile is always CT_TILE: 128 couts)
+    constexpr int NPIECE = NCH + NCH / 4;            // DMA pieces per wave per tile
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    for (int i = tid; i < 2 * CT_LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
 
-    cv_bf16x8 wf[72];  // this wave's 32 couts x 1152 (tap, cin): the A operand of every MFMA below
+    cv_bf16x8 wf[NSTEP];  // this wave's 32 couts x (9 taps x 8 NCH cin): the A operand of every MFMA below
 #pragma unroll
-    for (int t = 0; t < 72; ++t)
-        wf[t] = *(const cv_bf16x8*)(w + ((size_t)((t >> 3) * CV_C + wave * 32 + l31)) * CV_C + ((t & 7) * 2 + hi) * 8);
+    for (int t = 0; t < NSTEP; ++t)
+        wf[t] = *(const cv_bf16x8*)(w + ((size_t)((t / KS) * CV_C + wave * 32 + l31)) * (8 * NCH) + ((t % KS) * 2 + hi) * 8);
     cv_f32x16 bv;  // bias in the accumulator layout: the C operand of a unit's first MFMAs
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq)
@@ -353,22 +358,22 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     };
     bool dok_a, dok_b;
     const unsigned dsrc_a = cell_src(wave * 64 + lane, dok_a), dsrc_b = cell_src(256 + lane, dok_b);
-    // One LDS-DMA piece of tile `src` into buffer `dstbuf`: piece i < 16 = this wave's 64-cell piece of chunk strip i,
-    // i >= 16 = the fifth (57-cell) piece of strip 4 (i - 16) + wave.  Lanes on zero cells are masked off inside the
+    // One LDS-DMA piece of tile `src` into buffer `dstbuf`: piece i < NCH = this wave's 64-cell piece of chunk strip i,
+    // i >= NCH = the fifth (57-cell) piece of strip 4 (i - NCH) + wave.  Lanes on zero cells are masked off inside the
     // statement; a zero mask (no next tile) makes the whole piece a no-op.  No VALU instruction: scalar base + lane offset.
     const unsigned long long mask_a = __builtin_amdgcn_ballot_w64(dok_a), mask_b = __builtin_amdgcn_ballot_w64(dok_b);
     auto dma_piece = [&](const unsigned char* src, unsigned dstbuf, bool live, int i) {
-        const int c = i < 16 ? i : (i - 16) * 4 + wave;
+        const int c = i < NCH ? i : (i - NCH) * 4 + wave;
         const unsigned long long base = (unsigned long long)(src + (size_t)c * CT_GBLK);
-        const unsigned long long mask = live ? (i < 16 ? mask_a : mask_b) : 0ull;
-        const unsigned dst = dstbuf + (unsigned)(c * CT_LBLK + (i < 16 ? wave : 4) * 1024);
+        const unsigned long long mask = live ? (i < NCH ? mask_a : mask_b) : 0ull;
+        const unsigned dst = dstbuf + (unsigned)(c * CT_LBLK + (i < NCH ? wave : 4) * 1024);
         unsigned long long save;
         unsigned keep;
         asm volatile(
             "s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
             "global_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
             : "=&s"(save), "=&s"(keep)
-            : "s"(mask), "s"(dst), "v"(i < 16 ? dsrc_a : dsrc_b), "s"(base)
+            : "s"(mask), "s"(dst), "v"(i < NCH ? dsrc_a : dsrc_b), "s"(base)
             : "memory");
     };
 
@@ -380,17 +385,17 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         lmap[ct] = (unsigned)((cw_map.cell[ct * 32 + l31] - CT_CELL0) * 16 + hi * CT_LBLK) | ((unsigned)cw_map.pos[ct * 32 + l31] << 16);  // offset < 2^16
 
     cv_bf16x8 bb[4][4];  // ring of B fragments: k-step s lives in slot s & 3
-    auto load_step = [&](const unsigned char* const (&bp)[4], int s) {  // tap s / 8 = constant cell offset, cin chunks 2 (s % 8) + hi
-        const int tap = s >> 3, ks = s & 7;
+    auto load_step = [&](const unsigned char* const (&bp)[4], int s) {  // tap s / KS = constant cell offset, cin chunks 2 (s % KS) + hi
+        const int tap = s / KS, ks = s % KS;
         const int off = ((tap / 3) * 10 + (tap % 3)) * 16 + ks * (2 * CT_LBLK);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bb[s & 3][j] = *(const cv_bf16x8*)(bp[j] + off);
     };
 
     {   // first tile: all pieces at once, then the first fragments
-        const unsigned char* src = x + (size_t)blockIdx.x * CT_TILE;
+        const unsigned char* src = x + (size_t)blockIdx.x * XTILE;
 #pragma unroll
-        for (int i = 0; i < 20; ++i) dma_piece(src, lds0, true, i);
+        for (int i = 0; i < NPIECE; ++i) dma_piece(src, lds0, true, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CV_BARRIER();
     }
@@ -403,11 +408,11 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
-        const unsigned char* Xs = lds + buf * CT_LBUF;
-        const unsigned char* Xn = lds + (buf ^ 1) * CT_LBUF;
+        const unsigned char* Xs = lds + buf * LBUF;
+        const unsigned char* Xn = lds + (buf ^ 1) * LBUF;
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const unsigned char* nsrc = x + (size_t)(has_next ? tile + (int)gridDim.x : tile) * CT_TILE;
-        const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * CT_LBUF);
+        const unsigned char* nsrc = x + (size_t)(has_next ? tile + (int)gridDim.x : tile) * XTILE;
+        const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * LBUF);
         const unsigned char* rbase = RES ? res + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK : nullptr;
         unsigned char* ybase = y + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK;
 #pragma unroll
@@ -427,17 +432,17 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
             __builtin_amdgcn_sched_barrier(0);
             cv_f32x16 acc[4];
 #pragma unroll
-            for (int t = 0; t < 72; ++t) {  // fragments of steps 0..2 are already in flight (issued before the previous epilogue)
-                if (t + 3 < 72) load_step(bp, t + 3);
+            for (int t = 0; t < NSTEP; ++t) {  // fragments of steps 0..2 are already in flight (issued before the previous epilogue)
+                if (t + 3 < NSTEP) load_step(bp, t + 3);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
                     else if (t < 64) cw_mfma_a(acc[j], wf[t], bb[t & 3][j]);
                     else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
                 }
-                // the next tile's 20 DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the barrier
+                // the next tile's DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the barrier
                 // at the end of the previous tile)
-                if (u == 0 && t % 3 == 1 && t / 3 < 20) dma_piece(nsrc, ndst, has_next, t / 3);
+                if (u == 0 && t % 3 == 1 && t / 3 < NPIECE) dma_piece(nsrc, ndst, has_next, t / 3);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (u == 1) {
@@ -493,6 +498,41 @@ __global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned ch
     if (to_tiled) *(cv_u32x4*)(dst + t_off) = *(const cv_u32x4*)(src + n_off);
     else *(cv_u32x4*)(dst + n_off) = *(const cv_u32x4*)(src + t_off);
 }
+
+// 1x1 head convolution on the tiled layout (policy / value heads, core/network.py:131-156 conv + BatchNorm folded + ReLU):
+// out[b][pl][q] = relu(sum_c w[pl][c] x[b][q][c] + bias[pl]); planes [0, npol) go to pol_out [boards][npol][81], the rest to
+// val_out [boards][NPL - npol][81] (bf16; plane-major per board = nn.Flatten order).  HBM-bound: one pass over the tower output.
+template <int NPL> __global__ void __launch_bounds__(256)
+k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, unsigned short* __restrict__ pol_out,
+             unsigned short* __restrict__ val_out, long long npos, int npol) {
+    __shared__ float ws[NPL * CV_C];
+    for (int i = threadIdx.x; i < NPL * CV_C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npos) return;
+    const long long tile = i / CT_ROWS, board = i / CV_P2;
+    const int p = (int)(i - tile * CT_ROWS), q = (int)(i - board * CV_P2);
+    float acc[NPL];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) acc[pl] = bias[pl];
+    const unsigned char* src = x + (size_t)tile * CT_TILE + (size_t)p * 16;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+        const cv_u32x4 v = *(const cv_u32x4*)(src + (size_t)c * CT_GBLK);
+        const float f[8] = {cv_bf16_lo(v.x), cv_bf16_hi(v.x), cv_bf16_lo(v.y), cv_bf16_hi(v.y), cv_bf16_lo(v.z), cv_bf16_hi(v.z), cv_bf16_lo(v.w), cv_bf16_hi(v.w)};
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[pl] += f[e] * ws[pl * CV_C + c * 8 + e];
+    }
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+        const float v = fmaxf(acc[pl], 0.0f);
+        const unsigned short h = (unsigned short)(cv_pack_bf16(v, 0.0f) & 0xffffu);
+        if (pl < npol) pol_out[((size_t)board * npol + pl) * CV_P2 + q] = h;
+        else val_out[((size_t)board * (NPL - npol) + (pl - npol)) * CV_P2 + q] = h;
+    }
+}
 #endif  // __HIPCC__
 
 // Plain reference loop (host twin build only: lets the CPU tier exercise the ABI entry on tiny inputs).
@@ -506,8 +546,15 @@ static inline unsigned short cv_h_to_bf16(float f) {
     v.f = f;
     return (unsigned short)((v.u + 0x7fffu + ((v.u >> 16) & 1u)) >> 16);
 }
+static inline void cv_host_conv3x3_io(const unsigned short* x, const unsigned short* w, const float* bias, const unsigned short* res,
+                                      unsigned short* y, int nboards, int S, int Cin, int C, int relu);
 static inline void cv_host_conv3x3(const unsigned short* x, const unsigned short* w, const float* bias, const unsigned short* res,
                                    unsigned short* y, int nboards, int S, int C, int relu) {
+    cv_host_conv3x3_io(x, w, bias, res, y, nboards, S, C, C, relu);
+}
+// x: [boards][S][S][Cin], w: [9][C][Cin], y / res: [boards][S][S][C]
+static inline void cv_host_conv3x3_io(const unsigned short* x, const unsigned short* w, const float* bias, const unsigned short* res,
+                                      unsigned short* y, int nboards, int S, int Cin, int C, int relu) {
     for (int b = 0; b < nboards; ++b)
         for (int yy = 0; yy < S; ++yy)
             for (int xx = 0; xx < S; ++xx)
@@ -516,9 +563,9 @@ static inline void cv_host_conv3x3(const unsigned short* x, const unsigned short
                     for (int tap = 0; tap < 9; ++tap) {
                         const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
                         if (sy < 0 || sx < 0 || sy >= S || sx >= S) continue;
-                        const unsigned short* xi = x + ((size_t)(b * S + sy) * S + sx) * C;
-                        const unsigned short* wi = w + ((size_t)tap * C + co) * C;
-                        for (int ci = 0; ci < C; ++ci) acc += cv_h_bf16(xi[ci]) * cv_h_bf16(wi[ci]);
+                        const unsigned short* xi = x + ((size_t)(b * S + sy) * S + sx) * Cin;
+                        const unsigned short* wi = w + ((size_t)tap * C + co) * Cin;
+                        for (int ci = 0; ci < Cin; ++ci) acc += cv_h_bf16(xi[ci]) * cv_h_bf16(wi[ci]);
                     }
                     const size_t o = ((size_t)(b * S + yy) * S + xx) * C + co;
                     float v = acc + bias[co] + (res ? cv_h_bf16(res[o]) : 0.0f);

@@ -27,7 +27,7 @@
 
 enum { AZS_NEED_ROOT = 0, AZS_SEARCH = 1, AZS_MOVE_DONE = 2, AZS_IDLE = 3, AZS_WAIT_BUF = 4 };
 enum { AZ_ERR_NODES = 1, AZ_ERR_DEPTH = 2, AZ_ERR_SAMPLE = 4, AZ_ERR_STAGE = 8 };
-enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3 };
+enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FEAT_BF16_TILED = 4 };
 enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
 // statistics counters (u64 each)
 enum { AZC_SIMS = 0, AZC_NODE_VISITS, AZC_BACKUP_EDGES, AZC_LEAVES, AZC_DUP_LEAVES, AZC_TERMINAL_HITS, AZC_MOVES,
@@ -552,7 +552,39 @@ template <class Wv, int N, int GAME> struct Engine {
             }
         });
     }
+    // The evaluator's tiled input layout (include/azsp.h azsp_stem_tiled): [tile = 3 rows][4 chunks][3 NP positions][8] bf16, the
+    // 17 planes zero-padded to 32 channels.  Chunks 0..1 = the 16 stone planes, chunk 2 = colour plane + 7 zeros; chunk 3 and
+    // the padding are never written (the tensor is zero-initialised by its owner).
+    AZ_HD void emit_tiled(void* feat, int slot, int me) {
+        const size_t r = (size_t)g * c.P + slot, tile = r / 3;
+        const int sub = (int)(r - tile * 3);
+        uint16_t* base = (uint16_t*)feat + tile * (size_t)(4 * 3 * NP * 8) + (size_t)sub * NP * 8;
+        const u32 black = me == 0 ? 0x3F80u : 0u;
+        Wv::lanes([&](int lane) {
+            for (int e = lane; e < 3 * NP; e += AZ_WAVE) {
+                const int cc = e / NP, p = e - cc * NP;
+                u32 d[4] = {0u, 0u, 0u, 0u};
+                if (cc < 2) {
+                    for (int i = 0; i < 8; ++i) {
+                        const u32 bit = (u32)((sc.planes[cc * 8 + i][p >> 6] >> (p & 63)) & 1ull);
+                        d[i >> 1] |= (bit ? 0x3F80u : 0u) << ((i & 1) * 16);
+                    }
+                } else {
+                    d[0] = black;
+                }
+                u32* o = (u32*)(base + ((size_t)cc * 3 * NP + p) * 8);
+                o[0] = d[0];
+                o[1] = d[1];
+                o[2] = d[2];
+                o[3] = d[3];
+            }
+        });
+    }
     AZ_HD void write_features(void* feat, int slot, int me) {
+        if (c.feat_dtype == AZ_FEAT_BF16_TILED) {
+            emit_tiled(feat, slot, me);
+            return;
+        }
         const size_t row = ((size_t)g * c.P + slot) * (size_t)(17 * NP);
         switch (c.feat_dtype) {
             case AZ_FEAT_I8: emit_planes<int8_t>((int8_t*)feat + row, (int8_t)1, me); break;

@@ -108,11 +108,29 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
     const long long ntiles = (boards + CV_TB - 1) / CV_TB;
     const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);  // one persistent workgroup per CU
     if (res)
-        hipLaunchKernelGGL(k_conv3x3_tiled<true>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+        hipLaunchKernelGGL((k_conv3x3_tiled<true, 16>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
                            (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
     else
-        hipLaunchKernelGGL(k_conv3x3_tiled<false>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+        hipLaunchKernelGGL((k_conv3x3_tiled<false, 16>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
                            (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* st) {
+    if (S != CV_S || C != CV_C) return 1;
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const long long ntiles = (boards + CV_TB - 1) / CV_TB;
+    const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
+    hipLaunchKernelGGL((k_conv3x3_tiled<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+                       bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)ntiles, relu);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
+                      void* st) {
+    if (S != CV_S || C != CV_C || npol + nval != 3) return 1;
+    const long long npos = boards * CV_P2;
+    hipLaunchKernelGGL(k_head_tiled<3>, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x, w, bias,
+                       (unsigned short*)pol, (unsigned short*)val, npos, npol);
     return AZ_HIP(hipGetLastError());
 }
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* st) {

@@ -461,6 +461,9 @@ int launch_conv3x3(const void* x, const void* w, const float* bias, const void* 
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* stream);
+int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
+                      void* stream);
 }  // namespace azb
 
 template <class T> static T* az_new(AzHandle* h, size_t count) {
@@ -846,6 +849,21 @@ int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const vo
     if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t relu, void* stream) {
+    if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_stem_tiled(x, w, bias, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, int64_t boards, int32_t S, int32_t C, int32_t npol,
+                    int32_t nval, void* stream) {
+    if (!x || !w || !bias || !pol || !val || boards < 0 || boards > 0x7fffffff || npol < 1 || nval < 1) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_head_tiled(x, w, bias, pol, val, (long long)boards, S, C, npol, nval, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

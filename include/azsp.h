@@ -51,6 +51,7 @@ extern "C" {
 #define AZSP_FEAT_F32 1
 #define AZSP_FEAT_BF16 2
 #define AZSP_FEAT_F16 3
+#define AZSP_FEAT_BF16_TILED 4 /* bf16 in the evaluator's tiled layout, 17 planes padded to 32 channels (azsp_stem_tiled) */
 
 #define AZSP_OK 0
 #define AZSP_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -212,6 +213,18 @@ int azsp_tile_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t
  * filter bank stays in registers of a persistent workgroup.  S = 9, C = 128 on the device (AZSP_EINVAL otherwise). */
 int azsp_conv3x3_tiled(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                        int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+
+/* Stem of the evaluator (core/network.py:98-108 conv_block: conv3x3 17 -> C + BatchNorm + ReLU) on the tiled layout: the
+ * input is the feature tensor azsp_select writes with feature_dtype = AZSP_FEAT_BF16_TILED (17 planes zero-padded to 32
+ * channels: [tile][4][3*S*S][8] bf16, azsp_tiled_bytes(rows, S, 32) bytes); w_packed is [9 taps][C out][32 in] bf16 (input
+ * channels 17..31 zero), the output is the tower's tiled layout.  Same kernel as azsp_conv3x3_tiled with 4 input chunks. */
+int azsp_stem_tiled(const void* features_tiled_dev, const void* w_packed_dev, const float* bias_dev, void* y_tiled_dev, int64_t boards,
+                    int32_t board_size, int32_t channels, int32_t relu, void* stream);
+/* Both 1x1 head convolutions (core/network.py:131-156: conv1x1 + BatchNorm + ReLU of the policy and the value head) in one
+ * pass over the tiled tower output: w [policy_planes + value_planes][C] fp32 (BatchNorm folded), bias fp32;
+ * pol_out [boards][policy_planes][S*S], val_out [boards][value_planes][S*S] bf16 (plane-major = nn.Flatten order). */
+int azsp_head_tiled(const void* x_tiled_dev, const float* w_dev, const float* bias_dev, void* pol_out_dev, void* val_out_dev, int64_t boards,
+                    int32_t board_size, int32_t channels, int32_t policy_planes, int32_t value_planes, void* stream);
 
 #ifdef __cplusplus
 }

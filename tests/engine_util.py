@@ -113,7 +113,27 @@ def replay_env_batch(kind, game, n, move_lists, num_to_win=5, max_steps=0, komi=
 # ---------------------------------------------------------------------------------------------------
 # search / actor replay against an MCTS golden file
 # ---------------------------------------------------------------------------------------------------
-def run_golden_selfplay(kind, G_gold, eval_batch):
+def untile_features(flat, rows, n):
+    """AZSP_FEAT_BF16_TILED tensor ([tile][4][3 n^2][8] bf16) -> int8 planes [rows, 17, n, n]; checks the encoding on the way
+    (only 0.0 / 1.0, padding channels zero)."""
+    NP = n * n
+    t = flat.view(torch.int16).cpu().numpy().reshape(-1, 4, 3 * NP, 8)
+    x = np.ascontiguousarray(t.transpose(0, 2, 1, 3)).reshape(-1, 32)[: rows * NP].reshape(rows, NP, 32)
+    assert np.all((x == 0) | (x == 0x3F80)) and not x[:, :, 17:].any()
+    return np.ascontiguousarray((x[:, :, :17] == 0x3F80).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
+
+
+def tile_features(x):
+    """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_BF16_TILED tensor (flat bf16), the inverse of untile_features."""
+    rows, _, n, _ = x.shape
+    NP = n * n
+    ntiles = (rows + 2) // 3
+    full = torch.zeros(ntiles * 3 * NP, 32, dtype=torch.bfloat16)
+    full[: rows * NP, :17] = x.reshape(rows, 17, NP).permute(0, 2, 1).reshape(rows * NP, 17).to(torch.bfloat16)
+    return full.view(ntiles, 3 * NP, 4, 8).permute(0, 2, 1, 3).contiguous().reshape(-1)
+
+
+def run_golden_selfplay(kind, G_gold, eval_batch, feature_dtype=_abi.FEAT_I8):
     """Runs the batched actor on the games of one golden file with the recorded randomness injected.
     Returns (engine logs per game, harvest tuple)."""
     g, cfg = G_gold.g, G_gold.cfg
@@ -133,7 +153,7 @@ def run_golden_selfplay(kind, G_gold, eval_batch):
         deterministic=cfg.get("deterministic", False), reuse_tree=cfg.get("reuse", True), warm_up_steps=cfg["warm_up_steps"],
         resign_threshold=cfg.get("resign_threshold", -1.0), check_resign_after_steps=cfg.get("check_resign_after_steps", 40),
         force_resign_disabled=1 if cfg.get("resign_disabled", True) else 0, inject_random=True, inject_moves=M,
-        max_plies=cfg.get("max_moves") or 0, stop_at_game_end=True, feature_dtype=_abi.FEAT_I8, log_moves=True, log_capacity=M)
+        max_plies=cfg.get("max_moves") or 0, stop_at_game_end=True, feature_dtype=feature_dtype, log_moves=True, log_capacity=M)
     eng = Engine(binding, ec, device=dev)
     eng.set_injection(noise, unif)
     eng.reset_games()
@@ -145,7 +165,7 @@ def run_golden_selfplay(kind, G_gold, eval_batch):
         st, _ = eng.status()
         if not valid.any() and np.all(st[:, 0] == _abi.ST_IDLE):
             break
-        feats = eng.features.cpu().numpy()
+        feats = untile_features(eng.features, eng.rows, eng.N) if eng.features_tiled else eng.features.cpu().numpy()
         pri = np.zeros((eng.rows, A), dtype=np.float32)
         val = np.zeros(eng.rows, dtype=np.float32)
         rows = np.flatnonzero(valid)

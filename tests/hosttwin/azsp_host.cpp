@@ -64,4 +64,29 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
     host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
     return 0;
 }
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void*) {
+    const size_t nin = (size_t)boards * S * S * 32, nout = (size_t)boards * S * S * C;
+    std::vector<unsigned short> xn(nin), yn(nout);
+    host_tile_layout((const unsigned short*)x, xn.data(), boards, S, 32, 0);
+    cv_host_conv3x3_io(xn.data(), (const unsigned short*)w, bias, nullptr, yn.data(), (int)boards, S, 32, C, relu);
+    host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
+    return 0;
+}
+int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
+                      void*) {
+    const size_t n = (size_t)boards * S * S * C;
+    std::vector<unsigned short> xn(n);
+    host_tile_layout((const unsigned short*)x, xn.data(), boards, S, C, 0);
+    const int P2 = S * S;
+    for (long long b = 0; b < boards; ++b)
+        for (int q = 0; q < P2; ++q)
+            for (int pl = 0; pl < npol + nval; ++pl) {
+                float acc = bias[pl];
+                for (int ci = 0; ci < C; ++ci) acc += cv_h_bf16(xn[((size_t)b * P2 + q) * C + ci]) * w[pl * C + ci];
+                const unsigned short h = cv_h_to_bf16(acc > 0.0f ? acc : 0.0f);
+                if (pl < npol) ((unsigned short*)pol)[((size_t)b * npol + pl) * P2 + q] = h;
+                else ((unsigned short*)val)[((size_t)b * nval + (pl - npol)) * P2 + q] = h;
+            }
+    return 0;
+}
 }  // namespace azb

@@ -43,13 +43,14 @@ def check_gomoku_file(kind, path):
     return bad, len(off) - 1
 
 
-def check_mcts_golden(kind, name):
+def check_mcts_golden(kind, name, feature_dtype=None):
     """Batched actor with the recorded randomness injected vs the reference's outputs.
     Bit-exact: visit counts, chosen moves, root_Q, best_child_Q, evaluation counts, (Go) pi as float64,
     sample states / z / stats.  Gomoku pi (float32 in the reference, platform-dependent np.power) <= 1e-6."""
     G = golden_mcts.MctsGolden(name)
     g, cfg = G.g, G.cfg
-    logs, (states, pis, zs, games), n_evals, counters = eu.run_golden_selfplay(kind, G, eval_batch)
+    kw = {} if feature_dtype is None else {"feature_dtype": feature_dtype}
+    logs, (states, pis, zs, games), n_evals, counters = eu.run_golden_selfplay(kind, G, eval_batch, **kw)
     for gi in range(cfg["games"]):
         ix = G.moves_of_game(gi)
         for k, i in enumerate(ix):

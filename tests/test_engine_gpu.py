@@ -107,3 +107,12 @@ def test_gpu_search_errors():
 
 def test_gpu_dihedral():
     dc.check_dihedral("gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["go9_p8_s200", "gomoku13_p8_s200"])
+def test_gpu_tiled_feature_layout_matches_reference(name):
+    """AZSP_FEAT_BF16_TILED observation planes on the device: golden games replay bit-exactly through the un-tiled tensor."""
+    from alpha_zero_amd import _abi
+
+    pc.check_mcts_golden("gpu", name, feature_dtype=_abi.FEAT_BF16_TILED)

@@ -198,3 +198,75 @@ def test_gpu_tiled_tower_equals_rowmajor_tower(golden_dir):
     a.use_tiled_tower = False
     p2, v2 = a(x)
     assert (p1 - p2).abs().max().item() <= 5e-3 and (v1 - v2).abs().max().item() <= 2e-2
+
+
+def _stem_head_checks(bnd, boards, C, S, device):
+    """azsp_stem_tiled / azsp_head_tiled vs torch on the same bf16 operands."""
+    import engine_util as eu
+
+    g = torch.Generator().manual_seed(7 + boards)
+    x = (torch.rand(boards, 17, S, S, generator=g) > 0.6).float()
+    w = (torch.randn(C, 17, 3, 3, generator=g) * 0.2).to(torch.bfloat16)
+    bias = torch.randn(C, generator=g)
+    wp = torch.zeros(9, C, 32)
+    wp[:, :, :17] = w.float().permute(2, 3, 0, 1).reshape(9, C, 17)
+    wp = wp.to(torch.bfloat16).contiguous().to(device)
+    feat = eu.tile_features(x).to(device)
+    n = bnd.dll.azsp_tiled_bytes(boards, S, C) // 2
+    yt = torch.zeros(n, dtype=torch.bfloat16, device=device)
+    assert bnd.dll.azsp_stem_tiled(feat.data_ptr(), wp.data_ptr(), bias.to(device).data_ptr(), yt.data_ptr(), boards, S, C, 1, None) == 0
+    y = torch.empty(boards, C, S, S, dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    assert bnd.dll.azsp_tile_layout(yt.data_ptr(), y.data_ptr(), boards, S, C, 0, None) == 0
+    ref = torch.relu(torch.nn.functional.conv2d(x, w.float(), bias, padding=1))
+    if device != "cpu":
+        torch.cuda.synchronize()
+    assert (y.float().cpu() - ref).abs().max().item() <= 1.0 / 128 * max(1.0, ref.abs().max().item())
+    # heads on the stem output
+    hw = torch.randn(3, C, generator=g) * 0.2
+    hb = torch.randn(3, generator=g)
+    pol = torch.empty(boards, 2 * S * S, dtype=torch.bfloat16, device=device)
+    val = torch.empty(boards, S * S, dtype=torch.bfloat16, device=device)
+    assert bnd.dll.azsp_head_tiled(yt.data_ptr(), hw.to(device).data_ptr(), hb.to(device).data_ptr(), pol.data_ptr(), val.data_ptr(), boards, S, C,
+                                   2, 1, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    h = torch.relu(torch.nn.functional.conv2d(y.float().cpu(), hw.view(3, C, 1, 1), hb))
+    tol = 1.0 / 128 * max(1.0, h.abs().max().item())
+    assert (pol.float().cpu() - h[:, :2].reshape(boards, -1)).abs().max().item() <= tol
+    assert (val.float().cpu() - h[:, 2:].reshape(boards, -1)).abs().max().item() <= tol
+
+
+def test_stem_head_abi_host_twin():
+    import engine_util as eu
+
+    for boards in (1, 4):
+        _stem_head_checks(eu.hosttwin_binding(), boards, 16, 5, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 5, 770])
+def test_gpu_stem_head_tiled_match_torch(boards):
+    from alpha_zero_amd import _lib
+
+    _stem_head_checks(_lib.load(), boards, 128, 9, "cuda")
+
+
+@pytest.mark.gpu
+def test_gpu_forward_tiled_equals_forward():
+    """Whole evaluator on tiled features (stem, tower and head kernels) vs the same network fed NCHW planes."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(6)
+    net = AlphaZeroNet((17, 9, 9), 82, 3, 128, 64)
+    with torch.no_grad():  # a random-init net has logits of +-19: shrink the last layers so that softmax is well conditioned
+        net.policy_head[4].weight.mul_(0.2)
+        net.value_head[6].weight.mul_(0.3)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    assert inf.supports_tiled_features(9, "cuda")
+    x = (torch.rand(100, 17, 9, 9) > 0.6).float()
+    p1, v1 = inf.forward_tiled(eu.tile_features(x).cuda(), 100, 9)
+    p2, v2 = inf(x.cuda())
+    assert (p1 - p2).abs().max().item() <= 1e-2 and (v1 - v2).abs().max().item() <= 2e-2
+    ref_logits, ref_v = net.eval()(x)
+    assert (p1.cpu() - torch.softmax(ref_logits, -1)).abs().max().item() <= 2e-2 and (v1.cpu() - ref_v.squeeze(1)).abs().max().item() <= 3e-2
