@@ -158,6 +158,34 @@ def main():
     elapsed_max = float(tmax.item())
     total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
 
+    # ---- dominant kernel (the tower convolution): average launch duration, HIP events on the launch stream -----------
+    conv = None
+    if rank == 0 and getattr(actor.infer, "_tiled", None) is not None and actor.tiled_features:
+        import ctypes
+
+        inf, dll = actor.infer, actor.binding.dll
+        a, m, o = inf._tiled  # real activations of the last forward
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rows = eng.rows
+        reps = 5
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps * inf.n_blocks + 1)]
+        torch.cuda.synchronize(dev)
+        k = 0
+        ev[0].record()
+        for _ in range(reps):
+            for i in range(inf.n_blocks):  # the forward's own launch sequence, one event after every launch
+                dll.azsp_conv3x3_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, n, args.filters, 1, st)
+                k += 1
+                ev[k].record()
+                dll.azsp_conv3x3_tiled(m.data_ptr(), inf.wp[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows, n,
+                                       args.filters, 1, st)
+                k += 1
+                ev[k].record()
+                a, o = o, a
+        torch.cuda.synchronize(dev)
+        d = [ev[j].elapsed_time(ev[j + 1]) for j in range(k)]
+        conv = {"launches": k, "avg_ms": float(np.mean(d)), "avg_ms_plain": float(np.mean(d[0::2])), "avg_ms_residual": float(np.mean(d[1::2]))}
+
     if args.split_round and rank == 0:
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ta = tb = 0.0
@@ -196,17 +224,43 @@ def main():
                     traffic = pj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_game<OpSelect> (PUCT descents + virtual loss + observation planes)", "bound": "hbm",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4),
-                    "backup_kernels": {"avg_ms": round(bk_ms, 4), "alg_bytes_per_launch": round(bk_bytes),
-                                       "achieved_GBs": round(bk_bytes / (bk_ms * 1e-3) / 1e9, 2)}}
+        engine_roof = {"kernel": "k_game<OpSelect> (PUCT descents + virtual loss + observation planes)", "bound": "hbm",
+                       "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                       "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4),
+                       "share_of_step": round(k_ms / (elapsed_max / steps * 1e3), 4),
+                       "backup_kernels": {"avg_ms": round(bk_ms, 4), "alg_bytes_per_launch": round(bk_bytes),
+                                          "achieved_GBs": round(bk_bytes / (bk_ms * 1e-3) / 1e9, 2)}}
         flops_eval = net_flops_per_eval(n, A, args.blocks, args.filters, args.filters, game != "go")
         nn_tflops = flops_eval * args.games * args.parallel / (nn_ms * 1e-3) / 1e12
-        nn_roof = {"kernel": "policy/value ResNet forward on G*P rows (PyTorch-ROCm, MFMA)", "bound": "mfma",
-                   "achieved": round(nn_tflops, 2), "peak": MFMA_PEAK_TFLOPS[args.net_dtype], "unit": "TFLOP/s",
-                   "frac": round(nn_tflops / MFMA_PEAK_TFLOPS[args.net_dtype], 5), "avg_forward_ms": round(nn_ms, 3),
+        peak = MFMA_PEAK_TFLOPS[args.net_dtype]
+        nn_roof = {"kernel": "whole evaluator forward on G*P rows (stem + tower + heads)", "bound": "mfma",
+                   "achieved": round(nn_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                   "frac": round(nn_tflops / peak, 5), "avg_forward_ms": round(nn_ms, 3),
+                   "share_of_step": round(nn_ms / (elapsed_max / steps * 1e3), 4),
                    "batch_fill": round((cnt["leaves"] + cnt["root_evals"]) / (steps * args.games * args.parallel), 4)}
+        if conv is not None:
+            # the step's dominant kernel: 2 * blocks launches per forward.  Algorithmic work per launch = the dense 3x3
+            # convolution (padding taps counted, the usual convention): 2 * rows * N^2 * C * C * 9 flop.
+            rows = args.games * args.parallel
+            conv_flops = 2.0 * rows * n * n * args.filters * args.filters * 9
+            tf = conv_flops / (conv["avg_ms"] * 1e-3) / 1e12
+            ctraffic = None
+            cprof = os.path.join(ROOT, "profiles", "conv_kernel_pmc.json")
+            if os.path.exists(cprof):
+                try:
+                    pj = json.load(open(cprof))
+                    if pj.get("rows") == rows and pj.get("board") == n:
+                        ctraffic = pj.get("hbm_bytes_per_launch")
+                except Exception:
+                    ctraffic = None
+            roofline = {"kernel": "k_conv3x3_tiled (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)", "bound": "mfma",
+                        "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5), "traffic": ctraffic,
+                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * n * n * args.filters * 2 * 2.5),
+                        "avg_launch_ms": round(conv["avg_ms"], 4), "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4),
+                        "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4), "launches_per_step": 2 * args.blocks,
+                        "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4)}
+        else:
+            roofline = engine_roof
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline
@@ -221,16 +275,18 @@ def main():
             else f"self-play moves/sec (whole node), {n}x{n} {game} @ {args.sims} sims/move",
             "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.net_dtype, "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
                                    f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",
+                       "evaluator": "tiled layout, hand-written stem / tower / head kernels" if actor.tiled_features else "library convolutions",
                        "games_per_gpu": args.games, "stagger_plies": args.stagger, "hip_graph_forward": not args.no_graph,
                        "parallelism": f"games sharded x{world}, sample gather to rank 0"},
             "sims_per_sec": round(total_sims / elapsed_max, 1), "evals_per_sec": round(total_evals / elapsed_max, 1),
             "sims_per_move": round(total_sims / max(1.0, total_moves), 2),
             "select_nodes_per_sim": round(cnt["node_visits"] / max(1, cnt["sims"]), 3),
             "backup_nodes_per_sim": round(cnt["backup_edges"] / max(1, cnt["sims"]), 3),
-            "samples_gathered": samples_at_root, "roofline": roofline, "nn_roofline": nn_roof, "cpu_baseline": cpu,
+            "samples_gathered": samples_at_root, "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
