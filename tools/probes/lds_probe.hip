@@ -36,7 +36,7 @@ template <int PAT> __global__ void __launch_bounds__(256) k_lds(unsigned* out, i
 
 // MFMA issue probes: MODE 0 = MFMAs only (A in AGPR), 1 = + one ds_read_b128 per MFMA whose result feeds a later MFMA
 // (ring depth 3 steps like the conv kernel), 2 = like 1 with 4 accumulators (4 column tiles per step)
-template <int MODE> __global__ void __launch_bounds__(256, 1) k_mfma(float* out, int iters, long long* cyc) {
+template <int MODE> __global__ void __launch_bounds__(256, 1) k_mfma(float* out, int iters, long long* cyc, unsigned char* scratch) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[132608];
     for (int i = threadIdx.x; i < 132608 / 4; i += 256) ((unsigned*)lds)[i] = 0x3c003c00u;
     __syncthreads();
@@ -52,6 +52,10 @@ template <int MODE> __global__ void __launch_bounds__(256, 1) k_mfma(float* out,
     const unsigned char* bp3 = bp0 + 96 * 16;
     f32x16 acc[4];
     unsigned dummy[4] = {1u, 2u, 3u, 4u};
+    unsigned sdummy[4] = {1u, 2u, 3u, 4u};
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 stdata = {threadIdx.x, blockIdx.x};
+    const unsigned long long stbase = (unsigned long long)(scratch + (size_t)blockIdx.x * 65536);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -80,21 +84,36 @@ template <int MODE> __global__ void __launch_bounds__(256, 1) k_mfma(float* out,
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[2]) : "a"(wa[t]), "v"(bb[t & 3][2]));
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[3]) : "a"(wa[t]), "v"(bb[t & 3][3]));
             }
-            if (MODE >= 3) {  // independent VALU work in the MFMA shadow: (MODE - 2) * 2 ops per MFMA pair... see main()
+            if (MODE >= 3 && MODE <= 6) {  // independent VALU work in the MFMA shadow: (MODE - 2) * 2 ops per MFMA pair... see main()
 #pragma unroll
                 for (int q = 0; q < (MODE - 2) * 4; ++q) asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy[q & 3]) : "v"(lane));
+            }
+            if (MODE == 7 || MODE == 8) {  // scalar work between MFMAs: 4 / 8 dependent-free SALU ops per step (2 MFMAs)
+#pragma unroll
+                for (int q = 0; q < (MODE - 6) * 4; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sdummy[q & 3]));
+            }
+            if (MODE == 9 && (t & 3) == 1) {  // one 8-byte-per-lane global store per 4 steps (8 MFMAs)
+                asm volatile("global_store_dwordx2 %0, %1, %2" : : "v"((unsigned)(threadIdx.x * 8 + t * 2048)), "v"(stdata), "s"(stbase) : "memory");
+            }
+            if (MODE == 10 && (t & 3) == 1) {  // one LDS-DMA piece per 4 steps, bare (m0 write + instruction)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"((unsigned)(lane * 16 + t * 1024)), "s"((unsigned)(65536 + (t & 15) * 1024)), "s"(stbase) : "memory");
+            }
+            if (MODE == 11 && (t & 3) == 1) {  // the conv kernel's full DMA statement (exec + m0 save / restore)
+                unsigned long long save; unsigned keep;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %2\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                             : "=&s"(save), "=&s"(keep) : "s"(0x0fffffffffffffffull), "s"((unsigned)(65536 + (t & 15) * 1024)), "v"((unsigned)(lane * 16 + t * 1024)), "s"(stbase) : "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     const long long t1 = clock64();
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) s += acc[j][e];
-    out[blockIdx.x * 256 + threadIdx.x] = s + (float)(dummy[0] + dummy[1] + dummy[2] + dummy[3]);
+    out[blockIdx.x * 256 + threadIdx.x] = s + (float)(dummy[0] + dummy[1] + dummy[2] + dummy[3] + sdummy[0] + sdummy[1] + sdummy[2] + sdummy[3]);
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -120,13 +139,15 @@ int main() {
     hipMalloc(&out, 256 * 256 * 4);
     hipMalloc(&fout, 256 * 256 * 4);
     hipMalloc(&cyc, 8);
+    unsigned char* scratch;
+    hipMalloc(&scratch, 256 * 65536);
     const int iters = 2000;
 #define RUN_LDS(P) { float ms = timed([&] { hipLaunchKernelGGL(k_lds<P>, dim3(256), dim3(256), 0, 0, out, iters); }); \
         printf("lds pattern %d: %.3f ms, %.2f ns per ds_read_b128 per wave\n", P, ms, ms * 1e6 / (iters * 4.0)); }
     RUN_LDS(0) RUN_LDS(1) RUN_LDS(2) RUN_LDS(3) RUN_LDS(4) RUN_LDS(5) RUN_LDS(6) RUN_LDS(7)
-#define RUN_MFMA(M, NM) { float ms = timed([&] { hipLaunchKernelGGL(k_mfma<M>, dim3(256), dim3(256), 0, 0, fout, iters, cyc); }); \
+#define RUN_MFMA(M, NM) { float ms = timed([&] { hipLaunchKernelGGL(k_mfma<M>, dim3(256), dim3(256), 0, 0, fout, iters, cyc, scratch); }); \
         long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); \
         printf("mfma mode %d: %.3f ms, %.1f ns per MFMA, clock64 ticks per MFMA %.1f\n", M, ms, ms * 1e6 / (iters * 16.0 * NM), (double)c / (iters * 16.0 * NM)); }
-    RUN_MFMA(0, 2) RUN_MFMA(1, 2) RUN_MFMA(2, 4) RUN_MFMA(3, 2) RUN_MFMA(4, 2) RUN_MFMA(5, 2) RUN_MFMA(6, 2)
+    RUN_MFMA(0, 2) RUN_MFMA(1, 2) RUN_MFMA(2, 4) RUN_MFMA(3, 2) RUN_MFMA(4, 2) RUN_MFMA(5, 2) RUN_MFMA(6, 2) RUN_MFMA(7, 2) RUN_MFMA(8, 2) RUN_MFMA(9, 2) RUN_MFMA(10, 2) RUN_MFMA(11, 2)
     return 0;
 }
