@@ -25,6 +25,11 @@ __global__ void __launch_bounds__(256) k_dihedral(const DihedralArgs a, long lon
         az_dihedral_elem(a, t);
 }
 
+__global__ void __launch_bounds__(256) k_replay_gather(const ReplayGatherArgs a, long long total) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
+        az_replay_gather_elem(a, t);
+}
+
 __global__ void __launch_bounds__(256) k_bias_act(const BiasActArgs a) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.nvec; i += (long long)gridDim.x * blockDim.x)
         az_bias_act_vec(a, i);
@@ -66,6 +71,12 @@ int launch_dihedral(const DihedralArgs& a, long long total, void* st) {
     long long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_dihedral, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a, total);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* st) {
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a, total);
     return AZ_HIP(hipGetLastError());
 }
 int launch_bias_act(const BiasActArgs& a, void* st) {

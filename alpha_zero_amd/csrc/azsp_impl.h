@@ -338,6 +338,48 @@ AZ_HD void az_dihedral_elem(const DihedralArgs& a, long long t) {
     }
 }
 
+// Replay sampling (core/replay.py:72-83 sample, core/pipeline.py:634-643 tensors + apply_random_transformation): one flat
+// element kernel gathers the sampled rows of the HBM ring, applies one dihedral op to the whole batch and casts the planes.
+struct ReplayGatherArgs {
+    const int8_t* rs;   // ring states [capacity][ch][n][n]
+    const float* rp;    // ring pi [capacity][A]
+    const float* rz;    // ring z [capacity]
+    const long long* idx;
+    void* os;
+    float* op_;
+    float* oz;
+    int batch, ch, n, A, op, dtype;
+};
+AZ_HD uint16_t az_f32_to_bf16(float f);
+AZ_HD uint16_t az_f32_to_f16(float f);
+AZ_HD void az_replay_gather_elem(const ReplayGatherArgs& a, long long t) {
+    const int np = a.n * a.n;
+    const long long per = (long long)a.ch * np, ns = (long long)a.batch * per;
+    if (t < ns) {
+        const long long b = t / per;
+        const int e = (int)(t - b * per), p = e % np;
+        const int src = az_dihedral_src(a.op, a.n, p / a.n, p % a.n);
+        const int8_t v = a.rs[a.idx[b] * per + (e - p) + src];
+        switch (a.dtype) {
+            case 0: ((int8_t*)a.os)[t] = v; break;
+            case 1: ((float*)a.os)[t] = (float)v; break;
+            case 2: ((uint16_t*)a.os)[t] = az_f32_to_bf16((float)v); break;
+            default: ((uint16_t*)a.os)[t] = az_f32_to_f16((float)v); break;
+        }
+        return;
+    }
+    t -= ns;
+    if (t < (long long)a.batch * a.A) {
+        const long long b = t / a.A;
+        const int x = (int)(t - b * a.A);
+        const int src = x < np ? az_dihedral_src(a.op, a.n, x / a.n, x % a.n) : x;  // pass column untouched
+        a.op_[t] = a.rp[a.idx[b] * a.A + src];
+        return;
+    }
+    t -= (long long)a.batch * a.A;
+    if (t < a.batch) a.oz[t] = a.rz[a.idx[t]];
+}
+
 // Fused conv epilogue: 8 consecutive channels (16 B of bf16/fp16, 32 B of fp32) per work item, fp32 math, one rounding.
 struct BiasActArgs {
     void* y;
@@ -455,6 +497,7 @@ const char* backend_error();
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream);
 int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
 int launch_bias_act(const BiasActArgs& a, void* stream);
+int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* stream);
 // returns 0 ok, 1 unsupported shape, -1 launch error
 int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                    void* stream);
@@ -850,6 +893,17 @@ int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const vo
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_replay_gather(const int8_t* ring_states, const float* ring_pi, const float* ring_z, const int64_t* idx, int32_t batch, int32_t channels,
+                       int32_t n, int32_t A, int32_t op, int32_t state_dtype, void* out_states, float* out_pi, float* out_z, void* stream) {
+    if (!ring_states || !ring_pi || !ring_z || !idx || !out_states || !out_pi || !out_z || batch < 0 || channels < 1 || n < 1 ||
+        (A != n * n && A != n * n + 1) || op < 0 || op > 7 || state_dtype < AZSP_FEAT_I8 || state_dtype > AZSP_FEAT_F16)
+        return AZSP_EINVAL;
+    if (batch == 0) return AZSP_OK;
+    ReplayGatherArgs a = {ring_states, ring_pi, ring_z, (const long long*)idx, out_states, out_pi, out_z, batch, channels, n, A, op, state_dtype};
+    const long long total = (long long)batch * ((long long)channels * n * n + A + 1);
+    return azb::launch_replay_gather(a, total, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
 }
 
 int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t relu, void* stream) {

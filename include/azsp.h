@@ -23,6 +23,8 @@
  *   azsp_get_status / azsp_get_search the tuple uct_search() returns            (core/mcts_v2.py:450)
  *   azsp_commit_move                  sub-tree reuse after the caller chose the move (core/mcts_v2.py:436-446)
  *   azsp_harvest                      data_queue.put((game_seq, stats))         (core/pipeline.py:283, :349-380)
+ *   azsp_replay_gather                UniformReplay.sample + batch tensors + random transformation (core/replay.py:72-83,
+ *                                      core/pipeline.py:636-643)
  *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
  *                                     (utils/transformation.py:34-110)
  *   azsp_bias_act                     BatchNorm + residual add + ReLU after each convolution (core/network.py:42-82)
@@ -213,6 +215,15 @@ int azsp_tile_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t
  * filter bank stays in registers of a persistent workgroup.  S = 9, C = 128 on the device (AZSP_EINVAL otherwise). */
 int azsp_conv3x3_tiled(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                        int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+
+/* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch
+ * tensors and apply_random_transformation): out_states[b] = T_op(ring_states[idx[b]]) cast to state_dtype (AZSP_FEAT_I8 / F32 /
+ * BF16 / F16), out_pi[b] = T_op(ring_pi[idx[b]]), out_z[b] = ring_z[idx[b]].  The ring is what azsp_harvest fills:
+ * states int8 [capacity][channels][N][N], pi float [capacity][A], z float [capacity]; idx int64 [batch] (device); op as in
+ * azsp_dihedral, one per batch like the reference.  One pass over HBM, no host round trip. */
+int azsp_replay_gather(const int8_t* ring_states_dev, const float* ring_pi_dev, const float* ring_z_dev, const int64_t* idx_dev, int32_t batch,
+                       int32_t channels, int32_t board_size, int32_t num_actions, int32_t op, int32_t state_dtype, void* out_states_dev,
+                       float* out_pi_dev, float* out_z_dev, void* stream);
 
 /* Stem of the evaluator (core/network.py:98-108 conv_block: conv3x3 17 -> C + BatchNorm + ReLU) on the tiled layout: the
  * input is the feature tensor azsp_select writes with feature_dtype = AZSP_FEAT_BF16_TILED (17 planes zero-padded to 32

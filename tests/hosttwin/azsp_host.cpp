@@ -29,6 +29,10 @@ int launch_dihedral(const DihedralArgs& a, long long total, void*) {
     for (long long t = 0; t < total; ++t) az_dihedral_elem(a, t);
     return 0;
 }
+int launch_replay_gather(const ReplayGatherArgs& a, long long total, void*) {
+    for (long long t = 0; t < total; ++t) az_replay_gather_elem(a, t);
+    return 0;
+}
 int launch_bias_act(const BiasActArgs& a, void*) {
     for (long long i = 0; i < a.nvec; ++i) az_bias_act_vec(a, i);
     return 0;
