@@ -167,7 +167,7 @@ class SelfPlayActor:
 def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_simulations, num_parallel, c_puct_base, c_puct_init,
                             warm_up_steps, check_resign_after_steps, disable_resign_ratio, save_sgf_dir=None, save_sgf_interval=0,
                             logs_dir=None, load_ckpt=None, log_level="INFO", var_ckpt=None, var_resign_threshold=None,
-                            ckpt_event=None, stop_event=None, num_games=4096, net_dtype=torch.bfloat16, harvest_every=64):
+                            ckpt_event=None, stop_event=None, num_games=4096, net_dtype=torch.bfloat16, harvest_every=64, binding=None):
     """Same role and argument list as the reference actor entry point (pipeline.py:166-189), extended by
     `num_games`: one call drives `num_games` games on `device` and puts (game_seq, stats) tuples on
     `data_queue` exactly as `num_games` reference actors would."""
@@ -184,7 +184,13 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
                           num_parallel=num_parallel, c_puct_base=c_puct_base, c_puct_init=c_puct_init, warm_up_steps=warm_up_steps,
                           check_resign_after_steps=check_resign_after_steps, disable_resign_ratio=disable_resign_ratio,
                           resign_threshold=thr, komi=getattr(env, "komi", 7.5), num_to_win=getattr(env, "num_to_win", 5),
-                          seed=seed, rank=rank, device=device, net_dtype=net_dtype, training_steps=training_steps)
+                          seed=seed, rank=rank, device=device, net_dtype=net_dtype, training_steps=training_steps, binding=binding)
+    writer = None
+    if logs_dir:  # per-actor statistics file with the reference's columns (pipeline.py:196, :268-271; logs/go/9x9/actor0.csv)
+        from ..utils.csv_writer import CsvWriter
+        from ..utils.sgf import get_time_stamp
+
+        writer = CsvWriter(os.path.join(logs_dir, f"actor{rank}.csv"))
     last_ckpt, t_last = None, time.time()
     while stop_event is None or not stop_event.is_set():
         if ckpt_event is not None and ckpt_event.is_set():
@@ -200,7 +206,13 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
         finished = actor.harvest()
         now = time.time()
         for seq, stats in finished:
+            ts = stats.pop("training_steps")
             stats["time_per_game"] = round((now - t_last) * num_games / max(1, len(finished)), 4)
+            stats["training_steps"] = ts  # key order of the reference's stats / CSV columns (pipeline.py:268-271)
+            if writer is not None:
+                writer.write({"datetime": get_time_stamp(), **stats})
             data_queue.put((seq, stats))
         if finished:
             t_last = now
+    if writer is not None:
+        writer.close()

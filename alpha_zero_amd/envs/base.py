@@ -175,7 +175,12 @@ class BoardGameEnv:
         return ""
 
     def to_sgf(self):
-        return None
+        """Game record as SGF text (go.py:202-210 / gomoku.py:149-157): Go writes its ruleset and komi, Gomoku leaves both empty."""
+        from ..utils.sgf import get_time_stamp, make_sgf
+
+        is_go = self._game == "go"
+        return make_sgf(board_size=self.board_size, move_history=self.history, result_string=self.get_result_string(),
+                        ruleset="Chinese" if is_go else "", komi=self._komi if is_go else "", date=get_time_stamp())
 
     # -- copying: a copy is a new one-game engine loaded with this position (copy.deepcopy works, mcts_v2.py:382)
     def _hist_boards(self):

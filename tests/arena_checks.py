@@ -1,0 +1,56 @@
+"""SURVEY 8f-2/3 checks shared by the CPU (host twin) and GPU tiers: evaluator game, Elo, resign-threshold controller."""
+import json
+import os
+
+import numpy as np
+
+import dropin_checks as dc
+from synth_eval import make_eval_func
+
+
+def check_arena(kind, golden_dir):
+    from alpha_zero_amd.core.evaluate import EloRating, create_mcts_player, eval_against_prev_ckpt
+
+    g = np.load(os.path.join(golden_dir, "eval_arena.npz"))
+    for tag in ("p1", "p4"):
+        cfg = json.loads(str(g[f"{tag}_cfg"]))
+        want = json.loads(str(g[f"{tag}_stats"]))
+        env = dc.make_env(kind, "go", 5, komi=cfg["komi"])
+        black = create_mcts_player(num_simulations=cfg["sims"], num_parallel=cfg["P"], root_noise=False, deterministic=True,
+                                   eval_func=make_eval_func(26, cfg["sharp_black"]))
+        white = create_mcts_player(num_simulations=cfg["sims"], num_parallel=cfg["P"], root_noise=False, deterministic=True,
+                                   eval_func=make_eval_func(26, cfg["sharp_white"]))
+        be, we = EloRating(rating=0), EloRating(rating=0)
+        for k in range(3):
+            stats = eval_against_prev_ckpt(env, black, white, be, we, 19652, 1.25)
+            assert stats == want[k], (tag, k, stats, want[k])  # bit-exact, floats included
+            moves = [m if m is not None else -9 for m in [h.move for h in env.history]]
+            assert moves == list(g[f"{tag}_moves_{k}"])
+
+
+def check_elo_and_resign(golden_dir):
+    from alpha_zero_amd.core.evaluate import EloRating, ResignController, get_k_factor, maybe_adjust_resign_threshold
+
+    g = np.load(os.path.join(golden_dir, "eval_arena.npz"))
+    for ra, rb, score, k, exp, new in g["elo_grid"]:
+        e = EloRating(rating=ra)
+        assert get_k_factor((ra, rb)) == k and e.expected_score(rb) == exp
+        e.update_rating(rb, score)
+        assert e.rating == new
+    for cur, rate, target, want in g["resign_grid"]:
+        assert maybe_adjust_resign_threshold(cur, rate, target) == want
+    # bookkeeping walk-through of pipeline.py:519-553 with games_per_ckpt 400, disable ratio 0.1 -> adjust every 10 marked games
+    rc = ResignController(-0.9, no_resign_games=100, reset_fp_interval=1000, games_per_ckpt=400, disable_resign_ratio=0.1, target_fp_rate=0.05)
+    marked = {"is_resign_disabled": True, "is_marked_for_resign": True, "is_could_won": True}
+    plain = {"game_length": 50}
+    assert rc.on_game(marked, 50) == -0.9 and rc.resign_count == 0  # before no_resign_games: ignored
+    assert rc.on_game(marked, 100) == -0.9 and rc.resign_count == 0  # the hard reset at no_resign_games
+    n = 100
+    for i in range(9):
+        n += 1
+        assert rc.on_game(marked, n) == -0.9
+    n += 1
+    t = rc.on_game(marked, n)  # 10th marked game, all of them could have been won: fp rate 1.0
+    assert t == maybe_adjust_resign_threshold(-0.9, 1.0, 0.05) and t < -0.9
+    assert rc.on_game(plain, n + 1) == t
+    assert rc.on_game(plain, 1000) == -0.9  # periodic reset

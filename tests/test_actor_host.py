@@ -87,3 +87,32 @@ def test_sample_gather_two_ranks_gloo(tmp_path):
         for row, lrow in zip(mine[np.argsort(mine[:, 0])], loc["games"][np.argsort(loc["games"][:, 0])]):
             assert np.array_equal(out["states"][row[0]:row[0] + row[1]], loc["states"][lrow[0]:lrow[0] + lrow[1]])
             assert np.array_equal(out["z"][row[0]:row[0] + row[1]], loc["z"][lrow[0]:lrow[0] + lrow[1]])
+
+
+def test_actor_loop_writes_reference_csv(tmp_path):
+    """run_selfplay_actor_loop with logs_dir: actor{rank}.csv carries the reference's columns in its order
+    (header of the reference's logs/go/9x9/actor0.csv), and the queue receives (game_seq, stats) with the same key order."""
+    import csv
+    import queue
+    import threading
+
+    from alpha_zero_amd.core.pipeline import run_selfplay_actor_loop
+    from alpha_zero_amd.envs.go import GoEnv
+
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    env = GoEnv(board_size=5, _binding=eu.hosttwin_binding(), _device="cpu")
+    q, stop = queue.Queue(), threading.Event()
+    th = threading.Thread(target=run_selfplay_actor_loop, args=(
+        3, 0, net, "cpu", q, env, 12, 4, 19652, 1.25, 4, 10, 0.1), kwargs=dict(
+        logs_dir=str(tmp_path), stop_event=stop, num_games=8, net_dtype=torch.float32, harvest_every=20, binding=eu.hosttwin_binding()))
+    th.start()
+    first = q.get(timeout=120)
+    stop.set()
+    th.join(timeout=120)
+    assert not th.is_alive()
+    want = "datetime,game_length,game_result,num_passes,is_resign_disabled,is_marked_for_resign,is_could_won,marked_resign_player,resign_threshold,time_per_game,training_steps"
+    rows = list(csv.reader(open(os.path.join(str(tmp_path), "actor0.csv"))))
+    assert ",".join(rows[0]) == want and len(rows) >= 2 and len(rows[1]) == len(rows[0])
+    assert list(first[1].keys()) == want.split(",")[1:]
+    assert int(rows[1][1]) > 0 and rows[1][2][0] in "BWD"

@@ -116,3 +116,11 @@ def test_gpu_tiled_feature_layout_matches_reference(name):
     from alpha_zero_amd import _abi
 
     pc.check_mcts_golden("gpu", name, feature_dtype=_abi.FEAT_BF16_TILED)
+
+
+@pytest.mark.gpu
+def test_gpu_eval_against_prev_ckpt_matches_reference(golden_dir):
+    """the evaluator's game (two players, deterministic, fresh tree per move) + Elo, through the device engine."""
+    import arena_checks as ac
+
+    ac.check_arena("gpu", golden_dir)
