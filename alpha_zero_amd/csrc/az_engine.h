@@ -26,7 +26,7 @@
 #define AZ_INJ_K 16       // injected sampling uniforms per move
 
 enum { AZS_NEED_ROOT = 0, AZS_SEARCH = 1, AZS_MOVE_DONE = 2, AZS_IDLE = 3, AZS_WAIT_BUF = 4 };
-enum { AZ_ERR_NODES = 1, AZ_ERR_DEPTH = 2, AZ_ERR_SAMPLE = 4, AZ_ERR_STAGE = 8 };
+enum { AZ_ERR_NODES = 1, AZ_ERR_SAMPLE = 4, AZ_ERR_STAGE = 8 };  // bit 2 (tree depth) retired: deep paths walk parent links
 enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FEAT_BF16_TILED = 4 };
 enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
 // statistics counters (u64 each)
@@ -1227,15 +1227,5 @@ template <class Wv, int N, int GAME> struct Engine {
             if (Wv::uni(gr.root_N) < c.budget) break;
             search_done();
         }
-    }
-    AZ_HD void advance(const float* priors, const float* values) {
-        backup_phase(priors, values);
-        endmove_phase();
-    }
-    AZ_HD void round(const float* priors, const float* values, void* feat, unsigned char* valid) {
-        advance(priors, values);
-        select(feat, valid);
-        cnt[AZC_ROUNDS]++;
-        flush_counters();
     }
 };
