@@ -210,8 +210,10 @@ def main():
         vloss_edges = cnt["backup_edges"] - (cnt["sims"] - cnt["leaves"] + expanded)  # informational
         # select kernel, reference-equivalent dense layout: N, W, P rows of every visited node, the new
         # node's position, virtual loss read-modify-write of W per path edge, the leaf's 17 planes + 8-board history
+        # observation planes per leaf: 17 planes in the network dtype, or (tiled evaluator layout) 3 written 8-channel chunks
+        feat_bytes = 3 * n * n * 16 if actor.tiled_features else 17 * n * n * e_bytes
         alg_bytes = (cnt["node_visits"] * 12 * A + created * 64 + cnt["leaves"] * (cnt["backup_edges"] / max(1, cnt["sims"])) * 8
-                     + (cnt["leaves"] + cnt["root_evals"]) * (17 * n * n * e_bytes + 16 * W * 8)) / steps
+                     + (cnt["leaves"] + cnt["root_evals"]) * (feat_bytes + 16 * W * 8)) / steps
         # expand/backup kernel: prior + value in, P/N/W rows out, N and W read-modify-write per path edge (+ vloss revert)
         bk_bytes = (expanded * (12 * A + 4 * A + 4) + cnt["backup_edges"] * 16 + cnt["leaves"] * 8 * 4.5) / steps
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
