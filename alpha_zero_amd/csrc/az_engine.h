@@ -795,6 +795,41 @@ template <class Wv, int N, int GAME> struct Engine {
         Wv::sync();
     }
 
+    // Diagnostics (azsp_rng_probe): the production random streams of this slot for plies 0..plies-1 of its current game, drawn
+    // exactly as apply_noise / sample_move draw them, without touching any state.
+    AZ_HD void probe_rng(double* noise, double* unif, int plies, int tries) {
+        const u64 key = c.seed + (u64)c.rank;
+        const u32 uid = (u32)Wv::uni((int)gr.uid);
+        for (int ply = 0; ply < plies; ++ply) {
+            if (noise) {
+                double* row = noise + ((size_t)g * plies + ply) * A;
+                const double tot = Wv::sum_f64([&](int lane) -> double {
+                    double acc = 0.0;
+                    for (int a = lane; a < A; a += AZ_WAVE) {
+                        const double gs = gamma_sample(c.alpha, key, (u32)g, uid, ((u32)ply << 12) | (u32)a);
+                        row[a] = gs;
+                        acc += gs;
+                    }
+                    return acc;
+                });
+                Wv::sync();
+                Wv::lanes([&](int lane) {
+                    for (int a = lane; a < A; a += AZ_WAVE) row[a] = row[a] / (tot > 0.0 ? tot : 1.0);
+                });
+            }
+            if (unif) {
+                Wv::lanes([&](int lane) {
+                    for (int t = lane; t < tries; t += AZ_WAVE) {
+                        u32 r[4];
+                        Philox::gen(key, (u32)g, uid, ((u32)ply << 12) | 0xFFFu, 0x1000u + (u32)t, r);
+                        unif[((size_t)g * plies + ply) * tries + t] = Philox::u01(r[0], r[1]);
+                    }
+                });
+            }
+        }
+        Wv::sync();
+    }
+
     // ---- end of a search: policy, move, sample, env step, re-root ---------------------------------
     static AZ_HD float pairwise_sum_f32(const float* a, int n) {
         // numpy's float32 add.reduce order (pairwise, 8 accumulators, blocks of 128), so that the

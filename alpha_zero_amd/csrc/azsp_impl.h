@@ -99,6 +99,12 @@ struct OpStatus {
         }
     }
 };
+struct OpRngProbe {
+    double* noise;
+    double* unif;
+    int plies, tries;
+    template <class E> AZ_HD void operator()(E& e) const { e.probe_rng(noise, unif, plies, tries); }
+};
 // packed position uploaded by azsp_set_state: u64 stones[2][W], u64 hist[8][2][W], int scalars[8]
 struct OpSetState {
     int slot;
@@ -799,6 +805,26 @@ int azsp_get_status(void* e, int32_t* status, double* q, void* stream) {
     if (status && azb::d2h(status, h->d_status, sizeof(int) * 8 * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
     if (q && azb::d2h(q, h->d_q, sizeof(double) * 2 * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
     return az_check_engine_fault(h, stream);
+}
+
+int azsp_rng_probe(void* e, int32_t plies, int32_t tries, double* noise_host, double* unif_host, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || plies < 1 || plies > 1024 || tries < 0 || tries > 64 || (!noise_host && !unif_host)) return AZSP_EINVAL;
+    const size_t nn = (size_t)h->cfg.G * plies * h->A, nu = (size_t)h->cfg.G * plies * (tries > 0 ? tries : 1);
+    double* dn = noise_host ? (double*)azb::alloc(nn * sizeof(double)) : nullptr;
+    double* du = (unif_host && tries > 0) ? (double*)azb::alloc(nu * sizeof(double)) : nullptr;
+    int rc = AZSP_OK;
+    if ((noise_host && !dn) || (unif_host && tries > 0 && !du)) rc = AZSP_ENOMEM;
+    if (rc == AZSP_OK) {
+        OpRngProbe op = {dn, du, plies, tries};
+        rc = az_run(h, op, stream);
+    }
+    if (rc == AZSP_OK && dn && azb::d2h(noise_host, dn, nn * sizeof(double), stream)) rc = AZSP_EDEVICE;
+    if (rc == AZSP_OK && du && azb::d2h(unif_host, du, nu * sizeof(double), stream)) rc = AZSP_EDEVICE;
+    if (rc == AZSP_OK && azb::sync(stream)) rc = AZSP_EDEVICE;
+    if (dn) azb::release(dn);
+    if (du) azb::release(du);
+    return rc;
 }
 
 int azsp_get_search(void* e, int32_t slot, int32_t ply, double* pi, float* cn, double* q, void* stream) {

@@ -177,6 +177,13 @@ int azsp_commit_move(void* engine, const int32_t* moves_host, void* stream);
 int azsp_harvest(void* engine, int8_t* states_dev, float* pi_dev, float* z_dev, int32_t sample_capacity,
                  int32_t* games_host, int32_t max_games, int32_t* n_samples_out, int32_t* n_games_out, void* stream);
 
+/* Diagnostics: the production random streams (no injection) of every game slot for plies 0 .. plies-1 of its current game,
+ * drawn exactly as the search draws them and without changing any state: noise_host double[G][plies][A] = the Dirichlet(alpha)
+ * vectors add_dirichlet_noise uses (core/mcts_v2.py:259-260: one draw over all A actions), unif_host double[G][plies][tries] =
+ * the uniforms behind np.random.choice (core/mcts_v2.py:434; try t is consumed only if try t-1 was rejected).  Counter-based
+ * Philox4x32-10 keyed by (seed + rank, slot, game uid, ply, action / try): statistical tests in tests/ use this entry. */
+int azsp_rng_probe(void* engine, int32_t plies, int32_t tries, double* noise_host, double* unif_host, void* stream);
+
 /* counters_host uint64[16]: simulations, best_child calls, backup edges, leaves, duplicate leaves, terminal hits,
  * moves, games, root evaluations, nodes created, game-rounds, buffer stalls. */
 int azsp_counters(void* engine, uint64_t* counters_host, int32_t reset, void* stream);

@@ -124,3 +124,10 @@ def test_gpu_eval_against_prev_ckpt_matches_reference(golden_dir):
     import arena_checks as ac
 
     ac.check_arena("gpu", golden_dir)
+
+
+@pytest.mark.gpu
+def test_gpu_production_randomness_statistics():
+    import rng_checks as rc
+
+    rc.check_production_rng("gpu")

@@ -75,3 +75,9 @@ def test_product_refuses_to_run_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(_abi.AzspError, match="no CPU fallback"):
         _lib.load(require_gpu=True)
+
+
+def test_production_randomness_statistics():
+    import rng_checks as rc
+
+    rc.check_production_rng("host")
