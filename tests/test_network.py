@@ -270,3 +270,27 @@ def test_gpu_forward_tiled_equals_forward():
     assert (p1 - p2).abs().max().item() <= 1e-2 and (v1 - v2).abs().max().item() <= 2e-2
     ref_logits, ref_v = net.eval()(x)
     assert (p1.cpu() - torch.softmax(ref_logits, -1)).abs().max().item() <= 2e-2 and (v1.cpu() - ref_v.squeeze(1)).abs().max().item() <= 3e-2
+
+
+@pytest.mark.gpu
+def test_gpu_forward_tiled_full_batch_is_batch_independent():
+    """BASELINE size (G*P = 32 768 rows): a position's evaluation must not depend on what else is in the batch, which tile or
+    which workgroup it lands in.  Rows evaluated inside the full batch equal the same rows evaluated alone, bit for bit, and
+    duplicated positions get identical outputs wherever they sit."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(8)
+    net = AlphaZeroNet((17, 9, 9), 82, 10, 128, 128)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    rows = 32768
+    x = (torch.rand(rows, 17, 9, 9) > 0.6).float()
+    x[20000:20100] = x[:100]          # duplicates far away (other tiles, other workgroups, other tile phase: 20000 % 3 == 2)
+    x[rows - 50:] = x[100:150]        # ... and in the ragged last tile
+    feat = eu.tile_features(x).cuda()
+    p_all, v_all = (t.clone() for t in inf.forward_tiled(feat, rows, 9))
+    assert torch.isfinite(p_all).all() and torch.isfinite(v_all).all() and torch.allclose(p_all.sum(1), torch.ones(rows, device="cuda"), atol=1e-3)
+    assert torch.equal(p_all[20000:20100], p_all[:100]) and torch.equal(v_all[20000:20100], v_all[:100])
+    assert torch.equal(p_all[rows - 50:], p_all[100:150]) and torch.equal(v_all[rows - 50:], v_all[100:150])
+    p_sub, v_sub = inf.forward_tiled(eu.tile_features(x[:301]).cuda(), 301, 9)
+    assert torch.equal(p_sub, p_all[:301]) and torch.equal(v_sub, v_all[:301])
