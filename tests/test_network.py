@@ -172,7 +172,7 @@ def test_tiled_conv_abi_host_twin():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("boards", [1, 2, 3, 7, 770, 1000])
+@pytest.mark.parametrize("boards", [1, 2, 3, 7, 768, 770, 1000, 1539])
 def test_gpu_tiled_conv3x3_matches_torch(boards):
     """The weight-stationary MFMA kernel on the tiled layout vs an fp32 torch convolution of the same bf16 operands
     (asymmetric random weights; 1..many tiles per workgroup; partial last tiles; with and without ReLU)."""
@@ -180,7 +180,7 @@ def test_gpu_tiled_conv3x3_matches_torch(boards):
 
     bnd = _lib.load()
     _tiled_roundtrip_and_conv(bnd, boards, 128, 9, "cuda")
-    if boards == 7:
+    if boards in (7, 770):  # no ReLU (identity epilogue), also with a second tile per workgroup
         _tiled_roundtrip_and_conv(bnd, boards, 128, 9, "cuda", relu=0)
 
 
