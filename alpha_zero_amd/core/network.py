@@ -116,6 +116,13 @@ class InferenceNet(nn.Module):
         return (self.binding is not None and self.use_fused_conv and x.is_cuda and x.dtype == torch.bfloat16 and self.filters == 128
                 and x.shape[2] == 9 and x.shape[3] == 9 and x.is_contiguous(memory_format=torch.channels_last))
 
+    def _tiled_tower_ok(self, x):
+        """Shapes with a weight-stationary tower kernel (azsp_conv3x3_tiled): 9x9 planes x 128 filters (Go 9x9) and 17x17 planes x 64
+        filters (the 13x13 Gomoku network after its pad-3 stem)."""
+        return (self.binding is not None and self.use_fused_conv and self.use_tiled_tower and x.is_cuda and x.dtype == torch.bfloat16
+                and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17))
+                and x.is_contiguous(memory_format=torch.channels_last))
+
     def _conv(self, x, i, res=None):
         """relu(conv3x3(x) + bias [+ res]) of tower convolution i (0-based): one hand-written MFMA kernel when the shape is
         supported, else the library convolution followed by the fused epilogue kernel."""
@@ -228,7 +235,7 @@ class InferenceNet(nn.Module):
         """x: [B,17,N,N] any dtype -> (priors fp32 [B,A], values fp32 [B])."""
         x = x.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._epilogue(F.conv2d(x, self.w[0], None, padding=self.stem_pad), self.b[0])
-        if self._fused_conv_ok(x) and self.use_tiled_tower:
+        if self._tiled_tower_ok(x):
             x = self._tower_tiled(x)
         else:
             for i in range(self.n_blocks):

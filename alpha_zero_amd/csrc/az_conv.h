@@ -22,6 +22,8 @@
 #define CV_C 128
 #define CV_S 9
 #define CV_TB 3
+// boards per tile of the tiled activation layout: as many whole boards as fit 256 MFMA columns (3 at 9x9, 1 from 13x13 up)
+static inline int cv_tile_boards(int S) { return 256 / (S * S) > 0 ? 256 / (S * S) : 1; }
 #define CV_P2 (CV_S * CV_S)                   // 81
 #define CV_PS (CV_S + 2)                      // 11
 #define CV_PP (CV_PS * CV_PS)                 // 121
@@ -485,14 +487,15 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
 }
 
 // NHWC rows <-> tiled layout (tower entry / exit): one 16-B chunk per thread.
-__global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long nchunks, int to_tiled) {
+__global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long nchunks, int to_tiled, int nch,
+                              int tile_rows) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // index over (row, chunk) of the NHWC tensor
     if (i >= nchunks) return;
-    const long long row = i >> 4;
-    const int c = (int)(i & 15);
-    const long long tile = row / CT_ROWS;
-    const int p = (int)(row - tile * CT_ROWS);
-    const size_t t_off = (size_t)tile * CT_TILE + (size_t)c * CT_GBLK + (size_t)p * 16, n_off = (size_t)i * 16;
+    const long long row = i / nch;
+    const int c = (int)(i - row * nch);
+    const long long tile = row / tile_rows;
+    const int p = (int)(row - tile * tile_rows);
+    const size_t t_off = ((size_t)(tile * nch + c) * tile_rows + (size_t)p) * 16, n_off = (size_t)i * 16;
     if (to_tiled) *(cv_u32x4*)(dst + t_off) = *(const cv_u32x4*)(src + n_off);
     else *(cv_u32x4*)(dst + n_off) = *(const cv_u32x4*)(src + t_off);
 }

@@ -552,13 +552,14 @@ template <class Wv, int N, int GAME> struct Engine {
             }
         });
     }
-    // The evaluator's tiled input layout (include/azsp.h azsp_stem_tiled): [tile = 3 rows][4 chunks][3 NP positions][8] bf16, the
-    // 17 planes zero-padded to 32 channels.  Chunks 0..1 = the 16 stone planes, chunk 2 = colour plane + 7 zeros; chunk 3 and
+    // The evaluator's tiled input layout (include/azsp.h azsp_stem_tiled): [tile = T rows][4 chunks][T NP positions][8] bf16 with
+    // T = max(1, 256 / NP) boards per tile (3 at 9x9), the 17 planes zero-padded to 32 channels.  Chunks 0..1 = the 16 stone planes, chunk 2 = colour plane + 7 zeros; chunk 3 and
     // the padding are never written (the tensor is zero-initialised by its owner).
     AZ_HD void emit_tiled(void* feat, int slot, int me) {
-        const size_t r = (size_t)g * c.P + slot, tile = r / 3;
-        const int sub = (int)(r - tile * 3);
-        uint16_t* base = (uint16_t*)feat + tile * (size_t)(4 * 3 * NP * 8) + (size_t)sub * NP * 8;
+        constexpr int TBF = (256 / NP) > 0 ? 256 / NP : 1;
+        const size_t r = (size_t)g * c.P + slot, tile = r / TBF;
+        const int sub = (int)(r - tile * TBF);
+        uint16_t* base = (uint16_t*)feat + tile * (size_t)(4 * TBF * NP * 8) + (size_t)sub * NP * 8;
         const u32 black = me == 0 ? 0x3F80u : 0u;
         Wv::lanes([&](int lane) {
             for (int e = lane; e < 3 * NP; e += AZ_WAVE) {
@@ -572,7 +573,7 @@ template <class Wv, int N, int GAME> struct Engine {
                 } else {
                     d[0] = black;
                 }
-                u32* o = (u32*)(base + ((size_t)cc * 3 * NP + p) * 8);
+                u32* o = (u32*)(base + ((size_t)cc * TBF * NP + p) * 8);
                 o[0] = d[0];
                 o[1] = d[1];
                 o[2] = d[2];

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "azsp_impl.h"
+#include "az_conv64.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -113,6 +114,18 @@ static int cu_count() {
 }
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* st) {
+    if (S == C6_S && C == C6_C) {  // 17x17 planes, 64 filters (13x13 Gomoku network): one board per tile
+        const int n_cu = cu_count();
+        if (n_cu < 0) return -1;
+        const unsigned grid = (unsigned)(boards < n_cu ? boards : n_cu);
+        if (res)
+            hipLaunchKernelGGL(k_conv3x3_t64<true>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+                               bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+        else
+            hipLaunchKernelGGL(k_conv3x3_t64<false>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+                               bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+        return AZ_HIP(hipGetLastError());
+    }
     if (S != CV_S || C != CV_C) return 1;
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
@@ -145,10 +158,11 @@ int launch_head_tiled(const void* x, const float* w, const float* bias, void* po
     return AZ_HIP(hipGetLastError());
 }
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* st) {
-    if (S != CV_S || C != CV_C) return 1;
-    const long long nchunks = boards * CV_P2 * 16;
+    if (C % 8 || S < 1) return 1;
+    const int nch = C / 8, tile_rows = cv_tile_boards(S) * S * S;
+    const long long nchunks = boards * S * S * nch;
     hipLaunchKernelGGL(k_tile_layout, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)src,
-                       (unsigned char*)dst, nchunks, to_tiled);
+                       (unsigned char*)dst, nchunks, to_tiled, nch, tile_rows);
     return AZ_HIP(hipGetLastError());
 }
 }  // namespace azb

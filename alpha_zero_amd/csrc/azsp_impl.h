@@ -903,7 +903,8 @@ int azsp_conv3x3(const void* x, const void* w, const float* bias, const void* re
 
 int64_t azsp_tiled_bytes(int64_t boards, int32_t S, int32_t C) {
     if (boards < 0 || S <= 0 || C <= 0 || C % 8) return -1;
-    return (boards + CV_TB - 1) / CV_TB * (int64_t)CV_TB * S * S * C * 2;
+    const int tb = cv_tile_boards(S);
+    return (boards + tb - 1) / tb * (int64_t)tb * S * S * C * 2;
 }
 
 int azsp_tile_layout(const void* src, void* dst, int64_t boards, int32_t S, int32_t C, int32_t to_tiled, void* stream) {

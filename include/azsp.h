@@ -209,8 +209,8 @@ int azsp_bias_act(void* y_dev, const void* bias_dev, const void* residual_dev, i
 int azsp_conv3x3(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                  int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
 
-/* The residual tower's resident activation layout ("tiled"): [tile = 3 boards][C/8 channel chunks][3*S*S positions][8 ch]
- * bf16, azsp_tiled_bytes(boards, S, C) bytes.  A tile is what one workgroup of azsp_conv3x3_tiled multiplies at a time:
+/* The residual tower's resident activation layout ("tiled"): [tile = T boards][C/8 channel chunks][T*S*S positions][8 ch]
+ * bf16 with T = max(1, 256 / (S*S)) boards per tile (3 at 9x9, 1 from 13x13 up), azsp_tiled_bytes(boards, S, C) bytes.  A tile is what one workgroup of azsp_conv3x3_tiled multiplies at a time:
  * its LDS image equals its global image (flat LDS-DMA copy), fragment reads are conflict-free with immediate k offsets,
  * and the epilogue stores 512 contiguous bytes per instruction.  azsp_tile_layout converts channels-last rows
  * [boards][S][S][C] to (to_tiled = 1) / from (0) that layout at tower entry / exit.  Positions of boards past `boards`

@@ -117,7 +117,8 @@ def untile_features(flat, rows, n):
     """AZSP_FEAT_BF16_TILED tensor ([tile][4][3 n^2][8] bf16) -> int8 planes [rows, 17, n, n]; checks the encoding on the way
     (only 0.0 / 1.0, padding channels zero)."""
     NP = n * n
-    t = flat.view(torch.int16).cpu().numpy().reshape(-1, 4, 3 * NP, 8)
+    tb = max(1, 256 // NP)
+    t = flat.view(torch.int16).cpu().numpy().reshape(-1, 4, tb * NP, 8)
     x = np.ascontiguousarray(t.transpose(0, 2, 1, 3)).reshape(-1, 32)[: rows * NP].reshape(rows, NP, 32)
     assert np.all((x == 0) | (x == 0x3F80)) and not x[:, :, 17:].any()
     return np.ascontiguousarray((x[:, :, :17] == 0x3F80).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
@@ -127,10 +128,11 @@ def tile_features(x):
     """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_BF16_TILED tensor (flat bf16), the inverse of untile_features."""
     rows, _, n, _ = x.shape
     NP = n * n
-    ntiles = (rows + 2) // 3
-    full = torch.zeros(ntiles * 3 * NP, 32, dtype=torch.bfloat16)
+    tb = max(1, 256 // NP)
+    ntiles = (rows + tb - 1) // tb
+    full = torch.zeros(ntiles * tb * NP, 32, dtype=torch.bfloat16)
     full[: rows * NP, :17] = x.reshape(rows, 17, NP).permute(0, 2, 1).reshape(rows * NP, 17).to(torch.bfloat16)
-    return full.view(ntiles, 3 * NP, 4, 8).permute(0, 2, 1, 3).contiguous().reshape(-1)
+    return full.view(ntiles, tb * NP, 4, 8).permute(0, 2, 1, 3).contiguous().reshape(-1)
 
 
 def run_golden_selfplay(kind, G_gold, eval_batch, feature_dtype=_abi.FEAT_I8):

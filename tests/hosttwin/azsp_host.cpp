@@ -43,7 +43,7 @@ int launch_conv3x3(const void* x, const void* w, const float* bias, const void* 
 }
 // tiled layout on the host: [tile][C/8][3*S*S][8] <-> channels-last rows, then the plain loop
 static void host_tile_layout(const unsigned short* src, unsigned short* dst, long long boards, int S, int C, int to_tiled) {
-    const long long rows = boards * S * S, trows = (long long)CV_TB * S * S, nch = C / 8;
+    const long long rows = boards * S * S, trows = (long long)cv_tile_boards(S) * S * S, nch = C / 8;
     for (long long r = 0; r < rows; ++r)
         for (long long c = 0; c < nch; ++c) {
             const long long tile = r / trows, p = r % trows;

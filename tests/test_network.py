@@ -131,7 +131,8 @@ def _tiled_roundtrip_and_conv(bnd, boards, C, S, device, relu=1):
     bias = torch.randn(C, generator=g).to(device)
     wp = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
     n = bnd.dll.azsp_tiled_bytes(boards, S, C) // 2
-    assert n == (boards + 2) // 3 * 3 * S * S * C
+    tb = max(1, 256 // (S * S))  # boards per tile
+    assert n == (boards + tb - 1) // tb * tb * S * S * C
     xt, rt, yt = (torch.zeros(n, dtype=torch.bfloat16, device=device) for _ in range(3))
     assert bnd.dll.azsp_tile_layout(x.data_ptr(), xt.data_ptr(), boards, S, C, 1, None) == 0
     assert bnd.dll.azsp_tile_layout(res.data_ptr(), rt.data_ptr(), boards, S, C, 1, None) == 0
@@ -140,11 +141,11 @@ def _tiled_roundtrip_and_conv(bnd, boards, C, S, device, relu=1):
     if device != "cpu":
         torch.cuda.synchronize()
     assert torch.equal(back, x)
-    # the layout itself: [tile][C/8][3*S*S][8]
+    # the layout itself: [tile][C/8][tb*S*S][8]
     rows = x.permute(0, 2, 3, 1).reshape(boards * S * S, C // 8, 8)
-    full = torch.zeros((boards + 2) // 3 * 3 * S * S, C // 8, 8, dtype=torch.bfloat16, device=device)
+    full = torch.zeros((boards + tb - 1) // tb * tb * S * S, C // 8, 8, dtype=torch.bfloat16, device=device)
     full[: rows.shape[0]] = rows
-    assert torch.equal(xt.view(-1, C // 8, 3 * S * S, 8), full.view(-1, 3 * S * S, C // 8, 8).permute(0, 2, 1, 3))
+    assert torch.equal(xt.view(-1, C // 8, tb * S * S, 8), full.view(-1, tb * S * S, C // 8, 8).permute(0, 2, 1, 3))
     for r, rtile in ((None, None), (res, rt)):
         rc = bnd.dll.azsp_conv3x3_tiled(xt.data_ptr(), wp.data_ptr(), bias.data_ptr(), rtile.data_ptr() if rtile is not None else None,
                                         yt.data_ptr(), boards, S, C, relu, None)
@@ -294,3 +295,36 @@ def test_gpu_forward_tiled_full_batch_is_batch_independent():
     assert torch.equal(p_all[rows - 50:], p_all[100:150]) and torch.equal(v_all[rows - 50:], v_all[100:150])
     p_sub, v_sub = inf.forward_tiled(eu.tile_features(x[:301]).cuda(), 301, 9)
     assert torch.equal(p_sub, p_all[:301]) and torch.equal(v_sub, v_all[:301])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 2, 5, 256, 300, 1000])
+def test_gpu_tiled_conv3x3_gomoku_shape_matches_torch(boards):
+    """k_conv3x3_t64 (17x17 planes, 64 filters: the 13x13 Gomoku tower) vs an fp32 torch convolution of the same bf16 operands."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    _tiled_roundtrip_and_conv(bnd, boards, 64, 17, "cuda")
+    if boards == 5:
+        _tiled_roundtrip_and_conv(bnd, boards, 64, 17, "cuda", relu=0)
+
+
+@pytest.mark.gpu
+def test_gpu_gomoku_network_tiled_tower():
+    """The 13x13 Gomoku network (pad-3 stem -> 17x17 planes, 64 filters): tower on k_conv3x3_t64 vs the library-convolution path
+    of the same InferenceNet and vs the fp32 module."""
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(9)
+    net = AlphaZeroNet((17, 13, 13), 169, 3, 64, 64, gomoku=True)
+    with torch.no_grad():
+        net.policy_head[4].weight.mul_(0.2)
+        net.value_head[6].weight.mul_(0.3)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    x = (torch.rand(70, 17, 13, 13) > 0.6).float()
+    p1, v1 = inf(x.cuda())
+    inf.use_tiled_tower = False
+    p2, v2 = inf(x.cuda())
+    assert (p1 - p2).abs().max().item() <= 1e-2 and (v1 - v2).abs().max().item() <= 2e-2
+    logits, vr = net.eval()(x)
+    assert (p1.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v1.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2

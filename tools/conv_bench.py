@@ -9,7 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alpha_zero_amd import _lib
 
 b = _lib.load()
-B, C, S = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 128, 9
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+S, C = (int(v) for v in os.environ.get('CONV_BENCH_SHAPE', '9,128').split(','))  # '17,64' = the 13x13 Gomoku tower
 g = torch.Generator().manual_seed(0)
 SCALE = float(os.environ.get('CONV_BENCH_SCALE', '1'))  # 0: all-zero activations (data-dependent power check)
 x = SCALE * torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
@@ -52,7 +53,8 @@ def lib(r):
 
 
 flops = 2.0 * B * S * S * C * C * 9
-for name, f in (("tiled_ws", tiled), ("fused_mfma", mine), ("miopen+epilogue", lib), ("tile_layout", layout)):
+for name, f in ((("tiled_ws", tiled), ("fused_mfma", mine), ("miopen+epilogue", lib), ("tile_layout", layout)) if (S, C) == (9, 128) else
+                (("tiled_ws", tiled), ("miopen+epilogue", lib), ("tile_layout", layout))):
     for r in (None, res):
         for _ in range(5):
             f(r)
@@ -65,10 +67,11 @@ for name, f in (("tiled_ws", tiled), ("fused_mfma", mine), ("miopen+epilogue", l
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         print(f"{name:16s} residual={r is not None!s:5s} {ms:8.3f} ms  {flops / ms / 1e9:8.1f} TFLOP/s")
-ref = lib(res).float()
-mine(res)
-torch.cuda.synchronize()
-print("max |fused - library|:", (y.float() - ref).abs().max().item())
+if (S, C) == (9, 128):
+    ref = lib(res).float()
+    mine(res)
+    torch.cuda.synchronize()
+    print("max |fused - library|:", (y.float() - ref).abs().max().item())
 for r in (None, res):
     ref = lib(r).float()
     tiled(r)
