@@ -56,7 +56,7 @@ class Binding:
             "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],
             "azsp_bias_act": [V, V, V, C.c_int64, I, I, I, V], "azsp_conv3x3": [V, V, V, V, V, C.c_int64, I, I, I, V],
             "azsp_conv3x3_tiled": [V, V, V, V, V, C.c_int64, I, I, I, V], "azsp_tile_layout": [V, V, C.c_int64, I, I, I, V],
-            "azsp_stem_tiled": [V, V, V, V, C.c_int64, I, I, I, V], "azsp_head_tiled": [V, V, V, V, V, C.c_int64, I, I, I, I, V],
+            "azsp_stem_tiled": [V, V, V, V, C.c_int64, I, I, I, I, V], "azsp_head_tiled": [V, V, V, V, V, C.c_int64, I, I, I, I, V],
             "azsp_replay_gather": [V, V, V, V, I, I, I, I, I, I, V, V, V, V], "azsp_rng_probe": [V, I, I, V, V, V],
         }
         for k, a in sig.items():

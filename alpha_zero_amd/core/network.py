@@ -91,7 +91,7 @@ class InferenceNet(nn.Module):
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
             sw = convs[0][0]
-            self.stem_ok = sw.shape[1] <= 32 and sw.shape[2] == 3 and sw.shape[3] == 3 and self.stem_pad == 1
+            self.stem_ok = sw.shape[1] <= 32 and sw.shape[2] == 3 and sw.shape[3] == 3 and self.stem_pad in (1, 3)
             if self.stem_ok:
                 swp = torch.zeros(9, sw.shape[0], 32)
                 swp[:, :, : sw.shape[1]] = sw.permute(2, 3, 0, 1).reshape(9, sw.shape[0], sw.shape[1])
@@ -180,9 +180,11 @@ class InferenceNet(nn.Module):
         return a
 
     def supports_tiled_features(self, board_size, device):
-        """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled)."""
-        return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and self.filters == 128
-                and board_size == 9 and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
+        """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled): 9x9 Go with 128
+        filters (pad-1 stem) and 13x13 Gomoku with 64 filters (pad-3 stem, 17x17 planes)."""
+        shape_ok = (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 13, 3))
+        return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and shape_ok
+                and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
 
     @torch.no_grad()
     def forward_tiled(self, feat, rows, board_size, priors_out=None, values_out=None):
@@ -192,9 +194,11 @@ class InferenceNet(nn.Module):
 
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream)
-        B, S, C = rows, board_size, self.filters
+        B, C = rows, self.filters
+        S = board_size + 2 * (self.stem_pad - 1)  # planes of the tower (network.py:101-105: the Gomoku stem pads by 3)
         a, m, o = self._tiled_buffers(B, S, C, feat.device)
-        ck(dll.azsp_stem_tiled(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_stem_tiled")
+        ck(dll.azsp_stem_tiled(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, board_size, C, self.stem_pad, 1, st),
+           "azsp_stem_tiled")
         a = self._blocks_tiled(a, m, o, B, S, C, st)
         if getattr(self, "_head_key", None) != (B, feat.device):
             self._pol = torch.empty((B, self.npol * S * S), dtype=torch.bfloat16, device=feat.device)

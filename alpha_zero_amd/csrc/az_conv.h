@@ -502,36 +502,38 @@ __global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned ch
 
 // 1x1 head convolution on the tiled layout (policy / value heads, core/network.py:131-156 conv + BatchNorm folded + ReLU):
 // out[b][pl][q] = relu(sum_c w[pl][c] x[b][q][c] + bias[pl]); planes [0, npol) go to pol_out [boards][npol][81], the rest to
-// val_out [boards][NPL - npol][81] (bf16; plane-major per board = nn.Flatten order).  HBM-bound: one pass over the tower output.
+// val_out [boards][NPL - npol][S*S] (bf16; plane-major per board = nn.Flatten order), any (S, C) of the tiled layout.  HBM-bound:
+// one pass over the tower output.
 template <int NPL> __global__ void __launch_bounds__(256)
 k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, unsigned short* __restrict__ pol_out,
-             unsigned short* __restrict__ val_out, long long npos, int npol) {
-    __shared__ float ws[NPL * CV_C];
-    for (int i = threadIdx.x; i < NPL * CV_C; i += 256) ws[i] = w[i];
+             unsigned short* __restrict__ val_out, long long npos, int npol, int C, int P2, int tile_rows) {
+    extern __shared__ float ws[];  // [NPL][C]
+    for (int i = threadIdx.x; i < NPL * C; i += 256) ws[i] = w[i];
     __syncthreads();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npos) return;
-    const long long tile = i / CT_ROWS, board = i / CV_P2;
-    const int p = (int)(i - tile * CT_ROWS), q = (int)(i - board * CV_P2);
+    const int nch = C / 8;
+    const long long tile = i / tile_rows, board = i / P2;
+    const int p = (int)(i - tile * tile_rows), q = (int)(i - board * P2);
     float acc[NPL];
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) acc[pl] = bias[pl];
-    const unsigned char* src = x + (size_t)tile * CT_TILE + (size_t)p * 16;
+    const unsigned char* src = x + ((size_t)tile * nch * tile_rows + (size_t)p) * 16;
 #pragma unroll 4
-    for (int c = 0; c < 16; ++c) {
-        const cv_u32x4 v = *(const cv_u32x4*)(src + (size_t)c * CT_GBLK);
+    for (int c = 0; c < nch; ++c) {
+        const cv_u32x4 v = *(const cv_u32x4*)(src + (size_t)c * tile_rows * 16);
         const float f[8] = {cv_bf16_lo(v.x), cv_bf16_hi(v.x), cv_bf16_lo(v.y), cv_bf16_hi(v.y), cv_bf16_lo(v.z), cv_bf16_hi(v.z), cv_bf16_lo(v.w), cv_bf16_hi(v.w)};
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[pl] += f[e] * ws[pl * CV_C + c * 8 + e];
+            for (int e = 0; e < 8; ++e) acc[pl] += f[e] * ws[pl * C + c * 8 + e];
     }
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
         const float v = fmaxf(acc[pl], 0.0f);
         const unsigned short h = (unsigned short)(cv_pack_bf16(v, 0.0f) & 0xffffu);
-        if (pl < npol) pol_out[((size_t)board * npol + pl) * CV_P2 + q] = h;
-        else val_out[((size_t)board * (NPL - npol) + (pl - npol)) * CV_P2 + q] = h;
+        if (pl < npol) pol_out[((size_t)board * npol + pl) * P2 + q] = h;
+        else val_out[((size_t)board * (NPL - npol) + (pl - npol)) * P2 + q] = h;
     }
 }
 #endif  // __HIPCC__

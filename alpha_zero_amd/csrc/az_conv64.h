@@ -77,21 +77,29 @@ __device__ __forceinline__ void c6_mfma_ac(c6_f32x4& acc, const cv_bf16x8& wa, c
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(wa), "v"(b), "v"(c));
 }
 
-template <bool RES> __global__ void __launch_bounds__(CW_THREADS, 1)
+// NCH = input-channel chunks: 8 = tower layer (64 -> 64, input = a tiled 17x17 board); 4 = stem (17 planes padded to 32 -> 64): the
+// input is the engine's tiled 13x13 feature board, embedded at offset (2, 2) of the zero 17x17 plane by the DMA masks -- a pad-3
+// convolution of the 13x13 board IS the pad-1 convolution of that embedded plane (network.py:101-105).
+template <bool RES, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
               const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * C6_LBUF];
+    constexpr int HALVES = NCH / 4, NSTEP = 9 * HALVES;   // k-steps (32 input channels each)
+    constexpr int LBUF = NCH * C6_LBLK;                     // LDS buffer: NCH strips
+    constexpr int IN_S = NCH == 8 ? C6_S : 13, IN_OFF = NCH == 8 ? 0 : 2;  // input board size and its offset in the 17x17 plane
+    constexpr int IN_GBLK = IN_S * IN_S * 16, XTILE = NCH * IN_GBLK;
+    constexpr int SPW = NCH / 4, NPIECE = 6 * SPW;          // strips and DMA pieces per wave
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    for (int i = tid; i < 2 * C6_LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < 2 * LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
 
     // A fragments: step s = (tap, input half), cout tile q: lane (cout = 16 q + l15, cin = 32 half + 8 kg .. + 8)
-    cv_bf16x8 wf[C6_NSTEP * 4];
+    cv_bf16x8 wf[NSTEP * 4];
 #pragma unroll
-    for (int t = 0; t < C6_NSTEP * 4; ++t) {
+    for (int t = 0; t < NSTEP * 4; ++t) {
         const int s = t >> 2, q = t & 3;
-        wf[t] = *(const cv_bf16x8*)(w + ((size_t)((s >> 1) * C6_C + q * 16 + l15)) * C6_C + (s & 1) * 32 + kg * 8);
+        wf[t] = *(const cv_bf16x8*)(w + ((size_t)((s / HALVES) * C6_C + q * 16 + l15)) * (8 * NCH) + (s % HALVES) * 32 + kg * 8);
     }
     c6_f32x4 bv[4];  // bias in the D layout (rows = couts 16 q + 4 kg + e): the C operand of the first k-step
 #pragma unroll
@@ -100,19 +108,19 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
         for (int e = 0; e < 4; ++e) bv[q][e] = bias[q * 16 + 4 * kg + e];
     const unsigned lo16 = relu ? 0u : 0x80008000u;
 
-    // LDS-DMA plan: a strip is 6 pieces of 64 cells (the last one holds 4 position cells); wave q moves strips 2q and 2q+1
+    // LDS-DMA plan: a strip is 6 pieces of 64 cells (the last one holds 4 position cells); wave q moves strips SPW q .. SPW q + SPW - 1
     unsigned dsrc[6];
     unsigned long long dmask[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const int cell = 64 * i + lane, k = cell - C6_CELL0, yy = k / C6_PITCH, xx = k - yy * C6_PITCH;
-        const bool ok = k >= 0 && yy < C6_S && xx < C6_S;
-        dsrc[i] = (unsigned)((yy * C6_S + xx) * 16);
+        const int cell = 64 * i + lane, k = cell - C6_CELL0, yy = k / C6_PITCH - IN_OFF, xx = k % C6_PITCH - IN_OFF;
+        const bool ok = k >= 0 && yy >= 0 && xx >= 0 && yy < IN_S && xx < IN_S;
+        dsrc[i] = (unsigned)((yy * IN_S + xx) * 16);
         dmask[i] = __builtin_amdgcn_ballot_w64(ok);
     }
-    auto dma_piece = [&](const unsigned char* src, unsigned dstbuf, bool live, int i) {  // i in [0, 12): strip 2 wave + i / 6, piece i % 6
-        const int c = 2 * wave + i / 6, pc = i % 6;
-        const unsigned long long base = (unsigned long long)(src + (size_t)c * C6_GBLK);
+    auto dma_piece = [&](const unsigned char* src, unsigned dstbuf, bool live, int i) {  // i in [0, NPIECE): strip SPW wave + i / 6, piece i % 6
+        const int c = SPW * wave + i / 6, pc = i % 6;
+        const unsigned long long base = (unsigned long long)(src + (size_t)c * IN_GBLK);
         const unsigned long long mask = live ? dmask[pc] : 0ull;
         const unsigned dst = dstbuf + (unsigned)(c * C6_LBLK + pc * 1024);
         asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
@@ -130,17 +138,17 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
         lmap[j] = (unsigned)((cw64_map.cell[idx] - C6_CELL0) * 16 + kg * C6_LBLK) | ((unsigned)cw64_map.pos[idx] << 16);
     }
     cv_bf16x8 bb[2][5];  // B fragments: k-step s lives in slot s & 1
-    auto load_step = [&](const unsigned char* const (&bp)[5], int s) {  // tap s / 2 = constant cell offset, input half s % 2 = 4 strips on
-        const int tap = s >> 1;
-        const int off = ((tap / 3) * C6_PITCH + (tap % 3)) * 16 + (s & 1) * (4 * C6_LBLK);
+    auto load_step = [&](const unsigned char* const (&bp)[5], int s) {  // tap s / HALVES = constant cell offset, input half = 4 strips on
+        const int tap = s / HALVES;
+        const int off = ((tap / 3) * C6_PITCH + (tap % 3)) * 16 + (s % HALVES) * (4 * C6_LBLK);
 #pragma unroll
         for (int j = 0; j < 5; ++j) bb[s & 1][j] = *(const cv_bf16x8*)(bp[j] + off);
     };
 
     {   // first board: all pieces at once
-        const unsigned char* src = x + (size_t)blockIdx.x * C6_TILE;
+        const unsigned char* src = x + (size_t)blockIdx.x * XTILE;
 #pragma unroll
-        for (int i = 0; i < C6_NPIECE; ++i) dma_piece(src, lds0, true, i);
+        for (int i = 0; i < NPIECE; ++i) dma_piece(src, lds0, true, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CV_BARRIER();
     }
@@ -150,7 +158,7 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
         load_step(bp0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < C6_NSTEP * 4; ++t) {  // the compiler's wait for the weight loads belongs in front of the loop (see az_conv.h)
+    for (int t = 0; t < NSTEP * 4; ++t) {  // the compiler's wait for the weight loads belongs in front of the loop (see az_conv.h)
         if (t < 64) asm volatile("" : : "a"(wf[t]));
         else asm volatile("" : : "v"(wf[t]));
     }
@@ -159,11 +167,11 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
-        const unsigned char* Xs = lds + buf * C6_LBUF;
-        const unsigned char* Xn = lds + (buf ^ 1) * C6_LBUF;
+        const unsigned char* Xs = lds + buf * LBUF;
+        const unsigned char* Xn = lds + (buf ^ 1) * LBUF;
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const unsigned char* nsrc = x + (size_t)(has_next ? tile + (int)gridDim.x : tile) * C6_TILE;
-        const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * C6_LBUF);
+        const unsigned char* nsrc = x + (size_t)(has_next ? tile + (int)gridDim.x : tile) * XTILE;
+        const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * LBUF);
         const unsigned char* rbase = RES ? res + (size_t)tile * C6_TILE : nullptr;
         unsigned char* ybase = y + (size_t)tile * C6_TILE;
         const unsigned char* bp[5];
@@ -180,8 +188,8 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
         __builtin_amdgcn_sched_barrier(0);
         c6_f32x4 acc[5][4];
 #pragma unroll
-        for (int t = 0; t < C6_NSTEP; ++t) {  // the fragments of step 0 are already in flight (issued before the previous epilogue)
-            if (t + 1 < C6_NSTEP) load_step(bp, t + 1);
+        for (int t = 0; t < NSTEP; ++t) {  // the fragments of step 0 are already in flight (issued before the previous epilogue)
+            if (t + 1 < NSTEP) load_step(bp, t + 1);
 #pragma unroll
             for (int j = 0; j < 5; ++j)
 #pragma unroll
@@ -190,7 +198,7 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
                     else if (t * 4 + q < 64) c6_mfma_a(acc[j][q], wf[t * 4 + q], bb[t & 1][j]);
                     else c6_mfma_v(acc[j][q], wf[t * 4 + q], bb[t & 1][j]);
                 }
-            if (2 * t + 1 < C6_NPIECE) {  // the next board's pieces ride in the shadow of the first k-steps' MFMAs (12 steps to land)
+            if (2 * t + 1 < NPIECE) {  // the next board's pieces ride in the shadow of the first k-steps' MFMAs
                 dma_piece(nsrc, ndst, has_next, 2 * t);
                 dma_piece(nsrc, ndst, has_next, 2 * t + 1);
             }

@@ -119,10 +119,10 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
         if (n_cu < 0) return -1;
         const unsigned grid = (unsigned)(boards < n_cu ? boards : n_cu);
         if (res)
-            hipLaunchKernelGGL(k_conv3x3_t64<true>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+            hipLaunchKernelGGL((k_conv3x3_t64<true, 8>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
                                bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
         else
-            hipLaunchKernelGGL(k_conv3x3_t64<false>, dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+            hipLaunchKernelGGL((k_conv3x3_t64<false, 8>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
                                bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
         return AZ_HIP(hipGetLastError());
     }
@@ -139,10 +139,16 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
                            (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
     return AZ_HIP(hipGetLastError());
 }
-int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* st) {
-    if (S != CV_S || C != CV_C) return 1;
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
+    if (S == 13 && C == C6_C && pad == 3) {  // Gomoku: 13x13 boards -> 17x17 planes, one board per tile
+        const unsigned grid = (unsigned)(boards < n_cu ? boards : n_cu);
+        hipLaunchKernelGGL((k_conv3x3_t64<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+                           bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+        return AZ_HIP(hipGetLastError());
+    }
+    if (S != CV_S || C != CV_C || pad != 1) return 1;
     const long long ntiles = (boards + CV_TB - 1) / CV_TB;
     const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
     hipLaunchKernelGGL((k_conv3x3_tiled<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
@@ -151,10 +157,10 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
 }
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
                       void* st) {
-    if (S != CV_S || C != CV_C || npol + nval != 3) return 1;
-    const long long npos = boards * CV_P2;
-    hipLaunchKernelGGL(k_head_tiled<3>, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x, w, bias,
-                       (unsigned short*)pol, (unsigned short*)val, npos, npol);
+    if (C % 8 || C > 1024 || npol + nval != 3) return 1;
+    const long long npos = boards * S * S;
+    hipLaunchKernelGGL(k_head_tiled<3>, dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
+                       (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S, cv_tile_boards(S) * S * S);
     return AZ_HIP(hipGetLastError());
 }
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* st) {

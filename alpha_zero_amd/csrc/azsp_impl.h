@@ -510,7 +510,7 @@ int launch_conv3x3(const void* x, const void* w, const float* bias, const void* 
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
-int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* stream);
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
                       void* stream);
 }  // namespace azb
@@ -933,10 +933,11 @@ int azsp_replay_gather(const int8_t* ring_states, const float* ring_pi, const fl
     return azb::launch_replay_gather(a, total, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
 }
 
-int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t relu, void* stream) {
-    if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
+                    void* stream) {
+    if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff || pad < 1) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_stem_tiled(x, w, bias, y, (long long)boards, S, C, relu, stream);
+    const int rc = azb::launch_stem_tiled(x, w, bias, y, (long long)boards, S, C, pad, relu, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -167,6 +167,7 @@ def main():
         a, m, o = inf._tiled  # real activations of the last forward
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rows = eng.rows
+        S_t = n + 2 * (inf.stem_pad - 1)  # tower planes (17x17 behind the Gomoku pad-3 stem)
         reps = 5
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps * inf.n_blocks + 1)]
         torch.cuda.synchronize(dev)
@@ -174,17 +175,18 @@ def main():
         ev[0].record()
         for _ in range(reps):
             for i in range(inf.n_blocks):  # the forward's own launch sequence, one event after every launch
-                dll.azsp_conv3x3_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, n, args.filters, 1, st)
+                assert dll.azsp_conv3x3_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
                 k += 1
                 ev[k].record()
-                dll.azsp_conv3x3_tiled(m.data_ptr(), inf.wp[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows, n,
-                                       args.filters, 1, st)
+                assert dll.azsp_conv3x3_tiled(m.data_ptr(), inf.wp[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows,
+                                              S_t, args.filters, 1, st) == 0
                 k += 1
                 ev[k].record()
                 a, o = o, a
         torch.cuda.synchronize(dev)
         d = [ev[j].elapsed_time(ev[j + 1]) for j in range(k)]
-        conv = {"launches": k, "avg_ms": float(np.mean(d)), "avg_ms_plain": float(np.mean(d[0::2])), "avg_ms_residual": float(np.mean(d[1::2]))}
+        conv = {"launches": k, "avg_ms": float(np.mean(d)), "avg_ms_plain": float(np.mean(d[0::2])), "avg_ms_residual": float(np.mean(d[1::2])),
+                "planes": S_t}
 
     if args.split_round and rank == 0:
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -244,20 +246,22 @@ def main():
             # the step's dominant kernel: 2 * blocks launches per forward.  Algorithmic work per launch = the dense 3x3
             # convolution (padding taps counted, the usual convention): 2 * rows * N^2 * C * C * 9 flop.
             rows = args.games * args.parallel
-            conv_flops = 2.0 * rows * n * n * args.filters * args.filters * 9
+            S_t = conv["planes"]
+            conv_flops = 2.0 * rows * S_t * S_t * args.filters * args.filters * 9
             tf = conv_flops / (conv["avg_ms"] * 1e-3) / 1e12
             ctraffic = None
             cprof = os.path.join(ROOT, "profiles", "conv_kernel_pmc.json")
             if os.path.exists(cprof):
                 try:
                     pj = json.load(open(cprof))
-                    if pj.get("rows") == rows and pj.get("board") == n:
+                    if pj.get("rows") == rows and pj.get("board") == n and pj.get("channels") == args.filters:
                         ctraffic = pj.get("hbm_bytes_per_launch")
                 except Exception:
                     ctraffic = None
-            roofline = {"kernel": "k_conv3x3_tiled (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)", "bound": "mfma",
+            roofline = {"kernel": ("k_conv3x3_tiled" if S_t == 9 else "k_conv3x3_t64") + " (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)",
+                        "bound": "mfma",
                         "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5), "traffic": ctraffic,
-                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * n * n * args.filters * 2 * 2.5),
+                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * 2.5),
                         "avg_launch_ms": round(conv["avg_ms"], 4), "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4),
                         "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4), "launches_per_step": 2 * args.blocks,
                         "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4)}
@@ -280,7 +284,7 @@ def main():
             "dtype": args.net_dtype, "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
                                    f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",
-                       "evaluator": "tiled layout, hand-written stem / tower / head kernels" if actor.tiled_features else "library convolutions",
+                       "evaluator": "tiled layout, hand-written stem / tower / head kernels" if actor.tiled_features else "library convolutions + fused epilogue",
                        "games_per_gpu": args.games, "stagger_plies": args.stagger, "hip_graph_forward": not args.no_graph,
                        "parallelism": f"games sharded x{world}, sample gather to rank 0"},
             "sims_per_sec": round(total_sims / elapsed_max, 1), "evals_per_sec": round(total_evals / elapsed_max, 1),

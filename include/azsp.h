@@ -235,9 +235,11 @@ int azsp_replay_gather(const int8_t* ring_states_dev, const float* ring_pi_dev, 
 /* Stem of the evaluator (core/network.py:98-108 conv_block: conv3x3 17 -> C + BatchNorm + ReLU) on the tiled layout: the
  * input is the feature tensor azsp_select writes with feature_dtype = AZSP_FEAT_BF16_TILED (17 planes zero-padded to 32
  * channels: [tile][4][3*S*S][8] bf16, azsp_tiled_bytes(rows, S, 32) bytes); w_packed is [9 taps][C out][32 in] bf16 (input
- * channels 17..31 zero), the output is the tower's tiled layout.  Same kernel as azsp_conv3x3_tiled with 4 input chunks. */
+ * channels 17..31 zero), the output is the tower's tiled layout with planes of board_size + 2 (pad - 1): pad = 1 for Go, pad = 3
+ * for Gomoku (core/network.py:101-105: 13x13 boards become 17x17 planes).  Same kernels as azsp_conv3x3_tiled with 4 input chunks;
+ * on the device: (board 9, 128 filters, pad 1) and (board 13, 64 filters, pad 3). */
 int azsp_stem_tiled(const void* features_tiled_dev, const void* w_packed_dev, const float* bias_dev, void* y_tiled_dev, int64_t boards,
-                    int32_t board_size, int32_t channels, int32_t relu, void* stream);
+                    int32_t board_size, int32_t channels, int32_t pad, int32_t relu, void* stream);
 /* Both 1x1 head convolutions (core/network.py:131-156: conv1x1 + BatchNorm + ReLU of the policy and the value head) in one
  * pass over the tiled tower output: w [policy_planes + value_planes][C] fp32 (BatchNorm folded), bias fp32;
  * pol_out [boards][policy_planes][S*S], val_out [boards][value_planes][S*S] bf16 (plane-major = nn.Flatten order). */

@@ -68,12 +68,18 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
     host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
     return 0;
 }
-int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void*) {
-    const size_t nin = (size_t)boards * S * S * 32, nout = (size_t)boards * S * S * C;
-    std::vector<unsigned short> xn(nin), yn(nout);
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*) {
+    // un-tile the 32-channel features, embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1), pad-1 convolution
+    const int So = S + 2 * (pad - 1), off = pad - 1;
+    std::vector<unsigned short> xn((size_t)boards * S * S * 32), xe((size_t)boards * So * So * 32, 0), yn((size_t)boards * So * So * C);
     host_tile_layout((const unsigned short*)x, xn.data(), boards, S, 32, 0);
-    cv_host_conv3x3_io(xn.data(), (const unsigned short*)w, bias, nullptr, yn.data(), (int)boards, S, 32, C, relu);
-    host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
+    for (long long b = 0; b < boards; ++b)
+        for (int yy = 0; yy < S; ++yy)
+            for (int xx = 0; xx < S; ++xx)
+                for (int c = 0; c < 32; ++c)
+                    xe[(((size_t)b * So + yy + off) * So + xx + off) * 32 + c] = xn[(((size_t)b * S + yy) * S + xx) * 32 + c];
+    cv_host_conv3x3_io(xe.data(), (const unsigned short*)w, bias, nullptr, yn.data(), (int)boards, So, 32, C, relu);
+    host_tile_layout(yn.data(), (unsigned short*)y, boards, So, C, 1);
     return 0;
 }
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,

@@ -201,8 +201,8 @@ def test_gpu_tiled_tower_equals_rowmajor_tower(golden_dir):
     assert (p1 - p2).abs().max().item() <= 5e-3 and (v1 - v2).abs().max().item() <= 2e-2
 
 
-def _stem_head_checks(bnd, boards, C, S, device):
-    """azsp_stem_tiled / azsp_head_tiled vs torch on the same bf16 operands."""
+def _stem_head_checks(bnd, boards, C, S, device, pad=1):
+    """azsp_stem_tiled / azsp_head_tiled vs torch on the same bf16 operands (pad = 3: the Gomoku stem, planes grow to S + 4)."""
     import engine_util as eu
 
     g = torch.Generator().manual_seed(7 + boards)
@@ -213,21 +213,22 @@ def _stem_head_checks(bnd, boards, C, S, device):
     wp[:, :, :17] = w.float().permute(2, 3, 0, 1).reshape(9, C, 17)
     wp = wp.to(torch.bfloat16).contiguous().to(device)
     feat = eu.tile_features(x).to(device)
-    n = bnd.dll.azsp_tiled_bytes(boards, S, C) // 2
+    So = S + 2 * (pad - 1)
+    n = bnd.dll.azsp_tiled_bytes(boards, So, C) // 2
     yt = torch.zeros(n, dtype=torch.bfloat16, device=device)
-    assert bnd.dll.azsp_stem_tiled(feat.data_ptr(), wp.data_ptr(), bias.to(device).data_ptr(), yt.data_ptr(), boards, S, C, 1, None) == 0
-    y = torch.empty(boards, C, S, S, dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
-    assert bnd.dll.azsp_tile_layout(yt.data_ptr(), y.data_ptr(), boards, S, C, 0, None) == 0
-    ref = torch.relu(torch.nn.functional.conv2d(x, w.float(), bias, padding=1))
+    assert bnd.dll.azsp_stem_tiled(feat.data_ptr(), wp.data_ptr(), bias.to(device).data_ptr(), yt.data_ptr(), boards, S, C, pad, 1, None) == 0
+    y = torch.empty(boards, C, So, So, dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    assert bnd.dll.azsp_tile_layout(yt.data_ptr(), y.data_ptr(), boards, So, C, 0, None) == 0
+    ref = torch.relu(torch.nn.functional.conv2d(x, w.float(), bias, padding=pad))
     if device != "cpu":
         torch.cuda.synchronize()
     assert (y.float().cpu() - ref).abs().max().item() <= 1.0 / 128 * max(1.0, ref.abs().max().item())
     # heads on the stem output
     hw = torch.randn(3, C, generator=g) * 0.2
     hb = torch.randn(3, generator=g)
-    pol = torch.empty(boards, 2 * S * S, dtype=torch.bfloat16, device=device)
-    val = torch.empty(boards, S * S, dtype=torch.bfloat16, device=device)
-    assert bnd.dll.azsp_head_tiled(yt.data_ptr(), hw.to(device).data_ptr(), hb.to(device).data_ptr(), pol.data_ptr(), val.data_ptr(), boards, S, C,
+    pol = torch.empty(boards, 2 * So * So, dtype=torch.bfloat16, device=device)
+    val = torch.empty(boards, So * So, dtype=torch.bfloat16, device=device)
+    assert bnd.dll.azsp_head_tiled(yt.data_ptr(), hw.to(device).data_ptr(), hb.to(device).data_ptr(), pol.data_ptr(), val.data_ptr(), boards, So, C,
                                    2, 1, None) == 0
     if device != "cpu":
         torch.cuda.synchronize()
@@ -242,6 +243,7 @@ def test_stem_head_abi_host_twin():
 
     for boards in (1, 4):
         _stem_head_checks(eu.hosttwin_binding(), boards, 16, 5, "cpu")
+    _stem_head_checks(eu.hosttwin_binding(), 3, 16, 5, "cpu", pad=3)
 
 
 @pytest.mark.gpu
@@ -250,6 +252,7 @@ def test_gpu_stem_head_tiled_match_torch(boards):
     from alpha_zero_amd import _lib
 
     _stem_head_checks(_lib.load(), boards, 128, 9, "cuda")
+    _stem_head_checks(_lib.load(), boards, 64, 13, "cuda", pad=3)  # the Gomoku stem / heads (17x17 planes)
 
 
 @pytest.mark.gpu
@@ -328,3 +331,11 @@ def test_gpu_gomoku_network_tiled_tower():
     assert (p1 - p2).abs().max().item() <= 1e-2 and (v1 - v2).abs().max().item() <= 2e-2
     logits, vr = net.eval()(x)
     assert (p1.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v1.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
+    # ... and the whole evaluator on the engine's tiled 13x13 features: pad-3 stem, tower and heads in hand-written kernels
+    import engine_util as eu
+
+    inf.use_tiled_tower = True
+    assert inf.supports_tiled_features(13, "cuda")
+    p3, v3 = inf.forward_tiled(eu.tile_features(x).cuda(), 70, 13)
+    assert (p3 - p2).abs().max().item() <= 1e-2 and (v3 - v2).abs().max().item() <= 2e-2
+    assert (p3.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v3.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
