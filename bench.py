@@ -250,7 +250,7 @@ def main():
             conv_flops = 2.0 * rows * S_t * S_t * args.filters * args.filters * 9
             tf = conv_flops / (conv["avg_ms"] * 1e-3) / 1e12
             ctraffic = None
-            cprof = os.path.join(ROOT, "profiles", "conv_kernel_pmc.json")
+            cprof = os.path.join(ROOT, "profiles", "conv_kernel_pmc.json" if S_t == 9 else "conv64_kernel_pmc.json")
             if os.path.exists(cprof):
                 try:
                     pj = json.load(open(cprof))
