@@ -200,20 +200,25 @@ class Engine:
         self._ck(self.b.dll.azsp_commit_move(self.h, m.ctypes.data, self._stream()), "azsp_commit_move")
 
     # -- samples ----------------------------------------------------------------------------------------
-    def harvest(self, sample_capacity=None, max_games=None):
-        """Returns (states int8[n,17,N,N], pi float32[n,A], z float32[n], games int32[k,16]) -- device tensors + host meta."""
+    def harvest(self, sample_capacity=None, max_games=None, with_moves=False):
+        """Returns (states int8[n,17,N,N], pi float32[n,A], z float32[n], games int32[k,16]) -- device tensors + host meta;
+        with_moves=True appends moves int16[n] (the move played from every sample's position, -1 = resigned)."""
         cap = sample_capacity or max(4 * self.G, 2 * self.geo.stage_capacity)
         mg = max_games or 2 * self.G
         if self._harvest_bufs is None or self._harvest_bufs[0].shape[0] < cap:
             self._harvest_bufs = (torch.empty((cap, 17, self.N, self.N), dtype=torch.int8, device=self.device),
                                   torch.empty((cap, self.A), dtype=torch.float32, device=self.device),
-                                  torch.empty((cap,), dtype=torch.float32, device=self.device))
-        st, pi, z = self._harvest_bufs
+                                  torch.empty((cap,), dtype=torch.float32, device=self.device),
+                                  torch.empty((cap,), dtype=torch.int16, device=self.device))
+        st, pi, z, mvbuf = self._harvest_bufs
+        self._ck(self.b.dll.azsp_harvest_moves(self.h, mvbuf.data_ptr() if with_moves else None), "azsp_harvest_moves")
         games = np.zeros((mg, 16), dtype=np.int32)
         ns, ng = C.c_int32(0), C.c_int32(0)
         self._ck(self.b.dll.azsp_harvest(self.h, st.data_ptr(), pi.data_ptr(), z.data_ptr(), st.shape[0], games.ctypes.data, mg,
                                          C.byref(ns), C.byref(ng), self._stream()), "azsp_harvest")
         n, k = ns.value, ng.value
+        if with_moves:
+            return st[:n], pi[:n], z[:n], games[:k], mvbuf[:n]
         return st[:n], pi[:n], z[:n], games[:k]
 
     def counters(self, reset=False):

@@ -143,13 +143,17 @@ class SelfPlayActor:
     def harvest_tensors(self):
         return self.engine.harvest()
 
-    def harvest(self):
+    def harvest(self, with_moves=False):
         """Finished games as the reference actor emits them: [(game_seq: list[Transition], stats: dict)]
-        (pipeline.py:283, :356-380).  pi_prob is float64 for Go and float32 for Gomoku like the reference."""
-        states, pi, z, games = self.engine.harvest()
+        (pipeline.py:283, :356-380).  pi_prob is float64 for Go and float32 for Gomoku like the reference.
+        with_moves=True yields (game_seq, stats, moves): the game's move list as env.history holds it (flat actions, N*N = pass;
+        a final resignation is not a history move, base.py:224-226) -- what to_sgf() needs (pipeline.py:276-281)."""
+        got = self.engine.harvest(with_moves=with_moves)
+        states, pi, z, games = got[:4]
         if len(games) == 0:
             return []
         states, pi, z = states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+        moves = got[4].cpu().numpy() if with_moves else None
         out = []
         for row in games:
             s0, ln = int(row[0]), int(row[1])
@@ -157,8 +161,18 @@ class SelfPlayActor:
             seq = [Transition(state=states[s0 + i].copy(), pi_prob=pis[i].copy(), value=float(z[s0 + i])) for i in range(ln)]
             stats = game_stats_from_row(row, self.game, self.komi, self.resign_threshold)
             stats["training_steps"] = self.training_steps  # tag of the weights in use (pipeline.py:271, :492)
-            out.append((seq, stats))
+            out.append((seq, stats, [int(m) for m in moves[s0:s0 + ln] if m >= 0]) if with_moves else (seq, stats))
         return out
+
+    def game_sgf(self, stats, moves, date=""):
+        """SGF text of a harvested game in the reference's format (go.py:202-210 / gomoku.py:149-157 through sgf_wrapper.make_sgf)."""
+        from ..envs.base import PlayerMove
+        from ..utils.sgf import make_sgf
+
+        n = self.cfg.board_size
+        hist = [PlayerMove("B" if i % 2 == 0 else "W", m) for i, m in enumerate(moves)]
+        is_go = self.game == "go"
+        return make_sgf(n, hist, stats["game_result"], ruleset="Chinese" if is_go else "", komi=self.komi if is_go else "", date=date)
 
     def counters(self, reset=False):
         return self.engine.counters(reset)
@@ -191,7 +205,7 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
         from ..utils.sgf import get_time_stamp
 
         writer = CsvWriter(os.path.join(logs_dir, f"actor{rank}.csv"))
-    last_ckpt, t_last = None, time.time()
+    last_ckpt, t_last, played_games = None, time.time(), 0
     while stop_event is None or not stop_event.is_set():
         if ckpt_event is not None and ckpt_event.is_set():
             continue
@@ -203,8 +217,18 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
                 actor.set_network(network, st["training_steps"])
                 last_ckpt = new_ckpt
         actor.run_rounds(harvest_every)
-        finished = actor.harvest()
+        want_sgf = bool(save_sgf_dir) and save_sgf_interval > 0 and os.path.isdir(save_sgf_dir)
+        finished = actor.harvest(with_moves=want_sgf)
         now = time.time()
+        if want_sgf:  # every save_sgf_interval-th finished game is dumped like the reference does (pipeline.py:276-281)
+            from ..utils.sgf import get_time_stamp as _ts
+
+            for seq, stats, moves in finished:
+                played_games += 1
+                if played_games % save_sgf_interval == 0:
+                    with open(os.path.join(save_sgf_dir, f"actor{rank}_{_ts(True)}_{played_games}.sgf"), "w") as f:
+                        f.write(actor.game_sgf(stats, moves, date=_ts()))
+            finished = [(seq, stats) for seq, stats, _ in finished]
         for seq, stats in finished:
             ts = stats.pop("training_steps")
             stats["time_per_game"] = round((now - t_last) * num_games / max(1, len(finished)), 4)

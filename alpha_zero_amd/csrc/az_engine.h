@@ -60,6 +60,7 @@ struct AzMem {
     u64* stg_planes;         // [G][2][stage_cap][16][W]
     float* stg_pi;           // [G][2][stage_cap][A]
     unsigned char* stg_meta; // [G][2][stage_cap]   1 = black to move
+    int16_t* stg_move;       // [G][2][stage_cap]   the move played from the sample's position (-1 = resigned)
     int* stg_hdr;            // [G][2][16]  see SH_*
     // move log (tests / shim): per game per logged move
     double* log_pi;          // [G][log_cap][A]
@@ -1216,6 +1217,9 @@ template <class Wv, int N, int GAME> struct Engine {
         if (resign) R::go_resign(gr.env, ns);
         else ns = hdr(child).st;
         if (Wv::first()) {
+            // the move that leaves the recorded position: what env.history / to_sgf() would hold (resign is not a history move)
+            const int* sh = m.stg_hdr + ((size_t)g * 2 + gr.cur_buf) * SH_COUNT;
+            if (sh[SH_LEN] > 0) m.stg_move[((size_t)g * 2 + gr.cur_buf) * c.stage_cap + (sh[SH_LEN] - 1)] = (int16_t)(resign ? -1 : mv);
             if (GAME == AZ_GO && !resign && mv == NP) gr.num_passes += 1;
             gr.env = ns;
             gr.ply += 1;

@@ -224,6 +224,7 @@ struct OpHarvest {
     int* games;
     int max_games;
     int* out_counts;  // [0] samples, [1] games
+    int16_t* moves;   // optional: the move played from every sample's position (azsp_harvest_moves)
     template <class E> AZ_HD void operator()(E& e) const {
         const int NP = E::NP, A = E::A, W = E::W;
         const bool go = E::GAME_ID == AZ_GO;
@@ -273,6 +274,7 @@ struct OpHarvest {
                     // pipeline.py:349-354: z = reward for the samples of the last player, -reward for the others
                     const int mover = black ? 0 : 1;
                     z[start + k] = reward == 0 ? 0.0f : (mover == last_player ? (float)reward : (float)-reward);
+                    if (moves) moves[start + k] = e.m.stg_move[idx];
                 }
             }
             if (E::Wave::first()) {
@@ -489,6 +491,7 @@ struct AzHandle {
     int* d_hcounts;
     int* d_games;
     int d_games_cap;
+    int16_t* harvest_moves = nullptr;  // optional per-sample move output of azsp_harvest (azsp_harvest_moves)
 };
 
 namespace azb {  // implemented by the backend translation unit
@@ -648,6 +651,7 @@ int azsp_create(const AzspConfig* p, void** out) {
     m.stg_planes = az_new<u64>(h, G * 2 * c.stage_cap * 16 * h->W);
     m.stg_pi = az_new<float>(h, G * 2 * c.stage_cap * h->A);
     m.stg_meta = az_new<unsigned char>(h, G * 2 * c.stage_cap);
+    m.stg_move = az_new<int16_t>(h, G * 2 * c.stage_cap);
     m.stg_hdr = az_new<int>(h, G * 2 * SH_COUNT);
     m.log_pi = az_new<double>(h, G * c.log_cap * h->A);
     m.log_childN = az_new<float>(h, G * c.log_cap * h->A);
@@ -851,7 +855,7 @@ int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int3
     if (!h || !states || !pi || !z || !games || !n_samples || !n_games || cap < 1) return AZSP_EINVAL;
     if (max_games > h->d_games_cap) max_games = h->d_games_cap;
     if (azb::zero(h->d_hcounts, sizeof(int) * 4, stream)) return AZSP_EDEVICE;
-    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hcounts};
+    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hcounts, h->harvest_moves};
     int rc = az_run(h, op, stream);
     if (rc) return rc;
     int cnt[4];
@@ -860,6 +864,13 @@ int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int3
     *n_games = cnt[1];
     if (cnt[1] > 0 && azb::d2h(games, h->d_games, sizeof(int) * 16 * (size_t)cnt[1], stream)) return AZSP_EDEVICE;
     return az_check_engine_fault(h, stream);
+}
+
+int azsp_harvest_moves(void* e, int16_t* moves_dev) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    h->harvest_moves = moves_dev;
+    return AZSP_OK;
 }
 
 int azsp_counters(void* e, uint64_t* out, int32_t reset, void* stream) {

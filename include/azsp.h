@@ -184,6 +184,12 @@ int azsp_harvest(void* engine, int8_t* states_dev, float* pi_dev, float* z_dev, 
  * Philox4x32-10 keyed by (seed + rank, slot, game uid, ply, action / try): statistical tests in tests/ use this entry. */
 int azsp_rng_probe(void* engine, int32_t plies, int32_t tries, double* noise_host, double* unif_host, void* stream);
 
+/* Optional second output of azsp_harvest: moves_dev int16[sample_capacity] receives, for every harvested sample, the move
+ * that was played from its position (a flat action index, board_size^2 = pass, -1 = the mover resigned) -- what the
+ * reference's env.history / to_sgf() holds for a self-play game (envs/base.py:224-226, core/pipeline.py:276-281).
+ * NULL (the default) disables it.  The buffer must stay valid for every later azsp_harvest call. */
+int azsp_harvest_moves(void* engine, int16_t* moves_dev);
+
 /* counters_host uint64[16]: simulations, best_child calls, backup edges, leaves, duplicate leaves, terminal hits,
  * moves, games, root evaluations, nodes created, game-rounds, buffer stalls. */
 int azsp_counters(void* engine, uint64_t* counters_host, int32_t reset, void* stream);

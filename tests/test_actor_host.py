@@ -105,7 +105,8 @@ def test_actor_loop_writes_reference_csv(tmp_path):
     q, stop = queue.Queue(), threading.Event()
     th = threading.Thread(target=run_selfplay_actor_loop, args=(
         3, 0, net, "cpu", q, env, 12, 4, 19652, 1.25, 4, 10, 0.1), kwargs=dict(
-        logs_dir=str(tmp_path), stop_event=stop, num_games=8, net_dtype=torch.float32, harvest_every=20, binding=eu.hosttwin_binding()))
+        logs_dir=str(tmp_path), save_sgf_dir=str(tmp_path), save_sgf_interval=1, stop_event=stop, num_games=8, net_dtype=torch.float32,
+        harvest_every=20, binding=eu.hosttwin_binding()))
     th.start()
     first = q.get(timeout=120)
     stop.set()
@@ -116,3 +117,43 @@ def test_actor_loop_writes_reference_csv(tmp_path):
     assert ",".join(rows[0]) == want and len(rows) >= 2 and len(rows[1]) == len(rows[0])
     assert list(first[1].keys()) == want.split(",")[1:]
     assert int(rows[1][1]) > 0 and rows[1][2][0] in "BWD"
+    sgfs = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(".sgf"))  # pipeline.py:276-281: periodic SGF dumps
+    assert sgfs and sgfs[0].startswith("actor0_")
+    text = open(os.path.join(str(tmp_path), sgfs[0])).read()
+    assert text.startswith("(;\nCA[UTF-8]\nAP[AlphaZeroMini_sgfgenerator]\nRU[Chinese]") and "SZ[5]" in text and text.endswith(")")
+
+
+def check_harvested_moves(a):
+    """azsp_harvest_moves: the move list of every finished self-play game, replayed through the CPU oracle env, reproduces each
+    recorded sample state, the game length, the pass count and the result string."""
+    from oracle.envs import OracleGoEnv
+
+    got = []
+    for _ in range(300):
+        a.run_rounds(10)
+        got += a.harvest(with_moves=True)
+        if len(got) >= 14:
+            break
+    assert len(got) >= 14
+    resigned = 0
+    for seq, stats, moves in got:
+        env = OracleGoEnv(5)
+        obs = env.reset()
+        for i, t in enumerate(seq):
+            assert np.array_equal(t.state, obs)  # the sample is the observation before move i
+            if i < len(moves):
+                obs, _, done, _ = env.step(moves[i])
+        if len(moves) == len(seq) - 1:  # the last sample's mover resigned: not a history move (base.py:224-226)
+            resigned += 1
+            env.step(env.resign_move)
+        else:
+            assert len(moves) == len(seq)
+        assert env.is_game_over() and env.get_result_string() == stats["game_result"] and env.steps == stats["game_length"]
+        assert sum(1 for m in moves if m == 25) == stats["num_passes"]
+        sgf = a.game_sgf(stats, moves, date="d")
+        assert sgf.count(";B[") + sgf.count(";W[") == len(moves) and f"RE[{stats['game_result']}]" in sgf and "SZ[5]" in sgf
+    assert resigned >= 1  # the resignation path was exercised
+
+
+def test_harvested_moves_replay_to_the_samples_and_the_result():
+    check_harvested_moves(_actor(G=6, sims=12, P=4, resign_threshold=-0.3, check_resign_after_steps=4, disable_resign_ratio=0.5))

@@ -131,3 +131,22 @@ def test_gpu_production_randomness_statistics():
     import rng_checks as rc
 
     rc.check_production_rng("gpu")
+
+
+@pytest.mark.gpu
+def test_gpu_harvested_moves_replay_to_the_samples_and_the_result():
+    """azsp_harvest_moves on the device: move lists of finished self-play games replay (CPU oracle env) to every recorded sample
+    state, the game length, the pass count and the result string, resignations included."""
+    import torch
+
+    import test_actor_host as tah
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    a = SelfPlayActor(net, game="go", board_size=5, num_games=6, num_simulations=12, num_parallel=4, warm_up_steps=4, device="cuda",
+                      net_dtype=torch.float32, use_graph=False, binding=_lib.load(), resign_threshold=-0.3, check_resign_after_steps=4,
+                      disable_resign_ratio=0.5)
+    tah.check_harvested_moves(a)
