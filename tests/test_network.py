@@ -339,3 +339,33 @@ def test_gpu_gomoku_network_tiled_tower():
     p3, v3 = inf.forward_tiled(eu.tile_features(x).cuda(), 70, 13)
     assert (p3 - p2).abs().max().item() <= 1e-2 and (v3 - v2).abs().max().item() <= 2e-2
     assert (p3.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v3.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
+
+
+def test_tiled_bytes_rule_host_twin():
+    """azsp_tiled_bytes: T = max(1, 256 // S^2) boards per tile, whole tiles allocated."""
+    import engine_util as eu
+
+    b = eu.hosttwin_binding()
+    for S, C, boards in ((5, 16, 7), (9, 128, 32768), (9, 32, 10), (13, 32, 5), (17, 64, 3), (19, 256, 2)):
+        tb = max(1, 256 // (S * S))
+        assert b.dll.azsp_tiled_bytes(boards, S, C) == (boards + tb - 1) // tb * tb * S * S * C * 2
+    assert b.dll.azsp_tiled_bytes(-1, 9, 128) == -1 and b.dll.azsp_tiled_bytes(3, 9, 12) == -1
+
+
+@pytest.mark.gpu
+def test_gpu_gomoku_forward_tiled_full_batch_is_batch_independent():
+    """BASELINE C2 size (32 768 rows of 13x13 boards, 6 x 64 network): evaluations do not depend on the batch composition."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(10)
+    net = AlphaZeroNet((17, 13, 13), 169, 6, 64, 64, gomoku=True)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    rows = 32768
+    x = (torch.rand(rows, 17, 13, 13) > 0.7).float()
+    x[30000:30064] = x[:64]
+    p_all, v_all = (t.clone() for t in inf.forward_tiled(eu.tile_features(x).cuda(), rows, 13))
+    assert torch.isfinite(p_all).all() and torch.isfinite(v_all).all()
+    assert torch.equal(p_all[30000:30064], p_all[:64]) and torch.equal(v_all[30000:30064], v_all[:64])
+    p_sub, v_sub = inf.forward_tiled(eu.tile_features(x[:257]).cuda(), 257, 13)
+    assert torch.equal(p_sub, p_all[:257]) and torch.equal(v_sub, v_all[:257])
