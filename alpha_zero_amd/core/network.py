@@ -111,6 +111,22 @@ class InferenceNet(nn.Module):
             self.val_fc1_b = nn.Parameter(net.value_head[4].bias.to(dtype), requires_grad=False)
             self.val_fc2_w = nn.Parameter(net.value_head[6].weight.to(dtype), requires_grad=False)
             self.val_fc2_b = nn.Parameter(net.value_head[6].bias.to(dtype), requires_grad=False)
+            # zero-padded copies for azsp_fc_heads: weights [ceil32(out)][ceil16(in)] bf16, biases / last layer fp32
+            def _pad_w(wt):
+                out = torch.zeros((wt.shape[0] + 31) // 32 * 32, (wt.shape[1] + 15) // 16 * 16)
+                out[: wt.shape[0], : wt.shape[1]] = wt
+                return nn.Parameter(out.to(torch.bfloat16).contiguous(), requires_grad=False)
+
+            def _pad_v(v):
+                out = torch.zeros((v.numel() + 31) // 32 * 32)
+                out[: v.numel()] = v.reshape(-1)
+                return nn.Parameter(out.float().contiguous(), requires_grad=False)
+
+            self.fc_wp, self.fc_bp = _pad_w(net.policy_head[4].weight), _pad_v(net.policy_head[4].bias)
+            self.fc_w1, self.fc_b1 = _pad_w(net.value_head[4].weight), _pad_v(net.value_head[4].bias)
+            self.fc_w2, self.fc_b2 = _pad_v(net.value_head[6].weight), float(net.value_head[6].bias.item())
+            self.num_actions, self.fc_width = net.policy_head[4].weight.shape[0], net.value_head[4].weight.shape[0]
+            self.use_fused_fc = True
 
     def _fused_conv_ok(self, x):
         return (self.binding is not None and self.use_fused_conv and x.is_cuda and x.dtype == torch.bfloat16 and self.filters == 128
@@ -200,13 +216,24 @@ class InferenceNet(nn.Module):
         ck(dll.azsp_stem_tiled(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, board_size, C, self.stem_pad, 1, st),
            "azsp_stem_tiled")
         a = self._blocks_tiled(a, m, o, B, S, C, st)
+        k1, k2 = self.fc_wp.shape[1], self.fc_w1.shape[1]  # head-plane rows padded to the k-steps of azsp_fc_heads (zero padding)
         if getattr(self, "_head_key", None) != (B, feat.device):
-            self._pol = torch.empty((B, self.npol * S * S), dtype=torch.bfloat16, device=feat.device)
-            self._val = torch.empty((B, self.nval * S * S), dtype=torch.bfloat16, device=feat.device)
+            self._pol = torch.zeros((B + 1, k1), dtype=torch.bfloat16, device=feat.device)
+            self._val = torch.zeros((B + 1, k2), dtype=torch.bfloat16, device=feat.device)
+            self._pri = torch.empty((B, self.num_actions), dtype=torch.float32, device=feat.device)
+            self._v = torch.empty((B,), dtype=torch.float32, device=feat.device)
             self._head_key = (B, feat.device)
         ck(dll.azsp_head_tiled(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), self._pol.data_ptr(), self._val.data_ptr(),
-                               B, S, C, self.npol, self.nval, st), "azsp_head_tiled")
-        return self._fc_heads(self._pol, self._val, priors_out, values_out)
+                               B, S, C, self.npol, self.nval, k1, k2, st), "azsp_head_tiled")
+        fused_fc = self.use_fused_fc and (self.num_actions + 31) // 32 in (3, 6) and (self.fc_width + 31) // 32 in (2, 4)
+        if not fused_fc:
+            return self._fc_heads(self._pol[:B, : self.npol * S * S], self._val[:B, : self.nval * S * S], priors_out, values_out)
+        pri = priors_out if priors_out is not None else self._pri
+        v = values_out if values_out is not None else self._v
+        ck(dll.azsp_fc_heads(self._pol.data_ptr(), self._val.data_ptr(), self.fc_wp.data_ptr(), self.fc_bp.data_ptr(), k1 // 16, self.fc_w1.data_ptr(),
+                             self.fc_b1.data_ptr(), k2 // 16, self.fc_w2.data_ptr(), ctypes.c_float(self.fc_b2), pri.data_ptr(), v.data_ptr(), B,
+                             self.num_actions, self.fc_width, st), "azsp_fc_heads")
+        return pri, v
 
     def _fc_heads(self, pol, val, priors_out, values_out):
         """Fully connected layers of both heads (core/network.py:136-156) on the flattened head planes."""

@@ -502,11 +502,11 @@ __global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned ch
 
 // 1x1 head convolution on the tiled layout (policy / value heads, core/network.py:131-156 conv + BatchNorm folded + ReLU):
 // out[b][pl][q] = relu(sum_c w[pl][c] x[b][q][c] + bias[pl]); planes [0, npol) go to pol_out [boards][npol][81], the rest to
-// val_out [boards][NPL - npol][S*S] (bf16; plane-major per board = nn.Flatten order), any (S, C) of the tiled layout.  HBM-bound:
-// one pass over the tower output.
+// val_out [boards][NPL - npol][S*S] (bf16; plane-major per board = nn.Flatten order; rows pol_stride / val_stride elements
+// apart), any (S, C) of the tiled layout.  HBM-bound: one pass over the tower output.
 template <int NPL> __global__ void __launch_bounds__(256)
 k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, unsigned short* __restrict__ pol_out,
-             unsigned short* __restrict__ val_out, long long npos, int npol, int C, int P2, int tile_rows) {
+             unsigned short* __restrict__ val_out, long long npos, int npol, int C, int P2, int tile_rows, int pol_stride, int val_stride) {
     extern __shared__ float ws[];  // [NPL][C]
     for (int i = threadIdx.x; i < NPL * C; i += 256) ws[i] = w[i];
     __syncthreads();
@@ -532,8 +532,100 @@ k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, c
     for (int pl = 0; pl < NPL; ++pl) {
         const float v = fmaxf(acc[pl], 0.0f);
         const unsigned short h = (unsigned short)(cv_pack_bf16(v, 0.0f) & 0xffffu);
-        if (pl < npol) pol_out[((size_t)board * npol + pl) * P2 + q] = h;
-        else val_out[((size_t)board * (NPL - npol) + (pl - npol)) * P2 + q] = h;
+        if (pl < npol) pol_out[(size_t)board * pol_stride + pl * P2 + q] = h;
+        else val_out[(size_t)board * val_stride + (pl - npol) * P2 + q] = h;
+    }
+}
+
+// Fully connected layers of both heads + softmax / tanh (core/network.py:136-156) on the head planes k_head_tiled wrote:
+//     priors[b] = softmax(Wp pol[b] + bp),   value[b] = tanh(W2 relu(W1 val[b] + b1) + b2)
+// as MFMA GEMMs D[neuron][board] with one wave per 32 boards: A = zero-padded bf16 weights [NT * 32][KS * 16] streamed from L2,
+// B = the boards' head planes straight from global memory (row stride = KS * 16 elements, so every fragment is one aligned
+// 16-byte load), softmax / tanh on the accumulators (a board's 32 t neurons live in lanes l and l + 32).
+template <int NT1, int NT2> __global__ void __launch_bounds__(256)
+k_fc_heads(const unsigned short* __restrict__ pol, const unsigned short* __restrict__ val, const unsigned short* __restrict__ wp,
+           const float* __restrict__ bp, int ks1, const unsigned short* __restrict__ w1, const float* __restrict__ b1, int ks2,
+           const float* __restrict__ w2, float b2, float* __restrict__ priors, float* __restrict__ values, long long boards, int A) {
+    const int lane = threadIdx.x & 63, bl = lane & 31, hi = lane >> 5;
+    const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), b0 = task * 32;
+    if (b0 >= boards) return;
+    const long long b = b0 + bl < boards ? b0 + bl : boards - 1;  // tail lanes recompute the last board, never store
+    const bool live = b0 + bl < boards;
+    {   // ---- policy head: logits = Wp . pol + bp, softmax over the A actions
+        cv_f32x16 acc[NT1];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+        const unsigned short* xrow = pol + (size_t)b * ks1 * 16 + hi * 8;
+        const unsigned short* wrow = wp + (size_t)bl * ks1 * 16 + hi * 8;
+        for (int s = 0; s < ks1; ++s) {
+            const cv_bf16x8 bf = *(const cv_bf16x8*)(xrow + s * 16);
+#pragma unroll
+            for (int t = 0; t < NT1; ++t) {
+                const cv_bf16x8 af = *(const cv_bf16x8*)(wrow + (size_t)t * 32 * ks1 * 16 + s * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = 32 * t + 8 * (e >> 2) + 4 * hi + (e & 3);
+                const float v = n < A ? acc[t][e] + bp[n] : -__builtin_inff();
+                acc[t][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ex = __expf(acc[t][e] - mx);  // exp(-inf) = 0 for the padding neurons
+                acc[t][e] = ex;
+                sum += ex;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        if (live) {
+            float* prow = priors + (size_t)b * A;
+#pragma unroll
+            for (int t = 0; t < NT1; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = 32 * t + 8 * (e >> 2) + 4 * hi + (e & 3);
+                    if (n < A) prow[n] = acc[t][e] * inv;
+                }
+        }
+    }
+    {   // ---- value head: tanh(W2 . relu(W1 . val + b1) + b2)
+        cv_f32x16 acc[NT2];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+        const unsigned short* xrow = val + (size_t)b * ks2 * 16 + hi * 8;
+        const unsigned short* wrow = w1 + (size_t)bl * ks2 * 16 + hi * 8;
+        for (int s = 0; s < ks2; ++s) {
+            const cv_bf16x8 bf = *(const cv_bf16x8*)(xrow + s * 16);
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const cv_bf16x8 af = *(const cv_bf16x8*)(wrow + (size_t)t * 32 * ks2 * 16 + s * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+        float part = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = 32 * t + 8 * (e >> 2) + 4 * hi + (e & 3);  // padding neurons carry zero weights w1 / b1 / w2
+                part += fmaxf(acc[t][e] + b1[n], 0.0f) * w2[n];
+            }
+        part += __shfl_xor(part, 32);
+        if (live && hi == 0) values[b] = tanhf(part + b2);
     }
 }
 #endif  // __HIPCC__

@@ -156,12 +156,27 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
     return AZ_HIP(hipGetLastError());
 }
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
-                      void* st) {
+                      int pol_stride, int val_stride, void* st) {
     if (C % 8 || C > 1024 || npol + nval != 3) return 1;
     const long long npos = boards * S * S;
     hipLaunchKernelGGL(k_head_tiled<3>, dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
-                       (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S, cv_tile_boards(S) * S * S);
+                       (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S, cv_tile_boards(S) * S * S,
+                       pol_stride, val_stride);
     return AZ_HIP(hipGetLastError());
+}
+int launch_fc_heads(const FcHeadsArgs& a, void* st) {
+    const int nt1 = (a.A + 31) / 32, nt2 = (a.F + 31) / 32;
+    const unsigned grid = (unsigned)((a.boards + 127) / 128);
+#define AZ_FC_CASE(T1, T2)                                                                                                              \
+    if (nt1 == T1 && nt2 == T2) {                                                                                                       \
+        hipLaunchKernelGGL((k_fc_heads<T1, T2>), dim3(grid), dim3(256), 0, (hipStream_t)st, (const unsigned short*)a.pol,                 \
+                           (const unsigned short*)a.val, (const unsigned short*)a.wp, a.bp, a.ks1, (const unsigned short*)a.w1, a.b1, a.ks2, \
+                           a.w2, a.b2, a.priors, a.values, a.boards, a.A);                                                               \
+        return AZ_HIP(hipGetLastError());                                                                                               \
+    }
+    AZ_FC_CASE(3, 2) AZ_FC_CASE(3, 4) AZ_FC_CASE(6, 2) AZ_FC_CASE(6, 4)
+#undef AZ_FC_CASE
+    return 1;
 }
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* st) {
     if (C % 8 || S < 1) return 1;

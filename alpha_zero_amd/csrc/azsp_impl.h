@@ -515,7 +515,16 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
-                      void* stream);
+                      int pol_stride, int val_stride, void* stream);
+struct FcHeadsArgs {
+    const void *pol, *val, *wp, *w1;  // bf16: head planes (rows ks * 16 elements apart) and zero-padded weights [NT * 32][ks * 16]
+    const float *bp, *b1, *w2;        // fp32, padded to NT * 32
+    float b2;
+    float *priors, *values;
+    long long boards;
+    int ks1, ks2, A, F;
+};
+int launch_fc_heads(const FcHeadsArgs& a, void* stream);
 }  // namespace azb
 
 template <class T> static T* az_new(AzHandle* h, size_t count) {
@@ -953,10 +962,22 @@ int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, in
 }
 
 int azsp_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, int64_t boards, int32_t S, int32_t C, int32_t npol,
-                    int32_t nval, void* stream) {
+                    int32_t nval, int32_t pol_stride, int32_t val_stride, void* stream) {
     if (!x || !w || !bias || !pol || !val || boards < 0 || boards > 0x7fffffff || npol < 1 || nval < 1) return AZSP_EINVAL;
+    if (pol_stride == 0) pol_stride = npol * S * S;
+    if (val_stride == 0) val_stride = nval * S * S;
+    if (pol_stride < npol * S * S || val_stride < nval * S * S) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_head_tiled(x, w, bias, pol, val, (long long)boards, S, C, npol, nval, stream);
+    const int rc = azb::launch_head_tiled(x, w, bias, pol, val, (long long)boards, S, C, npol, nval, pol_stride, val_stride, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_fc_heads(const void* pol, const void* val, const void* wp, const float* bp, int32_t ks1, const void* w1, const float* b1, int32_t ks2,
+                  const float* w2, float b2, float* priors, float* values, int64_t boards, int32_t A, int32_t F, void* stream) {
+    if (!pol || !val || !wp || !bp || !w1 || !b1 || !w2 || !priors || !values || boards < 0 || ks1 < 1 || ks2 < 1 || A < 1 || F < 1) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    azb::FcHeadsArgs a = {pol, val, wp, w1, bp, b1, w2, b2, priors, values, (long long)boards, ks1, ks2, A, F};
+    const int rc = azb::launch_fc_heads(a, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -248,9 +248,18 @@ int azsp_stem_tiled(const void* features_tiled_dev, const void* w_packed_dev, co
                     int32_t board_size, int32_t channels, int32_t pad, int32_t relu, void* stream);
 /* Both 1x1 head convolutions (core/network.py:131-156: conv1x1 + BatchNorm + ReLU of the policy and the value head) in one
  * pass over the tiled tower output: w [policy_planes + value_planes][C] fp32 (BatchNorm folded), bias fp32;
- * pol_out [boards][policy_planes][S*S], val_out [boards][value_planes][S*S] bf16 (plane-major = nn.Flatten order). */
+ * pol_out [boards][policy_planes][S*S], val_out [boards][value_planes][S*S] bf16 (plane-major = nn.Flatten order); rows are
+ * pol_stride / val_stride elements apart (0 = dense; azsp_fc_heads wants multiples of 16 with zero padding). */
 int azsp_head_tiled(const void* x_tiled_dev, const float* w_dev, const float* bias_dev, void* pol_out_dev, void* val_out_dev, int64_t boards,
-                    int32_t board_size, int32_t channels, int32_t policy_planes, int32_t value_planes, void* stream);
+                    int32_t board_size, int32_t channels, int32_t policy_planes, int32_t value_planes, int32_t pol_stride, int32_t val_stride,
+                    void* stream);
+/* Fully connected layers of both heads with softmax / tanh (core/network.py:136-156 Linear layers, core/pipeline.py:105 softmax):
+ * priors[b] = softmax(Wp pol[b] + bp) over A actions (fp32), values[b] = tanh(W2 relu(W1 val[b] + b1) + b2).  pol / val: bf16 rows
+ * of k1_steps * 16 / k2_steps * 16 elements (zero padded), wp [ceil32(A)][k1_steps * 16] and w1 [ceil32(F)][k2_steps * 16] bf16
+ * zero padded, bp / b1 / w2 fp32 padded to ceil32.  MFMA GEMMs, one wave per 32 boards; A <= 192, F <= 128 on the device. */
+int azsp_fc_heads(const void* pol_dev, const void* val_dev, const void* wp_dev, const float* bp_dev, int32_t k1_steps, const void* w1_dev,
+                  const float* b1_dev, int32_t k2_steps, const float* w2_dev, float b2, float* priors_dev, float* values_dev, int64_t boards,
+                  int32_t num_actions, int32_t fc_width, void* stream);
 
 #ifdef __cplusplus
 }

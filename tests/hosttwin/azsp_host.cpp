@@ -3,6 +3,7 @@
 // policy: every "kernel" is a loop over games, every wave section a loop over 64 lanes.  It lets the
 // CPU-only test tier exercise tree search, rules and the C ABI logic without a GPU.  The product
 // package never loads this library (alpha_zero_amd/_lib.py only accepts libazsp.so + a HIP device).
+#include <math.h>
 #include <vector>
 #include <stdlib.h>
 
@@ -83,7 +84,7 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
     return 0;
 }
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
-                      void*) {
+                      int pol_stride, int val_stride, void*) {
     const size_t n = (size_t)boards * S * S * C;
     std::vector<unsigned short> xn(n);
     host_tile_layout((const unsigned short*)x, xn.data(), boards, S, C, 0);
@@ -94,9 +95,39 @@ int launch_head_tiled(const void* x, const float* w, const float* bias, void* po
                 float acc = bias[pl];
                 for (int ci = 0; ci < C; ++ci) acc += cv_h_bf16(xn[((size_t)b * P2 + q) * C + ci]) * w[pl * C + ci];
                 const unsigned short h = cv_h_to_bf16(acc > 0.0f ? acc : 0.0f);
-                if (pl < npol) ((unsigned short*)pol)[((size_t)b * npol + pl) * P2 + q] = h;
-                else ((unsigned short*)val)[((size_t)b * nval + (pl - npol)) * P2 + q] = h;
+                if (pl < npol) ((unsigned short*)pol)[(size_t)b * pol_stride + pl * P2 + q] = h;
+                else ((unsigned short*)val)[(size_t)b * val_stride + (pl - npol) * P2 + q] = h;
             }
+    return 0;
+}
+int launch_fc_heads(const FcHeadsArgs& a, void*) {
+    const unsigned short *pol = (const unsigned short*)a.pol, *val = (const unsigned short*)a.val, *wp = (const unsigned short*)a.wp,
+                         *w1 = (const unsigned short*)a.w1;
+    const int k1 = a.ks1 * 16, k2 = a.ks2 * 16;
+    std::vector<float> lg(a.A);
+    for (long long b = 0; b < a.boards; ++b) {
+        float mx = -1e30f;
+        for (int n = 0; n < a.A; ++n) {
+            float acc = 0.0f;
+            for (int k = 0; k < k1; ++k) acc += cv_h_bf16(wp[(size_t)n * k1 + k]) * cv_h_bf16(pol[(size_t)b * k1 + k]);
+            lg[n] = acc + a.bp[n];
+            if (lg[n] > mx) mx = lg[n];
+        }
+        float sum = 0.0f;
+        for (int n = 0; n < a.A; ++n) {
+            lg[n] = expf(lg[n] - mx);
+            sum += lg[n];
+        }
+        for (int n = 0; n < a.A; ++n) a.priors[(size_t)b * a.A + n] = lg[n] / sum;
+        float v = 0.0f;
+        for (int n = 0; n < a.F; ++n) {
+            float acc = 0.0f;
+            for (int k = 0; k < k2; ++k) acc += cv_h_bf16(w1[(size_t)n * k2 + k]) * cv_h_bf16(val[(size_t)b * k2 + k]);
+            acc += a.b1[n];
+            v += (acc > 0.0f ? acc : 0.0f) * a.w2[n];
+        }
+        a.values[b] = tanhf(v + a.b2);
+    }
     return 0;
 }
 }  // namespace azb

@@ -229,7 +229,7 @@ def _stem_head_checks(bnd, boards, C, S, device, pad=1):
     pol = torch.empty(boards, 2 * So * So, dtype=torch.bfloat16, device=device)
     val = torch.empty(boards, So * So, dtype=torch.bfloat16, device=device)
     assert bnd.dll.azsp_head_tiled(yt.data_ptr(), hw.to(device).data_ptr(), hb.to(device).data_ptr(), pol.data_ptr(), val.data_ptr(), boards, So, C,
-                                   2, 1, None) == 0
+                                   2, 1, 0, 0, None) == 0
     if device != "cpu":
         torch.cuda.synchronize()
     h = torch.relu(torch.nn.functional.conv2d(y.float().cpu(), hw.view(3, C, 1, 1), hb))
@@ -369,3 +369,57 @@ def test_gpu_gomoku_forward_tiled_full_batch_is_batch_independent():
     assert torch.equal(p_all[30000:30064], p_all[:64]) and torch.equal(v_all[30000:30064], v_all[:64])
     p_sub, v_sub = inf.forward_tiled(eu.tile_features(x[:257]).cuda(), 257, 13)
     assert torch.equal(p_sub, p_all[:257]) and torch.equal(v_sub, v_all[:257])
+
+
+def _fc_heads_check(bnd, boards, P2, A, Fw, device):
+    """azsp_fc_heads (MFMA GEMMs + softmax / tanh) vs torch on the same bf16 operands."""
+    import ctypes
+
+    g = torch.Generator().manual_seed(boards + A)
+    k1, k2 = (2 * P2 + 15) // 16 * 16, (P2 + 15) // 16 * 16
+    pol = torch.zeros(boards + 1, k1)
+    val = torch.zeros(boards + 1, k2)
+    pol[:boards, : 2 * P2] = torch.relu(torch.randn(boards, 2 * P2, generator=g))
+    val[:boards, :P2] = torch.relu(torch.randn(boards, P2, generator=g))
+    pol, val = pol.to(torch.bfloat16), val.to(torch.bfloat16)
+    wp, bp = (torch.randn(A, 2 * P2, generator=g) * 0.1).to(torch.bfloat16), torch.randn(A, generator=g) * 0.1
+    w1, b1 = (torch.randn(Fw, P2, generator=g) * 0.1).to(torch.bfloat16), torch.randn(Fw, generator=g) * 0.1
+    w2, b2 = torch.randn(Fw, generator=g) * 0.2, 0.05
+
+    def padw(w):
+        o = torch.zeros((w.shape[0] + 31) // 32 * 32, (w.shape[1] + 15) // 16 * 16, dtype=torch.bfloat16)
+        o[: w.shape[0], : w.shape[1]] = w
+        return o.to(device)
+
+    def padv(v):
+        o = torch.zeros((v.numel() + 31) // 32 * 32)
+        o[: v.numel()] = v
+        return o.to(device)
+
+    pri = torch.empty(boards, A, device=device)
+    v = torch.empty(boards, device=device)
+    keep = (pol.to(device), val.to(device), padw(wp), padv(bp), padw(w1), padv(b1), padv(w2))
+    rc = bnd.dll.azsp_fc_heads(keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), k1 // 16, keep[4].data_ptr(),
+                               keep[5].data_ptr(), k2 // 16, keep[6].data_ptr(), ctypes.c_float(b2), pri.data_ptr(), v.data_ptr(), boards, A, Fw, None)
+    assert rc == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    logits = pol[:boards, : 2 * P2].float() @ wp.float().T + bp
+    want_p = torch.softmax(logits, -1)
+    want_v = torch.tanh(torch.relu(val[:boards, :P2].float() @ w1.float().T + b1) @ w2 + b2)
+    assert (pri.cpu() - want_p).abs().max().item() <= 2e-5 and (v.cpu() - want_v).abs().max().item() <= 2e-5
+    assert torch.allclose(pri.sum(1).cpu(), torch.ones(boards), atol=1e-5)
+
+
+def test_fc_heads_abi_host_twin():
+    import engine_util as eu
+
+    _fc_heads_check(eu.hosttwin_binding(), 5, 25, 26, 16, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards,P2,A,Fw", [(1, 81, 82, 128), (33, 81, 82, 64), (1000, 81, 82, 128), (70, 289, 169, 64)])
+def test_gpu_fc_heads_match_torch(boards, P2, A, Fw):
+    from alpha_zero_amd import _lib
+
+    _fc_heads_check(_lib.load(), boards, P2, A, Fw, "cuda")
