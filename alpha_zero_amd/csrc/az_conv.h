@@ -25,8 +25,6 @@
 // boards per tile of the tiled activation layout: as many whole boards as fit 256 MFMA columns (3 at 9x9, 1 from 13x13 up)
 static inline int cv_tile_boards(int S) { return 256 / (S * S) > 0 ? 256 / (S * S) : 1; }
 #define CV_P2 (CV_S * CV_S)                   // 81
-#define CV_PS (CV_S + 2)                      // 11
-#define CV_PP (CV_PS * CV_PS)                 // 121
 #define CV_ROWB (CV_C * 2)                    // 256 bytes per position / per cout row
 #define CV_NPOS (CV_TB * CV_P2)               // 243
 #define CV_ZROW CV_NPOS                        // LDS row 243 is all zeros: what an off-board tap reads

@@ -27,10 +27,7 @@
 #define C6_CELL0 19                         // cell of (0, 0); (-1, -1) is cell 0
 #define C6_CELLS 352                        // 19 + 17 * 18 + 19 = 344, rounded up to a multiple of 16 (strip = multiple of 256 B)
 #define C6_LBLK (C6_CELLS * 16)             // 5,632 B per chunk strip
-#define C6_LBUF (C6_NCH * C6_LBLK)          // 45,056 B per buffer
 #define C6_NCT 20                           // column tiles of 16 positions
-#define C6_NSTEP 18                         // 9 taps x 2 halves of the 64 input channels
-#define C6_NPIECE 12                        // DMA pieces per wave per tile: 6 per strip, 2 strips per wave
 
 typedef __attribute__((ext_vector_type(4))) float c6_f32x4;
 
