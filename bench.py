@@ -1,6 +1,11 @@
 """bench.py -- self-play moves/sec of the batched engine (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: WORLD_SIZE must then equal N) or, when WORLD_SIZE is not set, bench.py re-executes itself under
+torch.distributed.run with N ranks -- the fan-out of training_go.py:317-347 (one actor per process), one process per GPU here.
+It exits non-zero when fewer than N devices are visible: a 1-GPU number is never reported as an N-GPU one.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 9x9 Go, G = 4096
 concurrent games per GPU, 200 sims/move with the reference budget semantics (root.N >= sims + P,
@@ -8,7 +13,13 @@ inherited visits count: mcts_v2.py:568), num_parallel P = 8, 10-block x 128-filt
 (random Kaiming init, torch.manual_seed(1)), Dirichlet root noise, sub-tree reuse, resign disabled.
 One "step" = one engine round over all games: expand/backup of the previous G*P leaf batch, end-of-move
 work, selection of the next P leaves per game, observation planes, and the network forward on G*P rows.
-All inputs live in HBM; nothing crosses PCIe inside the timed region except the periodic harvest counts.
+All inputs live in HBM; nothing crosses PCIe inside the timed region except the harvests of finished games.
+
+Before --warmup / --steps apply, an untimed, argument-independent PRE-ROLL brings the engine to its steady state: slots start
+from staggered random openings, then rounds run until every slot has committed >= 2 searched moves and >= 150 rounds have passed
+(a fresh tree needs 26 rounds to its first move; afterwards inherited sub-trees of different sizes de-phase the slots), so that
+move completions are spread evenly over rounds and a 20-round window measures the same moves/s as a 300-round one.  The timed
+region always contains at least one harvest + gather (every min(--harvest-every, --steps) rounds).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -53,7 +64,7 @@ def usable_host_cores():
     return n
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -68,25 +79,86 @@ def main():
     ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
+    ap.add_argument("--preroll-rounds", type=int, default=150, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
+    ap.add_argument("--preroll-moves", type=int, default=2, help="every slot must have committed this many searched moves before timing")
     ap.add_argument("--harvest-every", type=int, default=50)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=60.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = all usable host cores (cgroup quota aware)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-evaluator companion measurement (fp32_moves_per_s)")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable torch.backends.cudnn.benchmark (MIOpen find) for the convs")
     ap.add_argument("--split-round", action="store_true", help="diagnostic: launch expand/backup and select as two kernels and time each")
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous the ranks (RCCL on GPUs, gloo without a device), print the world size that joined and exit")
+    return ap.parse_args(argv)
 
+
+def self_launch_cmd(args, argv):
+    """The command bench.py re-executes itself with when --gpus N > 1 and no launcher started it (WORLD_SIZE unset): one rank per
+    GPU under torch.distributed.run on this node (training_go.py:317-347 starts one actor process per slot the same way)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_check(world, rank, local_rank):
+    """--launch-check: ranks rendezvous, count themselves with one all_reduce and rank 0 prints what joined."""
+    import torch.distributed as dist
+
+    if world > 1:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            one = torch.ones(1, device="cuda")
+        else:
+            dist.init_process_group("gloo")
+            one = torch.ones(1)
+        dist.all_reduce(one)
+        joined, backend = int(one.item()), dist.get_backend()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        joined, backend = 1, None
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": joined, "world_size_env": world, "backend": backend}), flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.launch_check or torch.cuda.is_available():
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible; refusing to report fewer ranks than asked")
+        import subprocess
+
+        raise SystemExit(subprocess.call(self_launch_cmd(args, argv)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher must start exactly --gpus ranks")
+    if args.launch_check:
+        return launch_check(world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} has no HIP device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
+        rccl_ranks = dist.get_world_size()
 
     from alpha_zero_amd.core.gather import gather_samples
     from alpha_zero_amd.core.network import AlphaZeroNet
@@ -96,22 +168,8 @@ def main():
     A = n * n + (1 if game == "go" else 0)
     torch.manual_seed(1)
     net = AlphaZeroNet((17, n, n), A, args.blocks, args.filters, args.filters, gomoku=(game != "go"))
-    dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.net_dtype]
+    DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
     torch.backends.cudnn.benchmark = not args.no_miopen_find
-    actor = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
-                          warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=dt,
-                          use_graph=not args.no_graph)
-    eng = actor.engine
-
-    if args.stagger > 0:  # mixed game phases from the first timed round (documented in DESIGN.md "Measurement")
-        rng = np.random.Generator(np.random.PCG64(1234 + rank))
-        plies = rng.integers(0, args.stagger + 1, size=args.games)
-        out = eng.env_step(None)
-        for t in range(int(plies.max())):
-            legal = out["legal"][:, : n * n].astype(bool)
-            r = rng.random(legal.shape) * legal
-            acts = np.where((plies > t) & legal.any(axis=1) & (out["scalars"][:, 5] == 0), r.argmax(axis=1), -2).astype(np.int32)
-            out = eng.env_step(acts)
 
     def barrier():
         if world > 1:
@@ -120,29 +178,78 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def harvest_and_gather():
-        st, pi, z, games = actor.harvest_tensors()
+    def make_actor(dtype_name):
+        """Engine + evaluator in the steady state: staggered openings, then the argument-independent pre-roll."""
+        act = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
+                            warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=DT[dtype_name],
+                            use_graph=not args.no_graph)
+        e = act.engine
+        if args.stagger > 0:  # mixed game phases from the first round (documented in DESIGN.md "Measurement")
+            rng = np.random.Generator(np.random.PCG64(1234 + rank))
+            plies = rng.integers(0, args.stagger + 1, size=args.games)
+            out = e.env_step(None)
+            for t in range(int(plies.max())):
+                legal = out["legal"][:, : n * n].astype(bool)
+                r = rng.random(legal.shape) * legal
+                acts = np.where((plies > t) & legal.any(axis=1) & (out["scalars"][:, 5] == 0), r.argmax(axis=1), -2).astype(np.int32)
+                out = e.env_step(acts)
+        return act
+
+    def harvest_and_gather(act):
+        st, pi, z, games = act.harvest_tensors()
         res = gather_samples(st, pi, z, games, dst=0)
         return 0 if res is None else int(res[0].shape[0])
 
-    for i in range(args.warmup):
-        actor.run_round()
-        if (i + 1) % args.harvest_every == 0:
-            harvest_and_gather()
-    barrier()
-    harvest_and_gather()
-    actor.counters(reset=True)
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
-    samples_at_root = 0
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        actor.run_round(evs[i])
-        if (i + 1) % args.harvest_every == 0:
-            samples_at_root += harvest_and_gather()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    cnt = actor.counters()
+    def preroll(act, min_rounds=None):
+        """Untimed and independent of --steps / --warmup: rounds until every slot has committed >= preroll_moves searched moves
+        (ply advanced, or a game finished) and >= preroll_rounds rounds have passed.  Returns the rounds it took."""
+        e = act.engine
+        st0, _ = e.status()
+        ply0, done0 = st0[:, 1].copy(), st0[:, 5].copy()
+        min_rounds = args.preroll_rounds if min_rounds is None else min_rounds
+        rounds, cap = 0, max(min_rounds, 40 * (args.sims // max(1, args.parallel) + 2))
+        while rounds < cap:
+            act.run_round()
+            rounds += 1
+            if rounds % args.harvest_every == 0:
+                harvest_and_gather(act)
+            if rounds >= min_rounds and rounds % 10 == 0:
+                st, _ = e.status()
+                moved = np.where(st[:, 5] > done0, args.preroll_moves, st[:, 1] - ply0)
+                ok = torch.tensor([1.0 if moved.min() >= args.preroll_moves else 0.0], device=dev)
+                if world > 1:  # all ranks leave the pre-roll together (their harvest / gather calls must stay paired)
+                    import torch.distributed as dist
+
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() > 0:
+                    break
+        return rounds
+
+    def timed(act, warmup, steps):
+        """--warmup untimed rounds, then exactly --steps rounds between barrier + synchronize on both sides."""
+        h_every = max(1, min(args.harvest_every, steps))  # the timed region always pays for >= 1 harvest + gather
+        for i in range(warmup):
+            act.run_round()
+            if (i + 1) % h_every == 0:
+                harvest_and_gather(act)
+        barrier()
+        harvest_and_gather(act)
+        act.counters(reset=True)
+        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)]
+        gathered = 0
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            act.run_round(evs[i])
+            if (i + 1) % h_every == 0:
+                gathered += harvest_and_gather(act)
+        barrier()
+        return time.perf_counter() - t0, act.counters(), evs, gathered
+
+    actor = make_actor(args.net_dtype)
+    eng = actor.engine
+    preroll_rounds = preroll(actor)
+    elapsed, cnt, evs, samples_at_root = timed(actor, args.warmup, args.steps)
     bk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # expand/backup + end-of-move kernels
     k_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))   # select kernel (the dominant hand-written kernel)
     nn_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
@@ -157,6 +264,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
     total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
+    if total_moves <= 0:
+        raise SystemExit("bench.py: no move was committed inside the timed region -- the pre-roll did not reach the steady state")
 
     # ---- dominant kernel (the tower convolution): average launch duration, HIP events on the launch stream -----------
     conv = None
@@ -267,6 +376,19 @@ def main():
                         "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4)}
         else:
             roofline = engine_roof
+        fp32 = None
+        if world == 1 and args.net_dtype != "fp32" and not args.no_fp32:
+            # the reference's evaluator precision (pipeline.py:91-123 runs the network in fp32): same engine, same workload, fp32
+            # network (library convolutions + fused epilogue kernel), shorter pre-roll and window -- a companion number, not `value`
+            del evs
+            a32 = make_actor("fp32")
+            pre32 = preroll(a32, min_rounds=60)
+            el32, c32, ev32, _ = timed(a32, 5, 40)
+            fp32 = {"moves_per_s": round(c32["moves"] / el32, 2), "sims_per_sec": round(c32["sims"] / el32, 1), "ms_per_step": round(el32 / 40 * 1e3, 3),
+                    "sims_per_move": round(c32["sims"] / max(1, c32["moves"]), 2), "steps": 40, "warmup": 5, "preroll_rounds": pre32,
+                    "evaluator": "fp32, library convolutions + fused epilogue kernel"}
+            del a32, ev32
+            torch.cuda.empty_cache()
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline
@@ -276,10 +398,20 @@ def main():
                                filters=args.filters, stagger=args.stagger)
             cpu["value"] = round(cpu["value"], 3)
             cpu["per_core"] = round(cpu["per_core"], 4)
+            # port vs the imported reference on identical seeded moves, measured in the development container by
+            # tools/calibrate_baseline.py (the reference cannot travel to the GPU box): ratio = port moves/s / reference moves/s
+            cal = os.path.join(ROOT, "tests", "golden", "cpu_baseline_calibration.json")
+            if os.path.exists(cal):
+                cj = json.load(open(cal))
+                key = f"{game}{n}_p{args.parallel}_s{args.sims}_{args.blocks}x{args.filters}"
+                ratio = cj.get("ratios", {}).get(key, {}).get("ratio")
+                cpu["calibration_ratio"] = ratio
+                cpu["reference_equivalent_value"] = round(cpu["value"] / ratio, 3) if ratio else None
+                cpu["calibration"] = "port / reference moves/s on the same seeded moves, tools/calibrate_baseline.py, key " + key
         line = {
             "metric": "self-play moves/sec (whole node), 9x9 Go @ 200 sims/move" if (game == "go" and n == 9 and args.sims == 200)
             else f"self-play moves/sec (whole node), {n}x{n} {game} @ {args.sims} sims/move",
-            "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.net_dtype, "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
@@ -291,7 +423,10 @@ def main():
             "sims_per_move": round(total_sims / max(1.0, total_moves), 2),
             "select_nodes_per_sim": round(cnt["node_visits"] / max(1, cnt["sims"]), 3),
             "backup_nodes_per_sim": round(cnt["backup_edges"] / max(1, cnt["sims"]), 3),
-            "samples_gathered": samples_at_root, "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
+            "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds,
+            "fp32_moves_per_s": fp32["moves_per_s"] if fp32 else None, "fp32_companion": fp32,
+            "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,
+            "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -1,0 +1,57 @@
+"""bench.py --gpus N: rank fan-out (reference: training_go.py:317-347 starts one actor process per slot).
+CPU tier: --launch-check rendezvouses the ranks over gloo and reports what joined; the measurement itself needs a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_gpus_n_self_launches_n_ranks():
+    r = _run(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size_env"] == 2 and line["backend"] == "gloo"
+
+
+def test_gpus_n_without_n_devices_fails_loudly():
+    """On a box with fewer than N devices `--gpus N` must not print a number (here: 0 devices)."""
+    r = _run(["--gpus", "2"])
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout) and "{" not in r.stdout
+
+
+def test_world_size_must_equal_gpus():
+    r = _run(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_self_launch_command_shape():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    a = bench.parse_args(["--gpus", "4", "--steps", "7"])
+    cmd = bench.self_launch_cmd(a, ["--gpus", "4", "--steps", "7"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+
+
+def test_broadcast_weights_two_ranks_gloo(tmp_path):
+    script = os.path.join(ROOT, "tests", "bcast_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
+    assert all(p.wait(timeout=300) == 0 for p in procs)
+    w0, w1 = (np.load(os.path.join(str(tmp_path), f"w{r}.npz")) for r in range(2))
+    assert set(w0.files) == set(w1.files) and len(w0.files) > 20
+    for k in w0.files:
+        if np.issubdtype(w0[k].dtype, np.floating):
+            assert np.array_equal(w0[k], w1[k]), k
