@@ -199,10 +199,18 @@ class Engine:
         m = np.ascontiguousarray(moves, dtype=np.int32).reshape(self.G)
         self._ck(self.b.dll.azsp_commit_move(self.h, m.ctypes.data, self._stream()), "azsp_commit_move")
 
+    def set_actor_state(self, resign_threshold, training_steps):
+        """Values every game that STARTS from now on reads (pipeline.py:232-246: the reference actor re-reads the shared resign
+        threshold and the checkpoint's training_steps before each game); games in progress keep theirs."""
+        self._ck(self.b.dll.azsp_set_actor_state(self.h, C.c_double(float(resign_threshold)), int(training_steps)), "azsp_set_actor_state")
+
     # -- samples ----------------------------------------------------------------------------------------
     def harvest(self, sample_capacity=None, max_games=None, with_moves=False):
         """Returns (states int8[n,17,N,N], pi float32[n,A], z float32[n], games int32[k,16]) -- device tensors + host meta;
-        with_moves=True appends moves int16[n] (the move played from every sample's position, -1 = resigned)."""
+        with_moves=True appends moves int16[n] (the move played from every sample's position, -1 = resigned).
+        The per-game extras of the same call (azsp_harvest_extra) are left in `self.last_extra` int32[k,4].
+        ALIASING: the device tensors are views of buffers this engine re-uses -- the NEXT harvest() overwrites them in place.
+        Consume (or .clone()) them before harvesting again; SelfPlayActor.harvest_tensors(clone=True) does the latter."""
         cap = sample_capacity or max(4 * self.G, 2 * self.geo.stage_capacity)
         mg = max_games or 2 * self.G
         if self._harvest_bufs is None or self._harvest_bufs[0].shape[0] < cap:
@@ -213,10 +221,14 @@ class Engine:
         st, pi, z, mvbuf = self._harvest_bufs
         self._ck(self.b.dll.azsp_harvest_moves(self.h, mvbuf.data_ptr() if with_moves else None), "azsp_harvest_moves")
         games = np.zeros((mg, 16), dtype=np.int32)
+        extra = np.zeros((mg, 4), dtype=np.int32)
+        self._ck(self.b.dll.azsp_harvest_extra(self.h, extra.ctypes.data), "azsp_harvest_extra")
         ns, ng = C.c_int32(0), C.c_int32(0)
         self._ck(self.b.dll.azsp_harvest(self.h, st.data_ptr(), pi.data_ptr(), z.data_ptr(), st.shape[0], games.ctypes.data, mg,
                                          C.byref(ns), C.byref(ng), self._stream()), "azsp_harvest")
         n, k = ns.value, ng.value
+        self._ck(self.b.dll.azsp_harvest_extra(self.h, None), "azsp_harvest_extra")  # the host array dies with this call
+        self.last_extra = extra[:k]
         if with_moves:
             return st[:n], pi[:n], z[:n], games[:k], mvbuf[:n]
         return st[:n], pi[:n], z[:n], games[:k]

@@ -115,7 +115,8 @@ class ResignController:
         self.init, self.no_resign_games, self.reset_fp_interval = init_resign_threshold, no_resign_games, reset_fp_interval
         self.step = int(games_per_ckpt * 0.5 * disable_resign_ratio * 0.5)
         self.target_fp_rate = target_fp_rate
-        self.threshold = init_resign_threshold
+        # pipeline.py:449-459: -1 while resignation is permanently off (init <= -1) or during the no-resign warm-up games
+        self.threshold = -1 if (init_resign_threshold <= -1 or no_resign_games > 0) else init_resign_threshold
         self.resign_count = self.last_resign_count = self.could_won_count = 0
 
     def on_game(self, stats, num_games_added):

@@ -26,7 +26,10 @@ class Node:
     def __init__(self, searcher, board, to_play, steps):
         self._searcher, self._board, self.to_play, self._steps = searcher, board, to_play, steps
         self._alive = True
-        weakref.finalize(self, _release, searcher)
+        # Returns the engine to the pool when a LIVE handle is dropped (the caller abandoned the tree).  A handle that is handed
+        # back to the next search passes its engine on to the new handle: its finalizer is detached there, otherwise dropping the
+        # old handle would put an engine that is still in use into the pool (and a second search would overwrite the live tree).
+        self._fin = weakref.finalize(self, _release, searcher)
 
     @property
     def is_expanded(self):
@@ -34,7 +37,9 @@ class Node:
 
 
 def _release(searcher):
-    _POOL.setdefault(searcher.key, []).append(searcher)
+    idle = _POOL.setdefault(searcher.key, [])
+    if not any(x is searcher for x in idle):  # never pool the same engine twice
+        idle.append(searcher)
 
 
 class _Searcher:
@@ -88,6 +93,7 @@ def _search(env, eval_func, root_node, c_puct_base, c_puct_init, num_simulations
             raise ValueError("`root_node` does not belong to this position")
         s = root_node._searcher
         root_node._alive = False
+        root_node._fin.detach()  # the engine moves on with this search; only the NEXT handle (or game end) releases it
     else:
         s = _get_searcher(env, num_simulations, num_parallel, c_puct_base, c_puct_init, root_noise)
         _load_position(s, env)

@@ -55,6 +55,44 @@ class AlphaZeroNet(nn.Module):
         return self.policy_head(f), self.value_head(f)
 
 
+@torch.no_grad()
+def widen_network(net: "AlphaZeroNet", num_filters: int) -> "AlphaZeroNet":
+    """Function-preserving copy of `net` with `num_filters` >= its own filter count: the extra channels have zero convolution
+    weights and identity BatchNorm (mean 0, var 1, gamma 1, beta 0), so they carry exact zeros through every ReLU and contribute
+    nothing to the heads.  Lets a trained network of an unsupported width (e.g. the reference's shipped 10 x 40 Gomoku checkpoint)
+    run on the hand-written evaluator kernels of the next supported width (64)."""
+    c0 = net.conv_block[0].out_channels
+    if num_filters < c0:
+        raise ValueError(f"cannot narrow {c0} filters to {num_filters}")
+    cin, h, w = net.conv_block[0].in_channels, None, None
+    A, fc = net.policy_head[4].out_features, net.value_head[4].out_features
+    oh_ow = net.value_head[4].in_features
+    side = int(round(oh_ow ** 0.5))
+    pad = net.conv_block[0].padding[0]
+    n = side - 2 * pad + 2
+    out = AlphaZeroNet((cin, n, n), A, len(net.res_blocks), num_filters, fc, gomoku=(pad == 3)).eval()
+
+    def conv(dst, src, pad_in=True):
+        dst.weight.zero_()
+        dst.weight[: src.weight.shape[0], : src.weight.shape[1]] = src.weight
+
+    def bn(dst, src):
+        k = src.num_features
+        dst.weight.fill_(1.0), dst.bias.zero_(), dst.running_mean.zero_(), dst.running_var.fill_(1.0)
+        dst.weight[:k], dst.bias[:k], dst.running_mean[:k], dst.running_var[:k] = src.weight, src.bias, src.running_mean, src.running_var
+        dst.eps, dst.num_batches_tracked = src.eps, src.num_batches_tracked.clone()
+
+    conv(out.conv_block[0], net.conv_block[0]), bn(out.conv_block[1], net.conv_block[1])
+    for bo, bi in zip(out.res_blocks, net.res_blocks):
+        conv(bo.conv_block1[0], bi.conv_block1[0]), bn(bo.conv_block1[1], bi.conv_block1[1])
+        conv(bo.conv_block2[0], bi.conv_block2[0]), bn(bo.conv_block2[1], bi.conv_block2[1])
+    conv(out.policy_head[0], net.policy_head[0]), bn(out.policy_head[1], net.policy_head[1])
+    conv(out.value_head[0], net.value_head[0]), bn(out.value_head[1], net.value_head[1])
+    for i, head in ((4, "policy_head"), (4, "value_head"), (6, "value_head")):
+        getattr(out, head)[i].load_state_dict(getattr(net, head)[i].state_dict())
+    return out
+
+
 def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     """Eval-mode BN(conv(x)) == conv'(x) + b'."""
     s = bn.weight / torch.sqrt(bn.running_var + bn.eps)

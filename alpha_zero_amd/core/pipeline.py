@@ -60,7 +60,7 @@ class SelfPlayActor:
     def __init__(self, network: AlphaZeroNet, *, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8,
                  c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
                  resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.bfloat16,
-                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None):
+                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None):
         """tiled_features: None = use the evaluator's tiled input layout whenever the network / board shape has the hand-written
         stem / tower / head kernels (9x9, 128 filters, bf16 on the GPU); False = always NCHW planes + library stem."""
         from .. import _lib
@@ -79,10 +79,16 @@ class SelfPlayActor:
             disable_resign_ratio=disable_resign_ratio, root_noise=root_noise, deterministic=deterministic,
             feature_dtype=_abi.FEAT_BF16_TILED if self.tiled_features else _FEAT_OF[net_dtype], training_steps=training_steps, seed=seed, rank=rank,
             device_index=self.device.index or 0)
+        for k, v in (engine_kw or {}).items():  # further EngineConfig fields (move logs, max_plies, ...: tests and diagnostics)
+            if not hasattr(self.cfg, k):
+                raise TypeError(f"unknown engine option {k}")
+            setattr(self.cfg, k, v)
         self.engine = Engine(self.binding, self.cfg, device=self.device)
         self.engine.reset_games()
         self._graph = None
         self.rounds = 0
+        self.straddled_games = 0  # harvested games that were in progress across a weight hot-swap (see harvest())
+        self.drop_straddling_games = False
         self.set_network(network, training_steps)
 
     # -- weights ---------------------------------------------------------------------------------------
@@ -90,7 +96,14 @@ class SelfPlayActor:
         """Checkpoint hot-swap (pipeline.py:232-239): new weights take effect at the next round."""
         self.infer = InferenceNet(network, dtype=self.net_dtype, binding=self.binding if self.device.type == "cuda" else None).to(self.device)
         self.training_steps = training_steps
+        self.engine.set_actor_state(self.resign_threshold, training_steps)  # games that start from now on carry this tag
         self._graph = None
+
+    def set_resign_threshold(self, resign_threshold):
+        """var_resign_threshold as the reference actor reads it before EVERY game (pipeline.py:241-242): games that start after this
+        call use (and report) the new value, games in progress keep theirs.  <= -1 disables resignation (pipeline.py:449-459)."""
+        self.resign_threshold = float(resign_threshold)
+        self.engine.set_actor_state(self.resign_threshold, self.training_steps)
 
     def _forward(self):
         e = self.engine
@@ -140,8 +153,12 @@ class SelfPlayActor:
             self.run_round()
 
     # -- output ----------------------------------------------------------------------------------------
-    def harvest_tensors(self):
-        return self.engine.harvest()
+    def harvest_tensors(self, clone=False):
+        """(states, pi, z, games) of the finished games as device tensors.  The tensors are views of buffers the engine re-uses: the
+        next harvest overwrites them in place.  clone=True returns private copies (for consumers that keep them across harvests,
+        e.g. an asynchronous learner or a replay insert on another stream)."""
+        st, pi, z, games = self.engine.harvest()
+        return (st.clone(), pi.clone(), z.clone(), games) if clone else (st, pi, z, games)
 
     def harvest(self, with_moves=False):
         """Finished games as the reference actor emits them: [(game_seq: list[Transition], stats: dict)]
@@ -150,17 +167,27 @@ class SelfPlayActor:
         a final resignation is not a history move, base.py:224-226) -- what to_sgf() needs (pipeline.py:276-281)."""
         got = self.engine.harvest(with_moves=with_moves)
         states, pi, z, games = got[:4]
+        extra = self.engine.last_extra
         if len(games) == 0:
             return []
         states, pi, z = states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
         moves = got[4].cpu().numpy() if with_moves else None
         out = []
-        for row in games:
+        for row, ex in zip(games, extra):
             s0, ln = int(row[0]), int(row[1])
+            if int(ex[3]):
+                # The game was in progress across a weight hot-swap -- impossible in the reference, whose actor only reloads between
+                # games (pipeline.py:232-239).  It keeps the tag of the weights that STARTED it (pipeline.py:237 -> :271) and is
+                # counted; drop_straddling_games=True discards it instead.
+                self.straddled_games += 1
+                if self.drop_straddling_games:
+                    continue
             pis = pi[s0:s0 + ln].astype(np.float64) if self.game == "go" else pi[s0:s0 + ln]
             seq = [Transition(state=states[s0 + i].copy(), pi_prob=pis[i].copy(), value=float(z[s0 + i])) for i in range(ln)]
-            stats = game_stats_from_row(row, self.game, self.komi, self.resign_threshold)
-            stats["training_steps"] = self.training_steps  # tag of the weights in use (pipeline.py:271, :492)
+            # the threshold this very game was played with (pipeline.py:241-242, :379), exact double
+            thr = float(np.array([ex[1], ex[2]], dtype=np.int32).view(np.float64)[0])
+            stats = game_stats_from_row(row, self.game, self.komi, thr)
+            stats["training_steps"] = int(row[12])  # weights in use when the game started (pipeline.py:237, :271, :492)
             out.append((seq, stats, [int(m) for m in moves[s0:s0 + ln] if m >= 0]) if with_moves else (seq, stats))
         return out
 
@@ -207,8 +234,10 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
         writer = CsvWriter(os.path.join(logs_dir, f"actor{rank}.csv"))
     last_ckpt, t_last, played_games = None, time.time(), 0
     while stop_event is None or not stop_event.is_set():
-        if ckpt_event is not None and ckpt_event.is_set():
+        if ckpt_event is not None and ckpt_event.is_set():  # the learner is writing a checkpoint (pipeline.py:228-230)
             continue
+        if var_resign_threshold is not None and env.has_resign_move and var_resign_threshold.value != actor.resign_threshold:
+            actor.set_resign_threshold(var_resign_threshold.value)  # pipeline.py:241-242: read before every game
         if var_ckpt is not None:
             new_ckpt = var_ckpt.value.decode("utf-8") if isinstance(var_ckpt.value, bytes) else str(var_ckpt.value)
             if new_ckpt != "" and new_ckpt != last_ckpt and os.path.exists(new_ckpt):  # pipeline.py:232-239
@@ -220,6 +249,10 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
         want_sgf = bool(save_sgf_dir) and save_sgf_interval > 0 and os.path.isdir(save_sgf_dir)
         finished = actor.harvest(with_moves=want_sgf)
         now = time.time()
+        if stop_event is not None and stop_event.is_set():
+            break
+        if ckpt_event is not None and ckpt_event.is_set():
+            continue  # pipeline.py:264-267: games that end while a checkpoint is being created are discarded
         if want_sgf:  # every save_sgf_interval-th finished game is dumped like the reference does (pipeline.py:276-281)
             from ..utils.sgf import get_time_stamp as _ts
 

@@ -33,6 +33,12 @@ enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
 enum { AZC_SIMS = 0, AZC_NODE_VISITS, AZC_BACKUP_EDGES, AZC_LEAVES, AZC_DUP_LEAVES, AZC_TERMINAL_HITS, AZC_MOVES,
        AZC_GAMES, AZC_ROOT_EVALS, AZC_NODES_CREATED, AZC_ROUNDS, AZC_STALLS, AZC_COUNT = 16 };
 
+AZ_HD u64 az_bits_f64(double v) {
+    u64 b;
+    __builtin_memcpy(&b, &v, sizeof b);
+    return b;
+}
+
 struct AzCfg {
     int game, n, G, P, sims, budget, parallel_mode, max_nodes;
     int root_noise, deterministic, reuse_tree, warm_up_steps;
@@ -71,7 +77,8 @@ struct AzMem {
 };
 
 enum { SH_STATE = 0, SH_LEN, SH_WINNER, SH_AREA_B, SH_AREA_W, SH_PASSES, SH_RESIGNED, SH_RESIGN_DISABLED, SH_MARKED,
-       SH_COULD_WON, SH_MARKED_PLAYER, SH_UID, SH_TRAINING_STEPS, SH_REWARD, SH_LAST_PLAYER, SH_COUNT = 16 };
+       SH_COULD_WON, SH_MARKED_PLAYER, SH_UID, SH_TRAINING_STEPS, SH_REWARD, SH_LAST_PLAYER,
+       SH_THR_LO, SH_THR_HI, SH_TS_END, SH_COUNT = 20 };  // THR_*: the game's own resign threshold (double bits); TS_END: weights tag at its end
 
 template <int W> struct GameRec {
     EnvState<W> env;     // the real position (== the root node's position)
@@ -81,6 +88,10 @@ template <int W> struct GameRec {
     int root_N;
     int root, n_free, status, root_fresh, root_noisy, ply, n_leaves, root_eval_pending;
     int uid, num_passes, marked_player, resign_disabled, cur_buf, out_move, noise_pending, noise_ready, games_done, warm_override;
+    // per-game actor state, read when the game starts like the reference actor does before every game (pipeline.py:232-246):
+    double resign_thr;   // var_resign_threshold.value at game start (<= -1: no resignation in this game)
+    int train_steps;     // training_steps of the weights in use at game start (pipeline.py:237, :271)
+    int pad0;
     int16_t leaf_node[AZ_MAXP];
     uint8_t leaf_depth[AZ_MAXP];
 };
@@ -299,9 +310,11 @@ template <class Wv, int N, int GAME> struct Engine {
             gr.n_leaves = 0;
             gr.root_eval_pending = 0;
             gr.noise_pending = 0;
+            gr.resign_thr = c.has_resign ? c.resign_threshold : -1.0;  // pipeline.py:241-242: re-read before every game
+            gr.train_steps = c.training_steps;
             int rd = 1;  // pipeline.py:244-246
             if (c.force_resign_disabled >= 0) rd = c.force_resign_disabled;
-            else if (c.has_resign && c.resign_threshold > -1.0) {
+            else if (c.has_resign && gr.resign_thr > -1.0) {
                 u32 r[4];
                 Philox::gen(c.seed + (u64)c.rank, (u32)g, (u32)gr.uid, 0u, 0x5E51u, r);
                 rd = Philox::u01(r[0], r[1]) > (double)c.disable_resign_ratio ? 0 : 1;
@@ -1067,7 +1080,11 @@ template <class Wv, int N, int GAME> struct Engine {
             sh[SH_COULD_WON] = (marked && fin.winner == gr.marked_player) ? 1 : 0;
             sh[SH_MARKED_PLAYER] = gr.marked_player;
             sh[SH_UID] = gr.uid;
-            sh[SH_TRAINING_STEPS] = c.training_steps;
+            sh[SH_TRAINING_STEPS] = gr.train_steps;  // the weights that STARTED the game (pipeline.py:237 -> :271)
+            sh[SH_TS_END] = c.training_steps;        // != the above: the game straddled a weight hot-swap
+            const u64 tb = az_bits_f64(gr.resign_thr);
+            sh[SH_THR_LO] = (int)(unsigned)(tb & 0xffffffffull);
+            sh[SH_THR_HI] = (int)(unsigned)(tb >> 32);
             sh[SH_REWARD] = fin.reward;  // reward of `last_player` (pipeline.py:349-354 turns it into z at harvest)
             sh[SH_LAST_PLAYER] = last_player;
             sh[SH_STATE] = AZB_COMPLETE;
@@ -1203,10 +1220,11 @@ template <class Wv, int N, int GAME> struct Engine {
         record_sample();
         const int mover = gr.env.to_play;
         bool resign = false;
-        if (GAME == AZ_GO && c.has_resign && gr.env.steps > c.check_resign_after) {
+        if (GAME == AZ_GO && c.has_resign && gr.resign_thr > -1.0 && gr.env.steps > c.check_resign_after) {
             // root_Q is a Python float on a fresh root, np.float32 otherwise; best_child_Q is np.float32
-            const bool lo_root = gr.root_fresh ? (rq < c.resign_threshold) : ((float)rq < (float)c.resign_threshold);
-            const bool lo_child = (float)cq < (float)c.resign_threshold;
+            const double thr = gr.resign_thr;  // this game's threshold (pipeline.py:241-242, :328-333)
+            const bool lo_root = gr.root_fresh ? (rq < thr) : ((float)rq < (float)thr);
+            const bool lo_child = (float)cq < (float)thr;
             if (lo_root && lo_child) {
                 if (gr.marked_player < 0 && Wv::first()) gr.marked_player = mover;
                 Wv::sync();

@@ -225,6 +225,7 @@ struct OpHarvest {
     int max_games;
     int* out_counts;  // [0] samples, [1] games
     int16_t* moves;   // optional: the move played from every sample's position (azsp_harvest_moves)
+    int* extra;       // [max_games][4] = {training_steps at game end, resign threshold double bits lo, hi, straddled a weight swap}
     template <class E> AZ_HD void operator()(E& e) const {
         const int NP = E::NP, A = E::A, W = E::W;
         const bool go = E::GAME_ID == AZ_GO;
@@ -292,6 +293,11 @@ struct OpHarvest {
                 o[10] = sh[SH_MARKED_PLAYER] < 0 ? 0 : (sh[SH_MARKED_PLAYER] == 0 ? b_id : w_id);
                 o[11] = sh[SH_UID];
                 o[12] = sh[SH_TRAINING_STEPS];
+                int* x = extra + (size_t)gi * 4;
+                x[0] = sh[SH_TS_END];
+                x[1] = sh[SH_THR_LO];
+                x[2] = sh[SH_THR_HI];
+                x[3] = sh[SH_TS_END] != sh[SH_TRAINING_STEPS] ? 1 : 0;
                 o[13] = reward;
                 o[14] = last_player == 0 ? b_id : w_id;
                 o[15] = e.g;
@@ -492,6 +498,8 @@ struct AzHandle {
     int* d_games;
     int d_games_cap;
     int16_t* harvest_moves = nullptr;  // optional per-sample move output of azsp_harvest (azsp_harvest_moves)
+    int* d_gextra = nullptr;           // [d_games_cap][4] per-game extras (azsp_harvest_extra)
+    int32_t* harvest_extra = nullptr;  // host destination of the extras, optional
 };
 
 namespace azb {  // implemented by the backend translation unit
@@ -619,7 +627,7 @@ int azsp_create(const AzspConfig* p, void** out) {
     c.deterministic = p->deterministic;
     c.reuse_tree = p->reuse_tree;
     c.warm_up_steps = p->warm_up_steps;
-    c.has_resign = (p->game == AZSP_GAME_GO && p->has_resign && p->resign_threshold > -1.0) ? 1 : 0;
+    c.has_resign = (p->game == AZSP_GAME_GO && p->has_resign) ? 1 : 0;  // env.has_resign_move; the threshold itself is per game (azsp_set_actor_state)
     c.check_resign_after = p->check_resign_after_steps;
     c.force_resign_disabled = p->force_resign_disabled;
     c.inject = p->inject_random;
@@ -674,8 +682,9 @@ int azsp_create(const AzspConfig* p, void** out) {
     h->d_hcounts = az_new<int>(h, 4);
     h->d_games_cap = (int)(2 * G);
     h->d_games = az_new<int>(h, (size_t)h->d_games_cap * 16);
+    h->d_gextra = az_new<int>(h, (size_t)h->d_games_cap * 4);
     if (!m.nodes || !m.games || !m.rootP || !m.free_stack || !m.leaf_path || !m.stg_planes || !m.stg_pi || !m.log_pi ||
-        !h->d_games || !m.err) {
+        !h->d_games || !h->d_gextra || !m.err) {
         for (void* q : h->allocs) azb::release(q);
         delete h;
         return AZSP_ENOMEM;
@@ -864,7 +873,7 @@ int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int3
     if (!h || !states || !pi || !z || !games || !n_samples || !n_games || cap < 1) return AZSP_EINVAL;
     if (max_games > h->d_games_cap) max_games = h->d_games_cap;
     if (azb::zero(h->d_hcounts, sizeof(int) * 4, stream)) return AZSP_EDEVICE;
-    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hcounts, h->harvest_moves};
+    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hcounts, h->harvest_moves, h->d_gextra};
     int rc = az_run(h, op, stream);
     if (rc) return rc;
     int cnt[4];
@@ -872,7 +881,23 @@ int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int3
     *n_samples = cnt[0];
     *n_games = cnt[1];
     if (cnt[1] > 0 && azb::d2h(games, h->d_games, sizeof(int) * 16 * (size_t)cnt[1], stream)) return AZSP_EDEVICE;
+    if (cnt[1] > 0 && h->harvest_extra && azb::d2h(h->harvest_extra, h->d_gextra, sizeof(int) * 4 * (size_t)cnt[1], stream)) return AZSP_EDEVICE;
     return az_check_engine_fault(h, stream);
+}
+
+int azsp_harvest_extra(void* e, int32_t* extra_host) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    h->harvest_extra = extra_host;
+    return AZSP_OK;
+}
+
+int azsp_set_actor_state(void* e, double resign_threshold, int32_t training_steps) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h) return AZSP_EINVAL;
+    h->cfg.resign_threshold = resign_threshold;  // AzCfg travels by value with every launch: the next new_game() reads it
+    h->cfg.training_steps = training_steps;
+    return AZSP_OK;
 }
 
 int azsp_harvest_moves(void* e, int16_t* moves_dev) {

@@ -23,6 +23,7 @@
  *   azsp_get_status / azsp_get_search the tuple uct_search() returns            (core/mcts_v2.py:450)
  *   azsp_commit_move                  sub-tree reuse after the caller chose the move (core/mcts_v2.py:436-446)
  *   azsp_harvest                      data_queue.put((game_seq, stats))         (core/pipeline.py:283, :349-380)
+ *   azsp_set_actor_state              per-game re-read of var_resign_threshold / checkpoint tag (core/pipeline.py:232-246)
  *   azsp_replay_gather                UniformReplay.sample + batch tensors + random transformation (core/replay.py:72-83,
  *                                      core/pipeline.py:636-643)
  *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
@@ -189,6 +190,18 @@ int azsp_rng_probe(void* engine, int32_t plies, int32_t tries, double* noise_hos
  * reference's env.history / to_sgf() holds for a self-play game (envs/base.py:224-226, core/pipeline.py:276-281).
  * NULL (the default) disables it.  The buffer must stay valid for every later azsp_harvest call. */
 int azsp_harvest_moves(void* engine, int16_t* moves_dev);
+
+/* Third optional output of azsp_harvest: extra_host int32[max_games][4] (host memory, row i belongs to games_host row i) =
+ * {training_steps of the weights in use when the game ENDED, the game's own resign threshold as the low / high word of its
+ * double, 1 if the game straddled a weight hot-swap (end tag != start tag)}.  games_host column 12 is the tag of the weights that
+ * STARTED the game, which is what the reference actor writes (core/pipeline.py:237 -> :271).  NULL (default) disables it. */
+int azsp_harvest_extra(void* engine, int32_t* extra_host);
+
+/* Per-game actor state: the reference actor re-reads the shared resign threshold (core/pipeline.py:241-242) and the weights'
+ * training_steps (core/pipeline.py:232-239) before EVERY game.  Both values take effect for games that start after this call
+ * (each game keeps the threshold / tag it started with; resign_disabled is drawn per game only while the threshold is > -1,
+ * core/pipeline.py:244-246).  resign_threshold <= -1 disables resignation (the learner's warm-up value, core/pipeline.py:449-459). */
+int azsp_set_actor_state(void* engine, double resign_threshold, int32_t training_steps);
 
 /* counters_host uint64[16]: simulations, best_child calls, backup edges, leaves, duplicate leaves, terminal hits,
  * moves, games, root evaluations, nodes created, game-rounds, buffer stalls. */

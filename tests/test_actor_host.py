@@ -57,11 +57,15 @@ def test_actor_gomoku_and_weight_swap():
     for _ in range(300):
         a.run_rounds(10)
         got += a.harvest()
-        if len(got) >= 4:
+        if len(got) >= 9:
             break
-    assert len(got) >= 4
+    assert len(got) >= 9
+    tags = [stats["training_steps"] for _, stats in got]
+    # games that were in progress at the swap keep the tag of the weights that STARTED them (pipeline.py:237 -> :271) and are
+    # counted as straddling; every game started afterwards carries the new tag
+    assert set(tags) <= {0, 1000} and 1000 in tags and tags.count(0) == a.straddled_games and a.straddled_games <= 4
     for seq, stats in got:
-        assert stats["training_steps"] == 1000 and set(stats) == {"game_length", "game_result", "training_steps"}
+        assert set(stats) == {"game_length", "game_result", "training_steps"}
         assert seq[0].pi_prob.dtype == np.float32
         assert stats["game_result"] in ("B+1.0", "W+1.0", "DRAW")
 
@@ -123,6 +127,134 @@ def test_actor_loop_writes_reference_csv(tmp_path):
     assert text.startswith("(;\nCA[UTF-8]\nAP[AlphaZeroMini_sgfgenerator]\nRU[Chinese]") and "SZ[5]" in text and text.endswith(")")
 
 
+def check_per_game_actor_state(a, n_games=8):
+    """pipeline.py:232-246: the resign threshold and the weights' training_steps are read when a game STARTS.  The actor begins
+    with resignation off (-1, the learner's warm-up value pipeline.py:449-459), the threshold is raised while games are in
+    progress, later lowered again: every game reports the threshold it started with, resigns only if that one allows it, and
+    draws resign_disabled only while its threshold is > -1 (pipeline.py:244-246)."""
+    G = a.cfg.num_games
+    assert a.resign_threshold == -1.0
+    a.run_rounds(6)                      # all first games are in progress with threshold -1
+    a.set_resign_threshold(-0.3)
+    a.set_network(a._net, training_steps=77) if hasattr(a, "_net") else None
+    got = []
+    for _ in range(400):
+        a.run_rounds(10)
+        got += a.harvest()
+        if len(got) >= n_games + G:
+            break
+    assert len(got) >= n_games + G
+    first, later = got[:G], got[G:]
+    thr = [s["resign_threshold"] for _, s in got]
+    assert set(thr) == {-1.0, -0.3}
+    old = [s for _, s in got if s["resign_threshold"] == -1.0]
+    new = [s for _, s in got if s["resign_threshold"] == -0.3]
+    assert len(old) == G                                  # exactly the games that were running when the value changed
+    assert all(s["is_resign_disabled"] and not s["is_marked_for_resign"] and not s["game_result"].endswith("+R") for s in old)
+    assert any(not s["is_resign_disabled"] for s in new)   # the per-game draw happens once the threshold is > -1
+    assert any(s["game_result"].endswith("+R") for s in new)  # and those games may resign
+    assert all(s["is_resign_disabled"] for s in new if s["is_marked_for_resign"])
+    return got
+
+
+def test_per_game_resign_threshold_and_training_steps():
+    a = _actor(G=6, sims=12, P=4, resign_threshold=-1.0, check_resign_after_steps=4, disable_resign_ratio=0.5)
+    torch.manual_seed(2)
+    a._net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    got = check_per_game_actor_state(a, n_games=20)
+    old = [s for _, s in got if s["resign_threshold"] == -1.0]
+    new = [s for _, s in got if s["resign_threshold"] == -0.3]
+    assert all(s["training_steps"] == 0 for s in old) and all(s["training_steps"] == 77 for s in new)
+    assert a.straddled_games == 6
+    # dropping instead of tagging
+    b = _actor(G=4, sims=12, P=4)
+    b.drop_straddling_games = True
+    b.run_rounds(6)
+    b.set_network(a._net, training_steps=5)
+    out = []
+    for _ in range(200):
+        b.run_rounds(10)
+        out += b.harvest()
+        if len(out) >= 6:
+            break
+    assert b.straddled_games == 4 and all(s["training_steps"] == 5 for _, s in out)
+
+
+def test_actor_loop_rereads_the_resign_threshold(tmp_path):
+    """run_selfplay_actor_loop follows var_resign_threshold at run time (pipeline.py:241-242) and discards games while ckpt_event is
+    set (pipeline.py:264-267)."""
+    import multiprocessing as mp
+    import queue
+    import threading
+
+    from alpha_zero_amd.core.pipeline import run_selfplay_actor_loop
+    from alpha_zero_amd.envs.go import GoEnv
+
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    env = GoEnv(board_size=5, _binding=eu.hosttwin_binding(), _device="cpu")
+    var_thr = mp.Value("d", -1.0)
+    q, stop, ckpt = queue.Queue(), threading.Event(), threading.Event()
+    th = threading.Thread(target=run_selfplay_actor_loop, args=(3, 0, net, "cpu", q, env, 12, 4, 19652, 1.25, 4, 4, 0.5), kwargs=dict(
+        logs_dir=str(tmp_path), stop_event=stop, ckpt_event=ckpt, var_resign_threshold=var_thr, num_games=6, net_dtype=torch.float32,
+        harvest_every=10, binding=eu.hosttwin_binding()))
+    th.start()
+    first = q.get(timeout=120)
+    assert first[1]["resign_threshold"] == -1.0
+    var_thr.value = -0.25
+    seen = []
+    for _ in range(400):
+        seen.append(q.get(timeout=120)[1]["resign_threshold"])
+        if seen[-1] == -0.25:
+            break
+    assert seen[-1] == -0.25
+    ckpt.set()      # learner writes a checkpoint: nothing may reach the queue while the event is set
+    import time
+    time.sleep(1.0)
+    while not q.empty():
+        q.get()
+    time.sleep(1.0)
+    assert q.empty()
+    ckpt.clear()
+    q.get(timeout=120)
+    stop.set()
+    th.join(timeout=120)
+    assert not th.is_alive()
+
+
+def test_resign_controller_warm_up_and_finalizer_pool():
+    from alpha_zero_amd.core import mcts_v2
+    from alpha_zero_amd.core.evaluate import ResignController
+
+    # pipeline.py:449-459, :533-536: -1 during the first no_resign_games games, reset to init when they are in
+    rc = ResignController(-0.88, no_resign_games=3, reset_fp_interval=100, games_per_ckpt=100, disable_resign_ratio=0.1)
+    assert rc.threshold == -1
+    assert rc.on_game({}, 1) == -1 and rc.on_game({}, 2) == -1 and rc.on_game({}, 3) == -0.88
+    assert ResignController(-1.0, 0, 100, 100, 0.1).threshold == -1
+    assert ResignController(-0.9, 0, 100, 100, 0.1).threshold == -0.9
+
+    # ADVICE r1: a consumed handle must not return its (still used) engine to the pool when it is garbage collected
+    class Stub:
+        key = ("stub",)
+
+    mcts_v2._POOL.pop(("stub",), None)
+    s = Stub()
+    n1 = mcts_v2.Node(s, np.zeros((5, 5), np.int8), 1, 0)
+    n1._alive = False
+    n1._fin.detach()          # what _search does when the handle is handed back
+    n2 = mcts_v2.Node(s, np.zeros((5, 5), np.int8), 2, 1)
+    del n1
+    import gc
+    gc.collect()
+    assert not mcts_v2._POOL.get(("stub",))           # the engine n2 uses is NOT in the pool
+    del n2
+    gc.collect()
+    assert mcts_v2._POOL.get(("stub",)) == [s]         # dropping the live handle releases it, once
+    mcts_v2._release(s)
+    assert mcts_v2._POOL.get(("stub",)) == [s]
+    mcts_v2._POOL.pop(("stub",), None)
+
+
 def check_harvested_moves(a):
     """azsp_harvest_moves: the move list of every finished self-play game, replayed through the CPU oracle env, reproduces each
     recorded sample state, the game length, the pass count and the result string."""
@@ -157,3 +289,71 @@ def check_harvested_moves(a):
 
 def test_harvested_moves_replay_to_the_samples_and_the_result():
     check_harvested_moves(_actor(G=6, sims=12, P=4, resign_threshold=-0.3, check_resign_after_steps=4, disable_resign_ratio=0.5))
+
+
+def check_actor_loop(device, binding, tmp_path):
+    """run_selfplay_actor_loop (pipeline.py:166-286): queue tuples (game_seq, stats) with the reference's key order,
+    actor{rank}.csv with the reference's columns, checkpoint hot-swap through var_ckpt (file + training_steps tag), the
+    threshold followed at run time, nothing queued while ckpt_event is set."""
+    import csv
+    import multiprocessing as mp
+    import queue
+    import threading
+    import time
+
+    import torch
+
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import run_selfplay_actor_loop
+    from alpha_zero_amd.core.replay import Transition
+    from alpha_zero_amd.envs.go import GoEnv
+
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    torch.manual_seed(5)
+    net2 = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    ck = os.path.join(str(tmp_path), "training_steps_500.ckpt")
+    torch.save({"network": net2.state_dict(), "training_steps": 500}, ck)
+    env = GoEnv(board_size=5, _binding=binding, _device=device)
+    var_thr, var_ckpt = mp.Value("d", -1.0), mp.Array("c", 512)
+    q, stop, ckpt_ev = queue.Queue(), threading.Event(), threading.Event()
+    th = threading.Thread(target=run_selfplay_actor_loop, args=(3, 0, net, device, q, env, 12, 4, 19652, 1.25, 4, 4, 0.5), kwargs=dict(
+        logs_dir=str(tmp_path), save_sgf_dir=str(tmp_path), save_sgf_interval=3, stop_event=stop, ckpt_event=ckpt_ev, var_ckpt=var_ckpt,
+        var_resign_threshold=var_thr, num_games=8, net_dtype=torch.float32, harvest_every=10, binding=binding))
+    th.start()
+    try:
+        seq, stats = q.get(timeout=300)
+        want = "datetime,game_length,game_result,num_passes,is_resign_disabled,is_marked_for_resign,is_could_won,marked_resign_player,resign_threshold,time_per_game,training_steps"
+        assert list(stats.keys()) == want.split(",")[1:]
+        assert isinstance(seq[0], Transition) and seq[0].state.shape == (17, 5, 5) and seq[0].state.dtype == np.int8
+        assert seq[0].pi_prob.dtype == np.float64 and seq[0].pi_prob.shape == (26,) and len(seq) == stats["game_length"]
+        assert stats["training_steps"] == 0 and stats["resign_threshold"] == -1.0
+        var_thr.value = -0.25
+        var_ckpt.value = ck.encode("utf-8")
+        tags = []
+        for _ in range(2000):
+            s = q.get(timeout=300)[1]
+            tags.append((s["training_steps"], s["resign_threshold"]))
+            if tags[-1] == (500, -0.25):
+                break
+        assert tags[-1] == (500, -0.25) and all(t in ((0, -1.0), (0, -0.25), (500, -0.25)) for t in tags)
+        ckpt_ev.set()
+        time.sleep(1.5)
+        while not q.empty():
+            q.get()
+        time.sleep(1.5)
+        assert q.empty()
+        ckpt_ev.clear()
+        q.get(timeout=300)
+    finally:
+        stop.set()
+        th.join(timeout=300)
+    assert not th.is_alive()
+    rows = list(csv.reader(open(os.path.join(str(tmp_path), "actor0.csv"))))
+    assert ",".join(rows[0]) == want and len(rows) >= 3 and all(len(r) == len(rows[0]) for r in rows[1:])
+    assert {r[-1] for r in rows[1:]} <= {"0", "500"} and "500" in {r[-1] for r in rows[1:]}
+    assert any(f.endswith(".sgf") for f in os.listdir(str(tmp_path)))
+
+
+def test_actor_loop_hot_swap_threshold_and_ckpt_event(tmp_path):
+    check_actor_loop("cpu", eu.hosttwin_binding(), tmp_path)

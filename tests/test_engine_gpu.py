@@ -150,3 +150,60 @@ def test_gpu_harvested_moves_replay_to_the_samples_and_the_result():
                       net_dtype=torch.float32, use_graph=False, binding=_lib.load(), resign_threshold=-0.3, check_resign_after_steps=4,
                       disable_resign_ratio=0.5)
     tah.check_harvested_moves(a)
+
+
+# ---- the reference's known-answer edge cases through the HIP env kernels ------------------------
+def test_gpu_go19_known_sequences(golden_dir):
+    """unit_tests/envs/go_test.py:80-209: suicide x2, ko, scoring sequences, stacked planes -- via azsp_env_step on the device."""
+    import edge_checks as ec
+
+    ec.check_go19_known_sequences("gpu", golden_dir)
+
+
+def test_gpu_go9_score_boards(golden_dir):
+    """others/go_score_system.py:100-236: the 7 boards via azsp_set_state + a scoring step on the device."""
+    import edge_checks as ec
+
+    ec.check_go9_score_boards("gpu", golden_dir)
+
+
+# ---- actor loop semantics on the device (VERDICT r1 #8) ----------------------------------------------------------
+def _gpu_actor(**kw):
+    import torch
+
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    args = dict(game="go", board_size=5, num_games=6, num_simulations=12, num_parallel=4, warm_up_steps=4, device="cuda",
+                net_dtype=torch.float32, use_graph=False, binding=_lib.load())
+    args.update(kw)
+    return SelfPlayActor(net, **args)
+
+
+def test_gpu_per_game_resign_threshold_and_training_steps():
+    """azsp_set_actor_state on the device: every game plays with, and reports, the threshold / weights tag it STARTED with
+    (pipeline.py:232-246)."""
+    import torch
+
+    import test_actor_host as tah
+    from alpha_zero_amd.core.network import AlphaZeroNet
+
+    a = _gpu_actor(resign_threshold=-1.0, check_resign_after_steps=4, disable_resign_ratio=0.5)
+    torch.manual_seed(2)
+    a._net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
+    got = tah.check_per_game_actor_state(a, n_games=20)
+    old = [s for _, s in got if s["resign_threshold"] == -1.0]
+    new = [s for _, s in got if s["resign_threshold"] == -0.3]
+    assert all(s["training_steps"] == 0 for s in old) and all(s["training_steps"] == 77 for s in new)
+    assert a.straddled_games == 6
+
+
+def test_gpu_run_selfplay_actor_loop(tmp_path):
+    """run_selfplay_actor_loop on the device (pipeline.py:166-286): see test_actor_host.check_actor_loop."""
+    import test_actor_host as tah
+    from alpha_zero_amd import _lib
+
+    tah.check_actor_loop("cuda", _lib.load(), tmp_path)

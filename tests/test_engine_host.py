@@ -81,3 +81,10 @@ def test_production_randomness_statistics():
     import rng_checks as rc
 
     rc.check_production_rng("host")
+
+
+def test_host_go19_known_sequences_and_score_boards(golden_dir):
+    import edge_checks as ec
+
+    ec.check_go19_known_sequences("host", golden_dir)
+    ec.check_go9_score_boards("host", golden_dir)
