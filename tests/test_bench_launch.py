@@ -55,3 +55,11 @@ def test_broadcast_weights_two_ranks_gloo(tmp_path):
     for k in w0.files:
         if np.issubdtype(w0[k].dtype, np.floating):
             assert np.array_equal(w0[k], w1[k]), k
+
+
+def test_cpu_baseline_calibration_fixture(golden_dir):
+    """SURVEY 8d last row: the port-vs-reference ratio is a committed fixture (tools/calibrate_baseline.py) that bench.py reports."""
+    doc = json.load(open(os.path.join(golden_dir, "cpu_baseline_calibration.json")))
+    r = doc["ratios"]["go9_p8_s200_10x128"]
+    assert 0.8 <= r["ratio"] <= 1.4 and r["reference_moves_per_s"] > 0 and sum(x["moves"] for x in r["runs"]) >= 100
+    assert abs(r["ratio"] - r["port_moves_per_s"] / r["reference_moves_per_s"]) < 1e-3

@@ -6,8 +6,9 @@ comparable visit by visit, so the statement is distributional: the SAME engine, 
 (production Philox streams keyed by (seed, slot, game, ply): identical in both runs), one full search per position (200 sims,
 P = 8), evaluator = (a) bf16 hand-written kernels, (b) fp32 network.  Bounded here (thresholds also stated in DESIGN.md 4):
 
-    top-1 agreement of the search policy  >= AGREE_MIN      sampled-move agreement (same uniform) >= MOVE_MIN
-    mean KL(pi_fp32 || pi_bf16) <= KL_MAX (eps-smoothed)      mean total variation <= TV_MAX      mean |root_Q diff| <= Q_MAX
+    top-1 agreement of the root visit counts >= AGREE_MIN      sampled-move agreement (same uniform) >= MOVE_MIN
+    mean KL(v_fp32 || v_bf16) <= KL_MAX  and  mean total variation <= TV_MAX  on the root visit distributions v = child_N / sum
+    (eps-smoothed KL; the temperature-sharpened pi = v^5 of late moves is reported, not bounded)      mean |root_Q diff| <= Q_MAX
 
 Two networks: the random-init 10 x 128 Go network of the bench (flat priors: the hardest case for agreement) and the reference's
 shipped, TRAINED 13x13 Gomoku checkpoint widened to the 64-filter kernels.  The measured values are written to
@@ -46,25 +47,26 @@ def _searched_policies(net, game, n, dtype, G, sims, P, stagger, seed=7):
             break
     st, q = e.status()
     assert np.all((st[:, 0] == _abi.ST_IDLE) | ~live)
-    pis, moves = [], []
+    pis, vis, moves = [], [], []
     for g in range(G):
         pi, cn, qq = e.get_search(g, 0)
-        pis.append(pi), moves.append(int(qq[3]))
-    return np.array(pis), np.array(moves), q[:, 0].copy(), live, act.tiled_features
+        pis.append(pi), moves.append(int(qq[3])), vis.append(cn.astype(np.float64) / max(1.0, float(cn.sum())))
+    return np.array(pis), np.array(vis), np.array(moves), q[:, 0].copy(), live, act.tiled_features
 
 
 def _compare(name, net, game, n, G, sims, P, stagger):
-    pa, ma, qa, live, tiled = _searched_policies(net, game, n, torch.bfloat16, G, sims, P, stagger)
+    pa, va, ma, qa, live, tiled = _searched_policies(net, game, n, torch.bfloat16, G, sims, P, stagger)
     assert tiled, "the bf16 run must go through the hand-written tiled evaluator"
-    pb, mb, qb, live_b, _ = _searched_policies(net, game, n, torch.float32, G, sims, P, stagger)
+    pb, vb, mb, qb, live_b, _ = _searched_policies(net, game, n, torch.float32, G, sims, P, stagger)
     assert np.array_equal(live, live_b)
-    pa, pb, ma, mb, qa, qb = pa[live], pb[live], ma[live], mb[live], qa[live], qb[live]
-    eps = 1e-4
-    sa, sb = (pa + eps) / (pa + eps).sum(1, keepdims=True), (pb + eps) / (pb + eps).sum(1, keepdims=True)
+    pa, pb, va, vb, ma, mb, qa, qb = pa[live], pb[live], va[live], vb[live], ma[live], mb[live], qa[live], qb[live]
+    eps = 1e-3  # ~ a fifth of one visit at 200 simulations
+    sa, sb = (va + eps) / (va + eps).sum(1, keepdims=True), (vb + eps) / (vb + eps).sum(1, keepdims=True)
     res = dict(name=name, positions=int(live.sum()), sims=sims, P=P,
-               top1_agreement=float((pa.argmax(1) == pb.argmax(1)).mean()), move_agreement=float((ma == mb).mean()),
-               mean_kl_fp32_bf16=float((sb * np.log(sb / sa)).sum(1).mean()), mean_tv=float(0.5 * np.abs(pa - pb).sum(1).mean()),
-               mean_abs_root_q_diff=float(np.abs(qa - qb).mean()), mean_top1_mass_fp32=float(pb.max(1).mean()))
+               top1_agreement=float((va.argmax(1) == vb.argmax(1)).mean()), move_agreement=float((ma == mb).mean()),
+               mean_kl_fp32_bf16=float((sb * np.log(sb / sa)).sum(1).mean()), mean_tv=float(0.5 * np.abs(va - vb).sum(1).mean()),
+               mean_abs_root_q_diff=float(np.abs(qa - qb).mean()), mean_top1_visit_share_fp32=float(vb.max(1).mean()),
+               mean_tv_search_pi=float(0.5 * np.abs(pa - pb).sum(1).mean()))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"precision_parity_{name}.json"), "w"), indent=1)
     print(json.dumps(res))
@@ -77,8 +79,8 @@ def test_gpu_bf16_search_close_to_fp32_search_go9_bench_network():
     torch.manual_seed(1)
     net = AlphaZeroNet((17, 9, 9), 82, 10, 128, 128)  # the bench's network: random Kaiming init = nearly flat priors
     r = _compare("go9_10x128_random_init", net, "go", 9, 384, 200, 8, 40)
-    assert r["top1_agreement"] >= 0.60 and r["move_agreement"] >= 0.60, r
-    assert r["mean_kl_fp32_bf16"] <= 0.10 and r["mean_tv"] <= 0.15 and r["mean_abs_root_q_diff"] <= 0.03, r
+    assert r["top1_agreement"] >= 0.80 and r["move_agreement"] >= 0.95, r
+    assert r["mean_kl_fp32_bf16"] <= 0.15 and r["mean_tv"] <= 0.15 and r["mean_abs_root_q_diff"] <= 0.04, r
 
 
 def test_gpu_bf16_search_close_to_fp32_search_trained_gomoku13(golden_dir):
@@ -87,5 +89,5 @@ def test_gpu_bf16_search_close_to_fp32_search_trained_gomoku13(golden_dir):
 
     net = widen_network(test_ckpt.load_shipped(golden_dir), 64)
     r = _compare("gomoku13_shipped_ckpt_widened64", net, "gomoku", 13, 256, 200, 8, 30)
-    assert r["top1_agreement"] >= 0.85 and r["move_agreement"] >= 0.80, r
-    assert r["mean_kl_fp32_bf16"] <= 0.05 and r["mean_tv"] <= 0.08 and r["mean_abs_root_q_diff"] <= 0.03, r
+    assert r["top1_agreement"] >= 0.95 and r["move_agreement"] >= 0.97, r
+    assert r["mean_kl_fp32_bf16"] <= 0.02 and r["mean_tv"] <= 0.03 and r["mean_abs_root_q_diff"] <= 0.02, r
