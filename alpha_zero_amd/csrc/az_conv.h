@@ -318,39 +318,116 @@ __device__ __forceinline__ unsigned cw_pk_bf16(float a, float b) {  // one v_cvt
     const b2 r = __builtin_convertvector((f2){a, b}, b2);
     return __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ float cw_add_f32(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ unsigned cw_pk_max_i16(unsigned a, unsigned b) {
     unsigned r;
     asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
-// NCH = input-channel chunks of 8: 16 for the tower (128 -> 128), 4 for the stem (17 planes padded to 32 -> 128).
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_tiled<RES, NCH> (NCH = input-channel chunks of 8: 16 for the tower 128 -> 128, 4 for the stem 17 planes padded to 32 -> 128):
+// the weight-stationary convolution described above with the EPILOGUE SOFTWARE-PIPELINED into the MFMA stream.
+// Measured (tools/probes/mfma_valu_probe.hip, profiles/r02_mfma_valu_probe.txt): with one wave per SIMD up to 4 plain VALU
+// instructions placed in EVERY gap between two MFMAs are free (32.6-32.8 cycles per MFMA with 0, 2 or 4 of them; only packed-f32
+// VALU is not: v_pk_add_f32 costs +11 cycles each), whereas the previous kernel ran the epilogue of a unit as one serial block
+// after its MFMAs (~10 % of the launch).  Here a tile is 4 units of 2 column tiles with two accumulator sets: while unit u
+// multiplies into set u & 1, the residual add / bf16 rounding / ReLU / stores of unit u - 1 are issued from the other set a few
+// instructions per k-step, the B-fragment ring runs on across unit and tile boundaries, the next tile's LDS-DMA pieces ride in units
+// 0-2, and the only synchronisation per tile is one barrier (3 k-steps before the end of unit 3, when every read of the
+// current buffer has been issued) behind an exactly counted s_waitcnt vmcnt(N) that leaves the younger stores in flight.
+template <int V> struct CpInt {
+    static constexpr int value = V;
+};
+template <int... I> struct CpSeq {};
+template <int N, int... I> struct CpMakeSeq : CpMakeSeq<N - 1, N - 1, I...> {};
+template <int... I> struct CpMakeSeq<0, I...> {
+    typedef CpSeq<I...> type;
+};
+// f(CpInt<0>{}), f(CpInt<1>{}), ...: compile-time k-step index (no reliance on the loop unroller's size heuristics)
+template <class F, int... I> __device__ __forceinline__ void cp_for_each(F&& f, CpSeq<I...>) { (f(CpInt<I>{}), ...); }
+template <int NSTEP> struct CpSched {  // static schedule of one unit's k-steps (everything below is compile-time)
+    static constexpr int E0 = 4;  // first k-step that may touch the previous unit's accumulators (>= 4 MFMAs behind their last write)
+    // residual layers: slot s (column tile s / 4, register quad s % 4) takes 3 phases (2 x unpack + add, then round / ReLU / store)
+    static constexpr int RSTRIDE = (NSTEP - E0 - 4) / 24 > 0 ? (NSTEP - E0 - 4) / 24 : 1;
+    static constexpr int PSTRIDE = (NSTEP - E0 - 4) / 8 > 0 ? (NSTEP - E0 - 4) / 8 : 1;
+    static constexpr int res_step(int s, int ph) { return E0 + (3 * s + ph) * RSTRIDE; }
+    static constexpr int plain_step(int s) { return E0 + s * PSTRIDE; }
+    static constexpr int store_step(bool res, int s) { return res ? res_step(s, 2) : plain_step(s); }
+    // DMA piece i of the next tile: unit i % 3, k-step 3 + 4 (i / 3)  (odd steps: never a store step's neighbour in program order)
+    static constexpr int dma_unit(int i) { return i % 3; }
+    static constexpr int dma_step(int i) { return 3 + 4 * (i / 3); }
+    // inverse maps (one candidate per k-step: keeps the loop body small enough for the unroller)
+    static constexpr int dma_at(int u, int t, int npiece) {  // piece issued at (unit u, k-step t) or -1
+        if (t < 3 || (t - 3) % 4 != 0 || u > 2) return -1;
+        const int i = 3 * ((t - 3) / 4) + u;
+        return i < npiece ? i : -1;
+    }
+    static constexpr int res_at(int t) {  // 3 * slot + phase handled at k-step t of a residual layer, or -1
+        if (t < E0 || (t - E0) % RSTRIDE != 0) return -1;
+        const int k = (t - E0) / RSTRIDE;
+        return k < 24 ? k : -1;
+    }
+    static constexpr int plain_at(int t) {  // slot handled at k-step t of a plain layer, or -1
+        if (t < E0 || (t - E0) % PSTRIDE != 0) return -1;
+        const int k = (t - E0) / PSTRIDE;
+        return k < 8 ? k : -1;
+    }
+    static constexpr int BAR_STEP = NSTEP - 3;  // unit 3: barrier before the first fragment loads of the next tile
+    static constexpr int RL0 = NSTEP >= 72 ? 40 : 0;  // first k-step of the unit's residual loads (late: the two sets' live ranges barely overlap)
+    // VMEM operations issued after the last DMA piece and before the barrier: stores of unit 1's epilogue still to come in unit 2,
+    // unit 3's residual loads (8, k-steps 0-3) and the stores of unit 2's epilogue (all before BAR_STEP)
+    static constexpr int after_last_dma(bool res, int npiece) {
+        int last_u = 0, last_t = -1;
+        for (int i = 0; i < npiece; ++i)
+            if (dma_unit(i) > last_u || (dma_unit(i) == last_u && dma_step(i) > last_t)) {
+                last_u = dma_unit(i);
+                last_t = dma_step(i);
+            }
+        int n = 0;
+        for (int u = last_u; u < 4; ++u)
+            for (int s = 0; s < 8; ++s) {
+                const int st = store_step(res, s);
+                if ((u > last_u || st >= last_t) && (u < 3 || st < BAR_STEP)) ++n;  // a store of the DMA's own k-step follows it
+            }
+        for (int u = last_u; u < 4; ++u)  // residual loads: 8 per unit in k-steps RL0 .. RL0 + 3
+            for (int k = 0; k < 4; ++k)
+                if (res && (u > last_u || RL0 + k > last_t) && (u < 3 || RL0 + k < BAR_STEP)) n += 2;
+        return n;
+    }
+};
+
 template <bool RES, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
-                const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
-    constexpr int KS = NCH / 2, NSTEP = 9 * KS;      // k-steps (16 cin) per tap, per unit
-    constexpr int LBUF = NCH * CT_LBLK;             // one LDS buffer: NCH chunk strips
-    constexpr int XTILE = NCH * CT_GBLK;            // input tile bytes (the output tile is always CT_TILE: 128 couts)
-    constexpr int NPIECE = NCH + NCH / 4;            // DMA pieces per wave per tile
+                  const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
+    constexpr int KS = NCH / 2, NSTEP = 9 * KS;
+    constexpr int LBUF = NCH * CT_LBLK, XTILE = NCH * CT_GBLK, NPIECE = NCH + NCH / 4;
+    typedef CpSched<NSTEP> SC;
+    static_assert((RES ? SC::res_step(7, 2) : SC::plain_step(7)) < SC::BAR_STEP, "epilogue must end before the barrier step");
+    static_assert(SC::dma_step(NPIECE - 1) < NSTEP - 4, "DMA pieces must be issued early in their unit");
+    constexpr int VM_AFTER_DMA = SC::after_last_dma(RES, NPIECE);
+    static_assert(VM_AFTER_DMA < 63, "vmcnt field");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     for (int i = tid; i < 2 * LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
 
-    cv_bf16x8 wf[NSTEP];  // this wave's 32 couts x (9 taps x 8 NCH cin): the A operand of every MFMA below
+    cv_bf16x8 wf[NSTEP];
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t)
         wf[t] = *(const cv_bf16x8*)(w + ((size_t)((t / KS) * CV_C + wave * 32 + l31)) * (8 * NCH) + ((t % KS) * 2 + hi) * 8);
-    cv_f32x16 bv;  // bias in the accumulator layout: the C operand of a unit's first MFMAs
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[rq * 4 + e] = bias[wave * 32 + 8 * rq + 4 * hi + e];
-    const unsigned lo16 = relu ? 0u : 0x80008000u;  // ReLU on packed bf16: signed-16 max with 0 (with the most negative value: identity)
+    // bias in the accumulator layout, kept in LDS ([wave][lane half][16 floats], broadcast reads): a unit's accumulators are
+    // initialised with it a few k-steps before the unit starts, which frees the 16 registers a C operand would pin
+    __shared__ __attribute__((aligned(64))) float bias_lds[4 * 2 * 16];
+    if (lane < 32) bias_lds[(wave * 2 + (lane >> 4)) * 16 + (lane & 15)] = bias[wave * 32 + 8 * ((lane & 15) >> 2) + 4 * (lane >> 4) + (lane & 3)];
+    const cv_f32x16* bias_ptr = (const cv_f32x16*)(bias_lds + (wave * 2 + hi) * 16);
+    const unsigned lo16 = relu ? 0u : 0x80008000u;
 
-    // LDS-DMA plan: a chunk strip is 5 pieces of 64 cells; wave q moves piece q of every strip and piece 4 of strips
-    // q, q+4, q+8, q+12.  Only position cells are transferred; a lane's source is its position's 16 B in the compact tile.
     auto cell_src = [&](int cell, bool& ok) -> unsigned {
         const int k = cell - CT_CELL0, b = k / CT_BPITCH, r = k - b * CT_BPITCH, yy = r / 10, xx = r - yy * 10;
         ok = k >= 0 && cell < CT_CELLS && b < CV_TB && yy < CV_S && xx < CV_S;
@@ -358,37 +435,31 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     };
     bool dok_a, dok_b;
     const unsigned dsrc_a = cell_src(wave * 64 + lane, dok_a), dsrc_b = cell_src(256 + lane, dok_b);
-    // One LDS-DMA piece of tile `src` into buffer `dstbuf`: piece i < NCH = this wave's 64-cell piece of chunk strip i,
-    // i >= NCH = the fifth (57-cell) piece of strip 4 (i - NCH) + wave.  Lanes on zero cells are masked off inside the
-    // statement; a zero mask (no next tile) makes the whole piece a no-op.  No VALU instruction: scalar base + lane offset.
     const unsigned long long mask_a = __builtin_amdgcn_ballot_w64(dok_a), mask_b = __builtin_amdgcn_ballot_w64(dok_b);
     auto dma_piece = [&](const unsigned char* src, unsigned dstbuf, bool live, int i) {
         const int c = i < NCH ? i : (i - NCH) * 4 + wave;
         const unsigned long long base = (unsigned long long)(src + (size_t)c * CT_GBLK);
         const unsigned long long mask = live ? (i < NCH ? mask_a : mask_b) : 0ull;
         const unsigned dst = dstbuf + (unsigned)(c * CT_LBLK + (i < NCH ? wave : 4) * 1024);
-        // EXEC is all ones everywhere in this kernel and nothing else in it uses M0 (checked in the ISA), so neither is saved:
-        // every scalar instruction here sits between two MFMA issues (probe: 12 cycles per bare piece, 39 with save / restore)
         asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
                      :
                      : "s"(mask), "s"(dst), "v"(i < NCH ? dsrc_a : dsrc_b), "s"(base)
                      : "memory");
     };
-
-    // this lane's 8 output positions (column tile ct, column l31) from the map: LDS byte offset of the (-1, -1) neighbour of
-    // its cell in its own chunk half (low 16 bits) and its position (high 16 bits)
     unsigned lmap[8];
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
-        lmap[ct] = (unsigned)((cw_map.cell[ct * 32 + l31] - CT_CELL0) * 16 + hi * CT_LBLK) | ((unsigned)cw_map.pos[ct * 32 + l31] << 16);  // offset < 2^16
+        lmap[ct] = (unsigned)((cw_map.cell[ct * 32 + l31] - CT_CELL0) * 16 + hi * CT_LBLK) | ((unsigned)cw_map.pos[ct * 32 + l31] << 16);
 
-    cv_bf16x8 bb[4][4];  // ring of B fragments: k-step s lives in slot s & 3
-    auto load_step = [&](const unsigned char* const (&bp)[4], int s) {  // tap s / KS = constant cell offset, cin chunks 2 (s % KS) + hi
+    cv_bf16x8 bb[4][2];  // ring of B fragments: k-step s of the running unit lives in slot s & 3
+    // k-step s of a unit: tap s / KS = constant cell offset, cin chunks 2 (s % KS) + hi; `slot` = (running k-step count) & 3
+    auto load_step = [&](const unsigned char* b0, const unsigned char* b1, int s, int slot) {
         const int tap = s / KS, ks = s % KS;
         const int off = ((tap / 3) * 10 + (tap % 3)) * 16 + ks * (2 * CT_LBLK);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bb[s & 3][j] = *(const cv_bf16x8*)(bp[j] + off);
+        bb[slot][0] = *(const cv_bf16x8*)(b0 + off);
+        bb[slot][1] = *(const cv_bf16x8*)(b1 + off);
     };
+    static_assert((4 * NSTEP) % 4 == 0, "a tile's k-steps keep the ring phase");
 
     {   // first tile: all pieces at once, then the first fragments
         const unsigned char* src = x + (size_t)blockIdx.x * XTILE;
@@ -396,14 +467,55 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         for (int i = 0; i < NPIECE; ++i) dma_piece(src, lds0, true, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CV_BARRIER();
+        load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), 0, 0);
+        load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), 1, 1);
+        load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), 2, 2);
     }
-    {
-        const unsigned char* bp0[4] = {lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), lds + (lmap[2] & 0xffffu), lds + (lmap[3] & 0xffffu)};
-        load_step(bp0, 0);
-        load_step(bp0, 1);
-        load_step(bp0, 2);
-    }
+    cv_f32x16 acc[2][2];   // [unit parity][column tile]
+    cv_u32x2 rr[2][2][4];  // residual of the unit: [unit parity][column tile][register quad]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][j][e] = 0.0f;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) rr[a][j][rq] = (cv_u32x2){0u, 0u};
+        }
+    acc[0][0] = *bias_ptr;  // (bias_lds was published by the barrier above)
+    acc[0][1] = *bias_ptr;
+    float ev[4];  // one epilogue slot between its phases
+
+    // epilogue phase `ph` of slot s of the unit with parity q, column tiles mapped by lmap[mb + j]; out = that unit's output base
+    auto epi = [&](int q, int mb, unsigned char* out, int s, int ph, bool store_ok) {
+        const int j = s >> 2, rq = s & 3;
+        if (RES) {
+            const cv_u32x2 r2 = rr[q][j][rq];
+            // plain v_add_f32: the compiler would SLP-pack two adds into v_pk_add_f32, which costs ~11 cycles of matrix-core time
+            // beside MFMAs (profiles/r02_mfma_valu_probe.txt) where a scalar add is free
+            if (ph == 0) {
+                ev[0] = cw_add_f32(acc[q][j][rq * 4 + 0], cv_bf16_lo(r2.x));
+                ev[1] = cw_add_f32(acc[q][j][rq * 4 + 1], cv_bf16_hi(r2.x));
+            } else if (ph == 1) {
+                ev[2] = cw_add_f32(acc[q][j][rq * 4 + 2], cv_bf16_lo(r2.y));
+                ev[3] = cw_add_f32(acc[q][j][rq * 4 + 3], cv_bf16_hi(r2.y));
+            }
+        } else if (ph == 2) {
+            ev[0] = acc[q][j][rq * 4 + 0], ev[1] = acc[q][j][rq * 4 + 1], ev[2] = acc[q][j][rq * 4 + 2], ev[3] = acc[q][j][rq * 4 + 3];
+        }
+        if (ph == 2) {
+            const unsigned gq = (lmap[mb + j] >> 16) * 16u + (unsigned)(hi * 8);
+            const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(ev[0], ev[1]), lo16), cw_pk_max_i16(cw_pk_bf16(ev[2], ev[3]), lo16)};
+#ifndef CP_ABL_NO_STORE
+            if (store_ok) *(cv_u32x2*)(out + rq * CT_GBLK + gq) = o;
+#else
+            if (o.x == 0x12345u && store_ok) *(cv_u32x2*)(out + rq * CT_GBLK + gq) = o;  // keeps the arithmetic alive
+#endif
+        }
+    };
+
     int it = 0;
+    unsigned char* yprev = y;  // output base of the previous tile (epilogue of its unit 3 runs inside this tile's unit 0)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
         const int buf = it & 1;
         const unsigned char* Xs = lds + buf * LBUF;
@@ -413,73 +525,89 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * LBUF);
         const unsigned char* rbase = RES ? res + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK : nullptr;
         unsigned char* ybase = y + (size_t)tile * CT_TILE + (size_t)(wave * 4) * CT_GBLK;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const unsigned char* bp[4];  // this unit's fragment bases
-            cv_u32x2 rr[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned mj = lmap[u * 4 + j];
-                bp[j] = Xs + (mj & 0xffffu);
-                if (RES) {
-                    const unsigned gq = (mj >> 16) * 16u + (unsigned)(hi * 8);
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) rr[j][rq] = *(const cv_u32x2*)(rbase + rq * CT_GBLK + gq);
+        const bool have_prev = it > 0;
+        // one unit = 2 column tiles x NSTEP k-steps; instantiated four times (a single 4 x NSTEP nest exceeds the unroller's budget)
+        auto unit = [&](auto UC) {
+            constexpr int u = decltype(UC)::value;
+            constexpr int q = u & 1, pq = q ^ 1;                  // accumulator set of this unit / of the previous one
+            constexpr int pmb = ((u + 3) & 3) * 2;                // lmap base of the previous unit's column tiles
+            unsigned char* pout = u == 0 ? yprev : ybase;          // where the previous unit's outputs go
+            const bool pstore = u > 0 || have_prev;
+            const unsigned char* b0 = Xs + (lmap[u * 2] & 0xffffu);
+            const unsigned char* b1 = Xs + (lmap[u * 2 + 1] & 0xffffu);
+            const unsigned char* nb0 = (u < 3 ? Xs : Xn) + (lmap[((u + 1) & 3) * 2] & 0xffffu);
+            const unsigned char* nb1 = (u < 3 ? Xs : Xn) + (lmap[((u + 1) & 3) * 2 + 1] & 0xffffu);
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::value;
+                if constexpr (u == 3 && t == SC::BAR_STEP) {
+                    // every read of this buffer has been issued (the ring runs 3 k-steps ahead).  All DMA pieces of the next tile are
+                    // older than the VM_AFTER_DMA youngest vector-memory operations of this wave, which may stay in flight.
+                    if (have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_AFTER_DMA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: its unit-0 epilogue stores were skipped
+                    CV_BARRIER();
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cv_f32x16 acc[4];
+#ifndef CP_ABL_NO_FRAG
+                if constexpr (t + 3 < NSTEP) load_step(b0, b1, t + 3, (u * NSTEP + t + 3) & 3);
+                else load_step(nb0, nb1, t + 3 - NSTEP, (u * NSTEP + t + 3) & 3);
+#endif
 #pragma unroll
-            for (int t = 0; t < NSTEP; ++t) {  // fragments of steps 0..2 are already in flight (issued before the previous epilogue)
-                if (t + 3 < NSTEP) load_step(bp, t + 3);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
-                    else if (t < 64) cw_mfma_a(acc[j], wf[t], bb[t & 3][j]);
-                    else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (t < 64) cw_mfma_a(acc[q][j], wf[t], bb[(u * NSTEP + t) & 3][j]);
+                    else cw_mfma_v(acc[q][j], wf[t], bb[(u * NSTEP + t) & 3][j]);
                 }
-                // the next tile's DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the barrier
-                // at the end of the previous tile)
-                if (u == 0 && t % 3 == 1 && t / 3 < NPIECE) dma_piece(nsrc, ndst, has_next, t / 3);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (u == 1) {
-                // Everything this wave has in flight is at least one unit old (DMA pieces, unit 0's stores, the residual): a
-                // free wait.  After the barrier all pieces of the next tile have landed and this buffer may be overwritten.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                CV_BARRIER();
-            }
-            {   // the next unit's first fragments (unit 1 of this tile / unit 0 of the next tile in the other buffer) fly while
-                // the epilogue below runs
-                const unsigned char* bpn[4];
+                // ---- riders of this k-step -------------------------------------------------------------------------------------
+                if constexpr (t == NSTEP - 6) acc[pq][0] = *bias_ptr;  // next unit's accumulators start from the bias
+                if constexpr (t == NSTEP - 5) acc[pq][1] = *bias_ptr;
+#ifdef CP_ABL_NO_RESLOAD
+                if constexpr (false) {
+#else
+                if constexpr (RES && t >= SC::RL0 && t < SC::RL0 + 4) {  // this unit's residual, two 8-byte loads per k-step (used by the epilogue inside the next unit)
+#endif
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bpn[j] = (u == 0 ? Xs : Xn) + (lmap[(1 - u) * 4 + j] & 0xffffu);
-                load_step(bpn, 0);
-                load_step(bpn, 1);
-                load_step(bpn, 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // MFMA results -> VALU reads: the asm MFMAs are opaque to the hazard recogniser, so the wait states are explicit
-            // (the accumulators are operands so that no read of them can be scheduled above the nops)
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    float v0 = acc[j][rq * 4 + 0], v1 = acc[j][rq * 4 + 1], v2 = acc[j][rq * 4 + 2], v3 = acc[j][rq * 4 + 3];
-                    if (RES) {
-                        const cv_u32x2 r2 = rr[j][rq];
-                        v0 += cv_bf16_lo(r2.x);
-                        v1 += cv_bf16_hi(r2.x);
-                        v2 += cv_bf16_lo(r2.y);
-                        v3 += cv_bf16_hi(r2.y);
+                    for (int k = 0; k < 2; ++k) {
+                        const int s = (t - SC::RL0) * 2 + k, j = s >> 2, rq = s & 3;
+                        const unsigned gq = (lmap[u * 2 + j] >> 16) * 16u + (unsigned)(hi * 8);
+                        rr[q][j][rq] = *(const cv_u32x2*)(rbase + rq * CT_GBLK + gq);
                     }
-                    const unsigned gq = (lmap[u * 4 + j] >> 16) * 16u + (unsigned)(hi * 8);  // (position, this lane's 4-cout slot) in a chunk block
-                    *(cv_u32x2*)(ybase + rq * CT_GBLK + gq) =
-                        (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(v0, v1), lo16), cw_pk_max_i16(cw_pk_bf16(v2, v3), lo16)};
                 }
+#ifndef CP_ABL_NO_DMA  // CP_ABL_*: ablation switches of tools/probes/conv_pipe_probe.hip, never defined in the product build
+#if defined(CP_ABL_DMA_MASK0)
+                if constexpr (SC::dma_at(u, t, NPIECE) >= 0) dma_piece(nsrc, ndst, false, SC::dma_at(u, t, NPIECE));
+#elif defined(CP_ABL_DMA_SAMESRC)
+                if constexpr (SC::dma_at(u, t, NPIECE) >= 0) dma_piece(x + (size_t)blockIdx.x * XTILE, ndst, has_next, SC::dma_at(u, t, NPIECE));
+#else
+                if constexpr (SC::dma_at(u, t, NPIECE) >= 0) dma_piece(nsrc, ndst, has_next, SC::dma_at(u, t, NPIECE));
+#endif
+#endif
+#ifndef CP_ABL_NO_EPI
+                if constexpr (RES) {
+                    if constexpr (SC::res_at(t) >= 0) epi(pq, pmb, pout, SC::res_at(t) / 3, SC::res_at(t) % 3, pstore);
+                } else if constexpr (SC::plain_at(t) >= 0) {
+                    epi(pq, pmb, pout, SC::plain_at(t), 2, pstore);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }, typename CpMakeSeq<NSTEP>::type{});
+        };
+        unit(CpInt<0>{});
+        unit(CpInt<1>{});
+        unit(CpInt<2>{});
+        unit(CpInt<3>{});
+        yprev = ybase;
+    }
+#ifdef CP_PROBE_CYCLES
+    if (threadIdx.x == 0) CP_PROBE_CYCLES[blockIdx.x] = (long long)it;
+#endif
+    // epilogue of the very last unit (accumulator set 1, column tiles 6 and 7)
+    if (it > 0) {
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[1][0]), "+v"(acc[1][1]));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (RES) {
+                epi(1, 6, yprev, s, 0, true);
+                epi(1, 6, yprev, s, 1, true);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            epi(1, 6, yprev, s, 2, true);
         }
     }
 }
