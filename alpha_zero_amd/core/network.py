@@ -171,10 +171,10 @@ class InferenceNet(nn.Module):
                 and x.shape[2] == 9 and x.shape[3] == 9 and x.is_contiguous(memory_format=torch.channels_last))
 
     def _tiled_tower_ok(self, x):
-        """Shapes with a weight-stationary tower kernel (azsp_conv3x3_tiled): 9x9 planes x 128 filters (Go 9x9) and 17x17 planes x 64
-        filters (the 13x13 Gomoku network after its pad-3 stem)."""
+        """Shapes with a weight-stationary tower kernel (azsp_conv3x3_tiled): 9x9 planes x 128 filters (Go 9x9), 17x17 planes x 64
+        filters (the 13x13 Gomoku network after its pad-3 stem) and 19x19 planes x 256 filters (the jumbo Go network)."""
         return (self.binding is not None and self.use_fused_conv and self.use_tiled_tower and x.is_cuda and x.dtype == torch.bfloat16
-                and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17))
+                and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17), (256, 19))
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     def _conv(self, x, i, res=None):
@@ -235,8 +235,8 @@ class InferenceNet(nn.Module):
 
     def supports_tiled_features(self, board_size, device):
         """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled): 9x9 Go with 128
-        filters (pad-1 stem) and 13x13 Gomoku with 64 filters (pad-3 stem, 17x17 planes)."""
-        shape_ok = (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 13, 3))
+        filters (pad-1 stem), 13x13 Gomoku with 64 filters (pad-3 stem, 17x17 planes) and 19x19 Go with 256 filters."""
+        shape_ok = (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 13, 3), (256, 19, 1))
         return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and shape_ok
                 and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
 
@@ -263,7 +263,8 @@ class InferenceNet(nn.Module):
             self._head_key = (B, feat.device)
         ck(dll.azsp_head_tiled(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), self._pol.data_ptr(), self._val.data_ptr(),
                                B, S, C, self.npol, self.nval, k1, k2, st), "azsp_head_tiled")
-        fused_fc = self.use_fused_fc and (self.num_actions + 31) // 32 in (3, 6) and (self.fc_width + 31) // 32 in (2, 4)
+        nt = ((self.num_actions + 31) // 32, (self.fc_width + 31) // 32)
+        fused_fc = self.use_fused_fc and nt in ((3, 2), (3, 4), (6, 2), (6, 4), (12, 8))
         if not fused_fc:
             return self._fc_heads(self._pol[:B, : self.npol * S * S], self._val[:B, : self.nval * S * S], priors_out, values_out)
         pri = priors_out if priors_out is not None else self._pri

@@ -7,6 +7,7 @@
 
 #include "azsp_impl.h"
 #include "az_conv64.h"
+#include "az_conv19.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -126,6 +127,22 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
                                bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
         return AZ_HIP(hipGetLastError());
     }
+    if (S == C9_S && C == 256) {  // 19x19 boards, 256 filters (jumbo Go network): two launches, one per 128-channel half of the input
+        const int n_cu = cu_count();
+        if (n_cu < 0) return -1;
+        if (x == y || res == y) return 1;  // y holds the partial sum between the launches
+        const long long nst = boards < n_cu / 4 ? boards : n_cu / 4;
+        const dim3 grid((unsigned)(4 * nst)), block(CW_THREADS);
+        if (res)
+            hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                               (const unsigned char*)res, (unsigned char*)y, (int)boards, 0, 1, 256, 0, 32, 0);
+        else
+            hipLaunchKernelGGL((k_conv3x3_hb19<false, 16>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                               (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, 0, 1, 256, 0, 32, 0);
+        hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                           (const unsigned char*)y, (unsigned char*)y, (int)boards, relu, 0, 256, 128, 32, 16);
+        return AZ_HIP(hipGetLastError());
+    }
     if (S != CV_S || C != CV_C) return 1;
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
@@ -146,6 +163,12 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
         const unsigned grid = (unsigned)(boards < n_cu ? boards : n_cu);
         hipLaunchKernelGGL((k_conv3x3_t64<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
                            bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+        return AZ_HIP(hipGetLastError());
+    }
+    if (S == C9_S && C == 256 && pad == 1) {  // 19x19 Go: 17 planes (padded to 32) -> 256 filters, one launch
+        const long long nst = boards < n_cu / 4 ? boards : n_cu / 4;
+        hipLaunchKernelGGL((k_conv3x3_hb19<false, 4>), dim3((unsigned)(4 * nst)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                           (const unsigned short*)w, bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu, 1, 32, 0, 4, 0);
         return AZ_HIP(hipGetLastError());
     }
     if (S != CV_S || C != CV_C || pad != 1) return 1;
@@ -174,7 +197,7 @@ int launch_fc_heads(const FcHeadsArgs& a, void* st) {
                            a.w2, a.b2, a.priors, a.values, a.boards, a.A);                                                               \
         return AZ_HIP(hipGetLastError());                                                                                               \
     }
-    AZ_FC_CASE(3, 2) AZ_FC_CASE(3, 4) AZ_FC_CASE(6, 2) AZ_FC_CASE(6, 4)
+    AZ_FC_CASE(3, 2) AZ_FC_CASE(3, 4) AZ_FC_CASE(6, 2) AZ_FC_CASE(6, 4) AZ_FC_CASE(12, 8)
 #undef AZ_FC_CASE
     return 1;
 }

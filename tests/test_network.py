@@ -186,6 +186,49 @@ def test_gpu_tiled_conv3x3_matches_torch(boards):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 2, 5, 70, 130])
+def test_gpu_tiled_conv3x3_go19_256_matches_torch(boards):
+    """BASELINE C5 shape (19x19 planes x 256 filters, training_go_jumbo.py:46): the half-board weight-stationary kernel, two
+    launches per convolution (one per 128-channel half of the input, partial sum in place), vs an fp32 torch convolution.
+    1..3 boards per tile stream, with / without residual and ReLU."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    _tiled_roundtrip_and_conv(bnd, boards, 256, 19, "cuda")
+    if boards in (5, 70):
+        _tiled_roundtrip_and_conv(bnd, boards, 256, 19, "cuda", relu=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 3, 66])
+def test_gpu_stem_head_tiled_go19_256_match_torch(boards):
+    from alpha_zero_amd import _lib
+
+    _stem_head_checks(_lib.load(), boards, 256, 19, "cuda")
+
+
+@pytest.mark.gpu
+def test_gpu_go19_256_network_tiled_forward_matches_fp32():
+    """The whole C5-shaped evaluator (stem, tower, heads, FC layers; fewer blocks) on the hand-written kernels vs the fp32 module."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(3)
+    net = AlphaZeroNet((17, 19, 19), 362, 3, 256, 256)
+    with torch.no_grad():
+        net.policy_head[4].weight.mul_(0.2)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    assert inf.supports_tiled_features(19, "cuda")
+    x = (torch.rand(9, 17, 19, 19) > 0.6).float()
+    pri, v = inf.forward_tiled(eu.tile_features(x).cuda(), 9, 19)
+    logits, vr = net.eval()(x)
+    dp, dv = (pri.cpu() - torch.softmax(logits, -1)).abs().max().item(), (v.cpu() - vr.squeeze(1)).abs().max().item()
+    assert dp <= 2e-2 and dv <= 3e-2, (dp, dv)
+    p2, v2 = inf(x.cuda())  # NCHW entry: library stem, tiled tower
+    assert (p2.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v2.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
+
+
+@pytest.mark.gpu
 def test_gpu_tiled_tower_equals_rowmajor_tower(golden_dir):
     """InferenceNet with the tiled tower vs the same network through the channels-last kernels: same bf16 operands and
     accumulation order per output, so the outputs agree to bf16 rounding of the intermediate activations."""
