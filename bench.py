@@ -367,10 +367,11 @@ def main(argv=None):
                         ctraffic = pj.get("hbm_bytes_per_launch")
                 except Exception:
                     ctraffic = None
-            roofline = {"kernel": ("k_conv3x3_tiled" if S_t == 9 else "k_conv3x3_t64") + " (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)",
+            kname = {9: "k_conv3x3_tiled", 17: "k_conv3x3_t64", 19: "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get(S_t, "conv3x3")
+            roofline = {"kernel": kname + " (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)",
                         "bound": "mfma",
                         "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5), "traffic": ctraffic,
-                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * 2.5),
+                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * (4.5 if S_t == 19 else 2.5)),
                         "avg_launch_ms": round(conv["avg_ms"], 4), "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4),
                         "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4), "launches_per_step": 2 * args.blocks,
                         "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4)}

@@ -40,6 +40,7 @@ def test_gpu_search_and_actor_match_reference(name):
     ("go", 5, 48, 4, 16, 60, dict(resign_threshold=-0.3, resign_disabled=False, check_resign_after_steps=5)),
     ("go", 13, 64, 8, 2, 16, {}),
     ("go", 19, 64, 8, 2, 10, {}),
+    ("go", 19, 800, 8, 1, 3, {}),   # BASELINE C5's budget: 800 sims/move, P = 8 (node pool 832 records of 5.6 KB)
     ("gomoku", 13, 200, 8, 4, 24, {}),
     ("gomoku", 7, 40, 1, 8, 49, {}),
     ("gomoku", 15, 64, 8, 2, 20, {}),

@@ -30,6 +30,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 CONFIGS = {
     # 9x9 Go, the BASELINE workload shape: parallel search, P=8, 200 sims, full self-play games
     "go9_p8_s200": dict(game="go", n=9, sims=200, parallel=8, games=2, seed=11, resign_threshold=-1.0, resign_disabled=True, max_moves=60),
+    # BASELINE C4's budget (400 sims/move, P = 8)
+    "go9_p8_s400": dict(game="go", n=9, sims=400, parallel=8, games=1, seed=31, resign_threshold=-1.0, resign_disabled=True, max_moves=36),
     "go9_p1_s50": dict(game="go", n=9, sims=50, parallel=1, games=2, seed=12, resign_threshold=-1.0, resign_disabled=True, max_moves=40),
     # tiny boards: games finish, terminal nodes are reached inside the tree, passes, max_steps
     "go5_p8_s64": dict(game="go", n=5, sims=64, parallel=8, games=4, seed=13, resign_threshold=-1.0, resign_disabled=True),
