@@ -120,7 +120,7 @@ class InferenceNet(nn.Module):
                 convs.append(_fold(blk.conv_block1[0], blk.conv_block1[1]))
                 convs.append(_fold(blk.conv_block2[0], blk.conv_block2[1]))
             self.n_blocks = len(net.res_blocks)
-            # fused MFMA convolution (azsp_conv3x3): weights as [tap = ky*3+kx][cout][cin] bf16, bias fp32
+            # hand-written MFMA convolutions (azsp_conv3x3_tiled): weights as [tap = ky*3+kx][cout][cin] bf16, bias fp32
             self.filters = net.conv_block[0].out_channels
             self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
                                                      requires_grad=False) for w, _ in convs[1:]])
@@ -166,10 +166,6 @@ class InferenceNet(nn.Module):
             self.num_actions, self.fc_width = net.policy_head[4].weight.shape[0], net.value_head[4].weight.shape[0]
             self.use_fused_fc = True
 
-    def _fused_conv_ok(self, x):
-        return (self.binding is not None and self.use_fused_conv and x.is_cuda and x.dtype == torch.bfloat16 and self.filters == 128
-                and x.shape[2] == 9 and x.shape[3] == 9 and x.is_contiguous(memory_format=torch.channels_last))
-
     def _tiled_tower_ok(self, x):
         """Shapes with a weight-stationary tower kernel (azsp_conv3x3_tiled): 9x9 planes x 128 filters (Go 9x9), 17x17 planes x 64
         filters (the 13x13 Gomoku network after its pad-3 stem) and 19x19 planes x 256 filters (the jumbo Go network)."""
@@ -178,18 +174,8 @@ class InferenceNet(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     def _conv(self, x, i, res=None):
-        """relu(conv3x3(x) + bias [+ res]) of tower convolution i (0-based): one hand-written MFMA kernel when the shape is
-        supported, else the library convolution followed by the fused epilogue kernel."""
-        if self._fused_conv_ok(x):
-            import ctypes
-
-            y = torch.empty_like(x)
-            rc = self.binding.dll.azsp_conv3x3(x.data_ptr(), self.wp[i].data_ptr(), self.b32[i].data_ptr(), res.data_ptr() if res is not None else None,
-                                               y.data_ptr(), x.shape[0], x.shape[2], x.shape[1], 1,
-                                               ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
-            if rc != 0:
-                raise RuntimeError(f"azsp_conv3x3 failed with code {rc}")
-            return y
+        """relu(conv3x3(x) + bias [+ res]) of tower convolution i (0-based) for shapes WITHOUT a hand-written tower kernel: the library
+        convolution followed by the fused epilogue kernel (see `evaluator_path`)."""
         return self._epilogue(F.conv2d(x, self.w[1 + i], None, padding=1), self.b[1 + i], res)
 
     def _epilogue(self, y, bias, res=None):
@@ -232,6 +218,17 @@ class InferenceNet(nn.Module):
                                       B, S, C, 1, st), "azsp_conv3x3_tiled")
             a, o = o, a
         return a
+
+    def evaluator_path(self, board_size, device):
+        """Which kernels the forward pass of this network runs on `device` -- reported by bench.py (`config.evaluator`) and logged
+        once by SelfPlayActor, so that an unsupported shape never degrades silently to the library path."""
+        if self.supports_tiled_features(board_size, device):
+            return "hand-written: tiled stem / tower / head / FC kernels (libazsp)"
+        if torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and self.binding is not None:
+            s = board_size + 2 * (self.stem_pad - 1)
+            if (self.filters, s) in ((128, 9), (64, 17), (256, 19)):
+                return "hand-written tower (azsp_conv3x3_tiled) behind a library stem and heads"
+        return f"library convolutions + azsp_bias_act epilogue (no hand-written kernel for {self.filters} filters on {board_size}x{board_size}, {self.dtype})"
 
     def supports_tiled_features(self, board_size, device):
         """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled): 9x9 Go with 128

@@ -72,6 +72,12 @@ class SelfPlayActor:
         self.use_graph = use_graph and self.device.type == "cuda"
         probe = InferenceNet(network, dtype=net_dtype, binding=self.binding if self.device.type == "cuda" else None)
         self.tiled_features = probe.supports_tiled_features(board_size, self.device) if tiled_features is None else bool(tiled_features)
+        self.evaluator_path = probe.evaluator_path(board_size, self.device) if self.tiled_features or tiled_features is None else \
+            "library stem (tiled features disabled by the caller)"
+        if self.device.type == "cuda" and not self.tiled_features and net_dtype == torch.bfloat16:
+            import warnings
+
+            warnings.warn(f"alpha_zero_amd: evaluator falls back to {self.evaluator_path}", RuntimeWarning, stacklevel=2)
         self.cfg = EngineConfig(
             game=game, board_size=board_size, num_games=num_games, num_parallel=num_parallel, num_simulations=num_simulations,
             c_puct_base=c_puct_base, c_puct_init=c_puct_init, warm_up_steps=warm_up_steps, komi=komi, num_to_win=num_to_win,

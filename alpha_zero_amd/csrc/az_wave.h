@@ -6,9 +6,8 @@
 //   * `Wv::lanes(f)` runs f(lane) on every lane (SPMD section; lanes only write their own data),
 //   * `Wv::ballot / any / argmax_first / sum_*` are the cross-lane primitives.
 // `WaveDev` maps these to CDNA4 wave64 hardware (v_cmp -> 64-bit ballot masks, DPP/bpermute
-// reductions).  `WaveHost` replays the same sections with a 64-iteration loop; it exists so
-// the *identical* engine source can be unit-tested on a machine without a GPU (tests/hosttwin,
-// never linked into the product library).
+// reductions).  (tests/hosttwin/az_host_policies.h holds a `WaveHost` that replays the same sections with a
+// 64-iteration loop so that the *identical* engine source can be unit-tested without a GPU; it is not part of the product.)
 #pragma once
 #include <stdint.h>
 
@@ -98,49 +97,8 @@ struct WaveDev {
 };
 #endif
 
-struct WaveHost {
-    static bool first() { return true; }
-    template <class F> static void lanes(F&& f) {
-        for (int l = 0; l < AZ_WAVE; ++l) f(l);
-    }
-    template <class F> static u64 ballot(F&& f) {
-        u64 m = 0;
-        for (int l = 0; l < AZ_WAVE; ++l)
-            if (f(l)) m |= 1ull << l;
-        return m;
-    }
-    static void sync() {}
-    template <class F> static int argmax_first(F&& f) {
-        double best = -1.0e300;
-        int bi = 0x7fffffff;
-        for (int l = 0; l < AZ_WAVE; ++l) {
-            double s = -1.0e300;
-            int idx = -1;
-            f(l, s, idx);
-            if (idx < 0) continue;
-            if (s > best || (s == best && idx < bi)) {
-                best = s;
-                bi = idx;
-            }
-        }
-        return bi;
-    }
-    static int bcast0(int v) { return v; }
-    template <class T> static T uni(T v) { return v; }
-    template <class F> static double sum_f64(F&& f) {
-        // same butterfly order as the device so that non-integer sums (production noise) agree as well
-        double v[AZ_WAVE];
-        for (int l = 0; l < AZ_WAVE; ++l) v[l] = f(l);
-        for (int o = 32; o > 0; o >>= 1) {
-            double w[AZ_WAVE];
-            for (int l = 0; l < AZ_WAVE; ++l) w[l] = v[l] + v[l ^ o];
-            for (int l = 0; l < AZ_WAVE; ++l) v[l] = w[l];
-        }
-        return v[0];
-    }
-    template <class F> static int sum_i32(F&& f) {
-        int v = 0;
-        for (int l = 0; l < AZ_WAVE; ++l) v += f(l);
-        return v;
-    }
-};
+// The plain-C++ replay of these primitives (`WaveHost`, a 64-iteration loop per section) that lets the CPU test tier run the
+// identical engine source lives in tests/hosttwin/az_host_policies.h; that build defines AZ_HOST_TWIN_POLICIES to pull it in here.
+#if defined(AZ_HOST_TWIN_POLICIES)
+#include AZ_HOST_TWIN_POLICIES
+#endif

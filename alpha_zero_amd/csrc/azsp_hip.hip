@@ -87,22 +87,6 @@ int launch_bias_act(const BiasActArgs& a, void* st) {
     hipLaunchKernelGGL(k_bias_act, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a);
     return AZ_HIP(hipGetLastError());
 }
-int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
-                   void* st) {
-    if (S != CV_S || C != CV_C) return 1;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const long long ntiles = (boards + CV_TB - 1) / CV_TB;
-    const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);  // one persistent workgroup per CU
-    hipLaunchKernelGGL(k_conv3x3_c128_s9, dim3(grid), dim3(CV_THREADS), 0, (hipStream_t)st, (const unsigned short*)x, (const unsigned short*)w, bias,
-                       (const unsigned short*)res, (unsigned short*)y, (int)boards, relu);
-    return AZ_HIP(hipGetLastError());
-}
 static int cu_count() {
     static int n_cu = 0;
     if (n_cu == 0) {

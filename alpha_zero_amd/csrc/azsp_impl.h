@@ -516,8 +516,6 @@ int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
 int launch_bias_act(const BiasActArgs& a, void* stream);
 int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* stream);
 // returns 0 ok, 1 unsupported shape, -1 launch error
-int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
-                   void* stream);
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
@@ -561,11 +559,14 @@ template <class Op> static int az_run(AzHandle* h, const Op& op, void* stream) {
     return AZSP_OK;
 }
 
+#ifndef AZ_GEOM_WAVE
+#define AZ_GEOM_WAVE WaveDev  // only the policy-independent constants of Engine<> are used here
+#endif
 static int az_geometry_of(int game, int n, int* A, int* AP, int* W, int* REC, int* GREC) {
     switch (game * 100 + n) {
 #define AZ_CASE(NN, GG)                              \
     case (GG) * 100 + (NN): {                        \
-        typedef Engine<WaveHost, NN, GG> E;          \
+        typedef Engine<AZ_GEOM_WAVE, NN, GG> E;       \
         *A = E::A; *AP = E::AP; *W = E::W; *REC = E::REC; *GREC = E::GREC; \
         return 0;                                    \
     }
@@ -936,14 +937,6 @@ int azsp_bias_act(void* y, const void* bias, const void* res, int64_t rows, int3
     if (rows == 0) return AZSP_OK;
     BiasActArgs a = {y, bias, res, (long long)rows * channels / 8, channels, dtype, relu};
     return azb::launch_bias_act(a, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
-}
-
-int azsp_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
-                 int32_t relu, void* stream) {
-    if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
-    if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_conv3x3(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
-    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
 int64_t azsp_tiled_bytes(int64_t boards, int32_t S, int32_t C) {

@@ -417,7 +417,7 @@ def main(argv=None):
             "dtype": args.net_dtype, "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
                                    f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",
-                       "evaluator": "tiled layout, hand-written stem / tower / head kernels" if actor.tiled_features else "library convolutions + fused epilogue",
+                       "evaluator": actor.evaluator_path,
                        "games_per_gpu": args.games, "stagger_plies": args.stagger, "hip_graph_forward": not args.no_graph,
                        "parallelism": f"games sharded x{world}, sample gather to rank 0"},
             "sims_per_sec": round(total_sims / elapsed_max, 1), "evals_per_sec": round(total_evals / elapsed_max, 1),

@@ -29,7 +29,7 @@
  *   azsp_dihedral                     apply_horizontal_flip / apply_vertical_flip / apply_rotation
  *                                     (utils/transformation.py:34-110)
  *   azsp_bias_act                     BatchNorm + residual add + ReLU after each convolution (core/network.py:42-82)
- *   azsp_conv3x3 / azsp_conv3x3_tiled a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
+ *   azsp_conv3x3_tiled                a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
  *   azsp_tile_layout / azsp_tiled_bytes the tower's resident activation layout
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
@@ -221,13 +221,6 @@ int azsp_dihedral(const void* states_in_dev, void* states_out_dev, int32_t state
 int azsp_bias_act(void* y_dev, const void* bias_dev, const void* residual_dev, int64_t rows, int32_t channels, int32_t dtype,
                   int32_t relu, void* stream);
 
-/* Fused 3x3 convolution of the residual tower (core/network.py:42-82, eval mode, BatchNorm folded):
- * y = act(conv3x3(x, w) + bias [+ residual]) on channels-last bf16 activations [boards][S][S][C]; w_packed is
- * [9 taps (ky*3+kx)][C out][C in] bf16, bias float[C].  MFMA implicit GEMM; supported on the device for S = 9, C = 128
- * (returns AZSP_EINVAL otherwise so the caller can use its library convolution + azsp_bias_act). */
-int azsp_conv3x3(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
-                 int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
-
 /* The residual tower's resident activation layout ("tiled"): [tile = T boards][C/8 channel chunks][T*S*S positions][8 ch]
  * bf16 with T = max(1, 256 / (S*S)) boards per tile (3 at 9x9, 1 from 13x13 up), azsp_tiled_bytes(boards, S, C) bytes.  A tile is what one workgroup of azsp_conv3x3_tiled multiplies at a time:
  * its LDS image equals its global image (flat LDS-DMA copy), fragment reads are conflict-free with immediate k offsets,
@@ -237,8 +230,11 @@ int azsp_conv3x3(const void* x_dev, const void* w_packed_dev, const float* bias_
 int64_t azsp_tiled_bytes(int64_t boards, int32_t board_size, int32_t channels);
 int azsp_tile_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t to_tiled,
                      void* stream);
-/* azsp_conv3x3 on the tiled layout (x, residual, y all tiled; same w_packed / bias): weight-stationary MFMA kernel, the
- * filter bank stays in registers of a persistent workgroup.  S = 9, C = 128 on the device (AZSP_EINVAL otherwise). */
+/* Fused 3x3 convolution of the residual tower (core/network.py:42-82, eval mode, BatchNorm folded) on the tiled layout:
+ * y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y tiled bf16, w_packed [9 taps (ky*3+kx)][C out][C in] bf16, bias
+ * float[C].  Weight-stationary MFMA kernels, the filter bank stays in the registers of persistent workgroups.  On the device:
+ * (S, C) = (9, 128) 9x9 Go, (17, 64) the 13x13 Gomoku tower, (19, 256) the jumbo Go tower (two launches per convolution, the
+ * partial sum lives in y: x and residual must not alias y); AZSP_EINVAL for other shapes. */
 int azsp_conv3x3_tiled(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                        int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
 

@@ -43,7 +43,7 @@ def check_elo_and_resign(golden_dir):
     rc = ResignController(-0.9, no_resign_games=100, reset_fp_interval=1000, games_per_ckpt=400, disable_resign_ratio=0.1, target_fp_rate=0.05)
     marked = {"is_resign_disabled": True, "is_marked_for_resign": True, "is_could_won": True}
     plain = {"game_length": 50}
-    assert rc.on_game(marked, 50) == -0.9 and rc.resign_count == 0  # before no_resign_games: ignored
+    assert rc.threshold == -1 and rc.on_game(marked, 50) == -1 and rc.resign_count == 0  # warm-up: resignation off (pipeline.py:453-456)
     assert rc.on_game(marked, 100) == -0.9 and rc.resign_count == 0  # the hard reset at no_resign_games
     n = 100
     for i in range(9):

@@ -7,7 +7,10 @@
 #include <vector>
 #include <stdlib.h>
 
+#define AZ_HOST_TWIN_POLICIES "../../tests/hosttwin/az_host_policies.h"
+#define AZ_GEOM_WAVE WaveHost
 #include "../../alpha_zero_amd/csrc/azsp_impl.h"
+#include "cv_host.h"
 
 namespace azb {
 void* alloc(size_t n) { return calloc(1, n); }
@@ -36,10 +39,6 @@ int launch_replay_gather(const ReplayGatherArgs& a, long long total, void*) {
 }
 int launch_bias_act(const BiasActArgs& a, void*) {
     for (long long i = 0; i < a.nvec; ++i) az_bias_act_vec(a, i);
-    return 0;
-}
-int launch_conv3x3(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void*) {
-    cv_host_conv3x3((const unsigned short*)x, (const unsigned short*)w, bias, (const unsigned short*)res, (unsigned short*)y, (int)boards, S, C, relu);
     return 0;
 }
 // tiled layout on the host: [tile][C/8][3*S*S][8] <-> channels-last rows, then the plain loop

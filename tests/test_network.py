@@ -76,52 +76,6 @@ def _conv_ref(x, w, b, res):
     return torch.relu(y)
 
 
-def test_fused_conv_abi_host_twin():
-    """azsp_conv3x3 through the ABI (host twin: plain loop restatement) vs torch conv2d on a tiny case."""
-    import engine_util as eu
-
-    b = eu.hosttwin_binding()
-    g = torch.Generator().manual_seed(1)
-    C, S, B = 16, 5, 2
-    x = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    res = torch.randn(B, C, S, S, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(C, C, 3, 3, generator=g) * 0.2).to(torch.bfloat16)
-    bias = torch.randn(C, generator=g)
-    wp = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
-    for r in (None, res):
-        y = torch.empty_like(x)
-        rc = b.dll.azsp_conv3x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(), B, S, C, 1, None)
-        assert rc == 0
-        ref = _conv_ref(x, w, bias, r)
-        assert (y.float() - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("boards", [1, 3, 7, 1000])
-def test_gpu_fused_conv3x3_matches_torch(boards):
-    """The MFMA kernel (9x9, 128 channels, bf16) vs an fp32 torch convolution of the same bf16 operands; tolerance = bf16
-    output rounding.  Asymmetric random weights catch any row/column or tap mix-up; partial last tiles are covered."""
-    from alpha_zero_amd import _lib
-
-    bnd = _lib.load()
-    g = torch.Generator().manual_seed(boards)
-    C, S = 128, 9
-    x = torch.randn(boards, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
-    res = torch.randn(boards, C, S, S, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16).cuda()
-    bias = torch.randn(C, generator=g).cuda()
-    wp = w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
-    for r in (None, res):
-        y = torch.empty_like(x)
-        rc = bnd.dll.azsp_conv3x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None, y.data_ptr(),
-                                  boards, S, C, 1, None)
-        torch.cuda.synchronize()
-        assert rc == 0
-        ref = _conv_ref(x, w, bias, r)
-        err = (y.float() - ref).abs().max().item()
-        assert err <= 1.0 / 128 * max(1.0, ref.abs().max().item()), err
-
-
 def _tiled_roundtrip_and_conv(bnd, boards, C, S, device, relu=1):
     """Shared by the host-twin and GPU tiers: layout round trip exact; tiled conv == fp32 torch conv within bf16 rounding."""
     g = torch.Generator().manual_seed(100 + boards)
@@ -226,22 +180,6 @@ def test_gpu_go19_256_network_tiled_forward_matches_fp32():
     assert dp <= 2e-2 and dv <= 3e-2, (dp, dv)
     p2, v2 = inf(x.cuda())  # NCHW entry: library stem, tiled tower
     assert (p2.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v2.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
-
-
-@pytest.mark.gpu
-def test_gpu_tiled_tower_equals_rowmajor_tower(golden_dir):
-    """InferenceNet with the tiled tower vs the same network through the channels-last kernels: same bf16 operands and
-    accumulation order per output, so the outputs agree to bf16 rounding of the intermediate activations."""
-    from alpha_zero_amd import _lib
-
-    torch.manual_seed(5)
-    net = AlphaZeroNet((17, 9, 9), 82, 3, 128, 64)
-    a = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
-    x = (torch.rand(50, 17, 9, 9) > 0.6).float().cuda()
-    p1, v1 = a(x)
-    a.use_tiled_tower = False
-    p2, v2 = a(x)
-    assert (p1 - p2).abs().max().item() <= 5e-3 and (v1 - v2).abs().max().item() <= 2e-2
 
 
 def _stem_head_checks(bnd, boards, C, S, device, pad=1):
