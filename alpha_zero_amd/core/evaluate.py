@@ -97,6 +97,85 @@ def eval_against_prev_ckpt(env, black_player, white_player, black_elo, white_elo
     return stats
 
 
+def play_eval_games_parallel(game, board_size, players, num_simulations, num_parallel, c_puct_base, c_puct_init, komi=7.5, num_to_win=5,
+                             binding=None, device="cuda", max_rounds=1 << 20):
+    """SURVEY 8f-2 "many in parallel": G evaluation games of pipeline.py:815-867 advance in lock-step on ONE engine.
+
+    players: one (black_eval, white_eval) pair per game; eval(states int8[B,17,N,N], True) -> (list of pi, list of v) with the
+    reference's eval_func contract (pipeline.py:91-123).  Every game is what eval_against_prev_ckpt plays: no root noise, arg-max
+    moves, a fresh tree for every move (`root_node=None`, pipeline.py:836), the searching player's own evaluator for all leaves of
+    its search.  The whole game runs inside the engine (search, move, env step, termination, scoring); per round the host only routes
+    the leaf rows of each game to the evaluator of the side to move.  Returns per game dict(moves, game_length, game_result,
+    num_passes, winner) -- the same games, move for move, as G sequential calls (tests/arena_checks.py)."""
+    import torch
+
+    from .. import _abi, _lib
+    from .engine import Engine, EngineConfig
+    from .pipeline import game_stats_from_row
+
+    binding = binding or _lib.load(require_gpu=True)
+    G = len(players)
+    cfg = EngineConfig(game=game, board_size=board_size, num_games=G, num_parallel=num_parallel, num_simulations=num_simulations,
+                       c_puct_base=c_puct_base, c_puct_init=c_puct_init, root_noise=False, deterministic=True, reuse_tree=False, warm_up_steps=-1,
+                       komi=komi, num_to_win=num_to_win, resign_threshold=-1.0, stop_at_game_end=True, feature_dtype=_abi.FEAT_I8)
+    eng = Engine(binding, cfg, device=device)
+    eng.reset_games()
+    A, P = eng.A, num_parallel
+    for _ in range(max_rounds):
+        eng.expand_backup()
+        eng.select()
+        st, _ = eng.status()
+        if np.all(st[:, 0] == _abi.ST_IDLE):
+            break
+        valid = eng.valid.cpu().numpy().astype(bool).reshape(G, P)
+        feats = eng.features.cpu().numpy().reshape(G, P, 17, board_size, board_size)
+        pri = np.zeros((G, P, A), dtype=np.float32)
+        val = np.zeros((G, P), dtype=np.float32)
+        for g in range(G):
+            rows = np.flatnonzero(valid[g])
+            if len(rows) == 0:
+                continue
+            ev = players[g][int(st[g, 1]) & 1]  # ply even: black is searching
+            ps, vs = ev(feats[g, rows], True)
+            for r, p_, v_ in zip(rows, ps, vs):
+                pri[g, r], val[g, r] = np.asarray(p_, dtype=np.float32), v_
+        eng.priors.copy_(torch.from_numpy(pri.reshape(G * P, A)))
+        eng.values.copy_(torch.from_numpy(val.reshape(G * P)))
+    else:
+        raise RuntimeError("evaluation games did not finish")
+    got = eng.harvest(sample_capacity=G * eng.geo.stage_capacity, max_games=G, with_moves=True)  # room for every game at full length
+    games, moves = got[3], got[4].cpu().numpy()
+    out = [None] * G
+    for row in games:
+        g, s0, ln = int(row[15]), int(row[0]), int(row[1])
+        stats = game_stats_from_row(row, game, komi)
+        out[g] = dict(moves=[int(m) for m in moves[s0:s0 + ln]], game_length=stats["game_length"], game_result=stats["game_result"],
+                      num_passes=stats.get("num_passes"), winner=int(row[2]))
+    eng.close()
+    assert all(o is not None for o in out)
+    return out
+
+
+def eval_many_against_prev_ckpt(game, board_size, players, elos, num_simulations, num_parallel, c_puct_base, c_puct_init, **kw):
+    """G evaluation games at once + the Elo bookkeeping of eval_against_prev_ckpt applied in game order: `elos` is one (black_elo,
+    white_elo) pair of EloRating objects per game (the same objects may appear in several games, e.g. one checkpoint against its
+    predecessor G times).  Returns the list of stats dicts (the evaluation.csv columns, pipeline.py:851-866)."""
+    res = play_eval_games_parallel(game, board_size, players, num_simulations, num_parallel, c_puct_base, c_puct_init, **kw)
+    black_id = 1
+    out = []
+    for r, (be, we) in zip(res, elos):
+        stats = {"game_length": r["game_length"], "game_result": r["game_result"]}
+        if game == "go":
+            stats["num_passes"] = r["num_passes"]
+        if r["winner"] != 0:
+            winner, loser = (be, we) if r["winner"] == black_id else (we, be)
+            winner.update_rating(loser.rating, 1)
+            loser.update_rating(winner.rating, 0)
+        stats["black_elo_rating"], stats["white_elo_rating"] = be.rating, we.rating
+        out.append(stats)
+    return out, res
+
+
 def maybe_adjust_resign_threshold(current_v, current_rate, target_rate, min_v=-0.9999, smoothing_factor=0.5):
     """pipeline.py:656-670: raise |threshold| only while the measured false-positive rate exceeds the target."""
     rate_delta = current_rate - target_rate

@@ -28,6 +28,36 @@ def check_arena(kind, golden_dir):
             assert moves == list(g[f"{tag}_moves_{k}"])
 
 
+def check_parallel_arena(kind, golden_dir):
+    """SURVEY 8f-2 "many in parallel": G evaluation games in lock-step on one engine reproduce the reference's games move for move
+    and its Elo sequence (golden eval_arena.npz: three consecutive games per configuration), and a colour-swapped pairing equals
+    the sequential drop-in path."""
+    import engine_util as eu
+    from alpha_zero_amd.core.evaluate import EloRating, create_mcts_player, eval_against_prev_ckpt, eval_many_against_prev_ckpt
+
+    binding, dev = eu.backend(kind)
+    g = np.load(os.path.join(golden_dir, "eval_arena.npz"))
+    for tag in ("p1", "p4"):
+        cfg = json.loads(str(g[f"{tag}_cfg"]))
+        want = json.loads(str(g[f"{tag}_stats"]))
+        strong, weak = make_eval_func(26, cfg["sharp_black"]), make_eval_func(26, cfg["sharp_white"])
+        be, we = EloRating(rating=0), EloRating(rating=0)
+        stats, res = eval_many_against_prev_ckpt("go", 5, [(strong, weak)] * 3, [(be, we)] * 3, cfg["sims"], cfg["P"], 19652, 1.25, komi=cfg["komi"],
+                                                 binding=binding, device=dev)
+        for k in range(3):
+            assert stats[k] == want[k], (tag, k, stats[k], want[k])
+            assert res[k]["moves"] == [int(m) for m in g[f"{tag}_moves_{k}"]]
+        # mixed pairings in one batch (colours swapped in slot 1) vs the sequential drop-in evaluator game
+        stats2, res2 = eval_many_against_prev_ckpt("go", 5, [(strong, weak), (weak, strong)], [(EloRating(0), EloRating(0)), (EloRating(0), EloRating(0))],
+                                                   cfg["sims"], cfg["P"], 19652, 1.25, komi=cfg["komi"], binding=binding, device=dev)
+        env = dc.make_env(kind, "go", 5, komi=cfg["komi"])
+        mk = lambda sharp: create_mcts_player(num_simulations=cfg["sims"], num_parallel=cfg["P"], root_noise=False, deterministic=True,
+                                               eval_func=make_eval_func(26, sharp))
+        seq = eval_against_prev_ckpt(env, mk(cfg["sharp_white"]), mk(cfg["sharp_black"]), EloRating(0), EloRating(0), 19652, 1.25)
+        assert stats2[1] == seq and res2[1]["moves"] == [h.move for h in env.history]
+        assert res2[0]["moves"] == [int(m) for m in g[f"{tag}_moves_0"]]
+
+
 def check_elo_and_resign(golden_dir):
     from alpha_zero_amd.core.evaluate import EloRating, ResignController, get_k_factor, maybe_adjust_resign_threshold
 

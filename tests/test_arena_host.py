@@ -20,3 +20,7 @@ def test_checkpoint_dictionary(tmp_path):
     import sgf_checks as sc
 
     sc.check_checkpoint(str(tmp_path))
+
+
+def test_parallel_evaluation_games_match_reference(golden_dir):
+    ac.check_parallel_arena("host", golden_dir)

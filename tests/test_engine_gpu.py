@@ -208,3 +208,11 @@ def test_gpu_run_selfplay_actor_loop(tmp_path):
     from alpha_zero_amd import _lib
 
     tah.check_actor_loop("cuda", _lib.load(), tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_parallel_evaluation_games_match_reference(golden_dir):
+    """several evaluation games (two evaluators, deterministic, fresh tree per move) in lock-step on one device engine."""
+    import arena_checks as ac
+
+    ac.check_parallel_arena("gpu", golden_dir)
