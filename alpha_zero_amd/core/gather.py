@@ -1,8 +1,8 @@
 """Sample gather to the replay rank: replaces `data_queue.put` across actor processes
 (reference: alpha_zero/core/pipeline.py:283 -> learner :485).  One process per GPU; games never interact
-during search, so this is the only exchange on the data path: per harvest, one all_gather of counts and
-point-to-point sends of the finished-game tensors to `dst` (RCCL over xGMI when the backend is "nccl":
-every sender uses its own direct link into the root).  Works unchanged on gloo/CPU tensors (tests)."""
+during search, so this is the only exchange on the data path: per harvest, one all_gather of counts and one
+`gather` per tensor of the finished games to `dst` (RCCL over xGMI when the backend is "nccl": every sender uses
+its own direct link into the root).  Works unchanged on gloo/CPU tensors (tests)."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -11,55 +11,51 @@ import torch.distributed as dist
 def gather_samples(states, pi, z, games, dst=0, group=None):
     """states int8[n,17,N,N], pi f32[n,A], z f32[n] (device tensors of this rank), games int32[k,16] (numpy).
     Returns on `dst` the concatenation over ranks (rank order) with game `start` offsets rebased and column 15
-    (slot) made global as rank*2^20 + slot; on other ranks returns None."""
+    (slot) made global as rank*2^20 + slot; on other ranks returns None.
+
+    Collectives only (every rank takes part in every call, no point-to-point pairing to get wrong): one all_gather of the
+    (samples, games) counts, then one `gather` to `dst` per tensor, padded to the largest count of this harvest.  The volume
+    is ~1.7 KB per sample, a few MB per harvest: padding costs nothing against one xGMI link."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return states, pi, z, games
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = states.device
-    g_t = torch.as_tensor(np.ascontiguousarray(games, dtype=np.int32)).to(dev)
+    g_t = torch.as_tensor(np.ascontiguousarray(games, dtype=np.int32)).reshape(-1, 16).to(dev)
     counts = torch.tensor([states.shape[0], g_t.shape[0]], dtype=torch.int64, device=dev)
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts, group=group)
     all_counts = torch.stack(all_counts).cpu().numpy()
+    maxn, maxk = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
+
+    def gather_padded(t, m):
+        """t [c, ...] -> list over ranks of [m, ...] on dst (None elsewhere); every rank calls with the same m."""
+        pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+        pad[: t.shape[0]] = t
+        out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+        dist.gather(pad, out, dst=dst, group=group)
+        return out
+
+    gs = gather_padded(states, maxn) if maxn else None
+    gp = gather_padded(pi, maxn) if maxn else None
+    gz = gather_padded(z, maxn) if maxn else None
+    gg = gather_padded(g_t, maxk) if maxk else None
     if rank != dst:
-        ops = []
-        if counts[0] > 0:
-            ops += [dist.P2POp(dist.isend, t.contiguous(), dst, group) for t in (states, pi, z)]
-        if counts[1] > 0:
-            ops.append(dist.P2POp(dist.isend, g_t, dst, group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
         return None
     parts_s, parts_p, parts_z, parts_g = [], [], [], []
-    ops, bufs = [], {}
-    for r in range(world):
-        n, k = int(all_counts[r, 0]), int(all_counts[r, 1])
-        if r == dst:
-            bufs[r] = (states, pi, z, g_t)
-            continue
-        bs = torch.empty((n,) + tuple(states.shape[1:]), dtype=states.dtype, device=dev)
-        bp = torch.empty((n,) + tuple(pi.shape[1:]), dtype=pi.dtype, device=dev)
-        bz = torch.empty((n,), dtype=z.dtype, device=dev)
-        bg = torch.empty((k, 16), dtype=torch.int32, device=dev)
-        bufs[r] = (bs, bp, bz, bg)
-        if n > 0:
-            ops += [dist.P2POp(dist.irecv, t, r, group) for t in (bs, bp, bz)]
-        if k > 0:
-            ops.append(dist.P2POp(dist.irecv, bg, r, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
     base = 0
     for r in range(world):
-        bs, bp, bz, bg = bufs[r]
-        gg = bg.cpu().numpy().copy()
-        if len(gg):
-            gg[:, 0] += base
-            gg[:, 15] += r << 20
-        base += bs.shape[0]
-        parts_s.append(bs), parts_p.append(bp), parts_z.append(bz), parts_g.append(gg)
-    return torch.cat(parts_s), torch.cat(parts_p), torch.cat(parts_z), np.concatenate(parts_g) if parts_g else games
+        n, k = int(all_counts[r, 0]), int(all_counts[r, 1])
+        if n:
+            parts_s.append(gs[r][:n]), parts_p.append(gp[r][:n]), parts_z.append(gz[r][:n])
+        if k:
+            rows = gg[r][:k].cpu().numpy().copy()
+            rows[:, 0] += base
+            rows[:, 15] += r << 20
+            parts_g.append(rows)
+        base += n
+    if not parts_s:
+        return states[:0], pi[:0], z[:0], np.zeros((0, 16), dtype=np.int32)
+    return torch.cat(parts_s), torch.cat(parts_p), torch.cat(parts_z), (np.concatenate(parts_g) if parts_g else np.zeros((0, 16), dtype=np.int32))
 
 
 def broadcast_weights(network: torch.nn.Module, src=0, group=None):

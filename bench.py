@@ -127,6 +127,87 @@ def launch_check(world, rank, local_rank):
         print(json.dumps({"launch_check": True, "n_gpus": joined, "world_size_env": world, "backend": backend}), flush=True)
 
 
+# ---- the measurement flow (module level: tests/bench_flow_worker.py drives exactly these functions under gloo, 2 ranks, with a
+# host-twin actor, so the N-rank control flow the driver runs on 8 GPUs -- paired collectives, synchronised pre-roll exit, gather
+# inside the timed region, max-over-ranks timing -- is exercised on CPU; bench.py itself only ever builds GPU actors) -------------
+def barrier(world, dev):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def harvest_and_gather(act):
+    from alpha_zero_amd.core.gather import gather_samples
+
+    st, pi, z, games = act.harvest_tensors()
+    res = gather_samples(st, pi, z, games, dst=0)
+    return 0 if res is None else int(res[0].shape[0])
+
+
+def preroll(act, args, world, dev, min_rounds=None):
+    """Untimed and independent of --steps / --warmup: rounds until every slot has committed >= preroll_moves searched moves
+    (ply advanced, or a game finished) and >= preroll_rounds rounds have passed.  Returns the rounds it took."""
+    e = act.engine
+    st0, _ = e.status()
+    ply0, done0 = st0[:, 1].copy(), st0[:, 5].copy()
+    min_rounds = args.preroll_rounds if min_rounds is None else min_rounds
+    rounds, cap = 0, max(min_rounds, 40 * (args.sims // max(1, args.parallel) + 2))
+    while rounds < cap:
+        act.run_round()
+        rounds += 1
+        if rounds % args.harvest_every == 0:
+            harvest_and_gather(act)
+        if rounds >= min_rounds and rounds % 10 == 0:
+            st, _ = e.status()
+            moved = np.where(st[:, 5] > done0, args.preroll_moves, st[:, 1] - ply0)
+            ok = torch.tensor([1.0 if moved.min() >= args.preroll_moves else 0.0], device=dev)
+            if world > 1:  # all ranks leave the pre-roll together (their harvest / gather calls must stay paired)
+                import torch.distributed as dist
+
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() > 0:
+                break
+    return rounds
+
+
+def timed(act, args, world, dev, warmup, steps):
+    """--warmup untimed rounds, then exactly --steps rounds between barrier + synchronize on both sides."""
+    h_every = max(1, min(args.harvest_every, steps))  # the timed region always pays for >= 1 harvest + gather
+    for i in range(warmup):
+        act.run_round()
+        if (i + 1) % h_every == 0:
+            harvest_and_gather(act)
+    barrier(world, dev)
+    harvest_and_gather(act)
+    act.counters(reset=True)
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if dev.type == "cuda" else [None] * steps
+    gathered = 0
+    barrier(world, dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        act.run_round(evs[i])
+        if (i + 1) % h_every == 0:
+            gathered += harvest_and_gather(act)
+    barrier(world, dev)
+    return time.perf_counter() - t0, act.counters(), evs, gathered
+
+
+def reduce_totals(cnt, elapsed, world, dev):
+    """Whole-job totals: moves / sims / evaluations summed over ranks, elapsed = MAX over ranks."""
+    tot = torch.tensor([float(cnt["moves"]), float(cnt["sims"]), float(cnt["leaves"])], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
+    return float(tmax.item()), total_moves, total_sims, total_evals
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -160,7 +241,6 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=dev)
         rccl_ranks = dist.get_world_size()
 
-    from alpha_zero_amd.core.gather import gather_samples
     from alpha_zero_amd.core.network import AlphaZeroNet
     from alpha_zero_amd.core.pipeline import SelfPlayActor
 
@@ -170,13 +250,6 @@ def main(argv=None):
     net = AlphaZeroNet((17, n, n), A, args.blocks, args.filters, args.filters, gomoku=(game != "go"))
     DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
     torch.backends.cudnn.benchmark = not args.no_miopen_find
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-        torch.cuda.synchronize(dev)
 
     def make_actor(dtype_name):
         """Engine + evaluator in the steady state: staggered openings, then the argument-independent pre-roll."""
@@ -195,75 +268,15 @@ def main(argv=None):
                 out = e.env_step(acts)
         return act
 
-    def harvest_and_gather(act):
-        st, pi, z, games = act.harvest_tensors()
-        res = gather_samples(st, pi, z, games, dst=0)
-        return 0 if res is None else int(res[0].shape[0])
-
-    def preroll(act, min_rounds=None):
-        """Untimed and independent of --steps / --warmup: rounds until every slot has committed >= preroll_moves searched moves
-        (ply advanced, or a game finished) and >= preroll_rounds rounds have passed.  Returns the rounds it took."""
-        e = act.engine
-        st0, _ = e.status()
-        ply0, done0 = st0[:, 1].copy(), st0[:, 5].copy()
-        min_rounds = args.preroll_rounds if min_rounds is None else min_rounds
-        rounds, cap = 0, max(min_rounds, 40 * (args.sims // max(1, args.parallel) + 2))
-        while rounds < cap:
-            act.run_round()
-            rounds += 1
-            if rounds % args.harvest_every == 0:
-                harvest_and_gather(act)
-            if rounds >= min_rounds and rounds % 10 == 0:
-                st, _ = e.status()
-                moved = np.where(st[:, 5] > done0, args.preroll_moves, st[:, 1] - ply0)
-                ok = torch.tensor([1.0 if moved.min() >= args.preroll_moves else 0.0], device=dev)
-                if world > 1:  # all ranks leave the pre-roll together (their harvest / gather calls must stay paired)
-                    import torch.distributed as dist
-
-                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if ok.item() > 0:
-                    break
-        return rounds
-
-    def timed(act, warmup, steps):
-        """--warmup untimed rounds, then exactly --steps rounds between barrier + synchronize on both sides."""
-        h_every = max(1, min(args.harvest_every, steps))  # the timed region always pays for >= 1 harvest + gather
-        for i in range(warmup):
-            act.run_round()
-            if (i + 1) % h_every == 0:
-                harvest_and_gather(act)
-        barrier()
-        harvest_and_gather(act)
-        act.counters(reset=True)
-        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)]
-        gathered = 0
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            act.run_round(evs[i])
-            if (i + 1) % h_every == 0:
-                gathered += harvest_and_gather(act)
-        barrier()
-        return time.perf_counter() - t0, act.counters(), evs, gathered
-
     actor = make_actor(args.net_dtype)
     eng = actor.engine
-    preroll_rounds = preroll(actor)
-    elapsed, cnt, evs, samples_at_root = timed(actor, args.warmup, args.steps)
+    preroll_rounds = preroll(actor, args, world, dev)
+    elapsed, cnt, evs, samples_at_root = timed(actor, args, world, dev, args.warmup, args.steps)
     bk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # expand/backup + end-of-move kernels
     k_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))   # select kernel (the dominant hand-written kernel)
     nn_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
 
-    moves = float(cnt["moves"])
-    tot = torch.tensor([moves, float(cnt["sims"]), float(cnt["leaves"])], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed_max = float(tmax.item())
-    total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
+    elapsed_max, total_moves, total_sims, total_evals = reduce_totals(cnt, elapsed, world, dev)
     if total_moves <= 0:
         raise SystemExit("bench.py: no move was committed inside the timed region -- the pre-roll did not reach the steady state")
 
@@ -383,8 +396,8 @@ def main(argv=None):
             # network (library convolutions + fused epilogue kernel), shorter pre-roll and window -- a companion number, not `value`
             del evs
             a32 = make_actor("fp32")
-            pre32 = preroll(a32, min_rounds=60)
-            el32, c32, ev32, _ = timed(a32, 5, 40)
+            pre32 = preroll(a32, args, world, dev, min_rounds=60)
+            el32, c32, ev32, _ = timed(a32, args, world, dev, 5, 40)
             fp32 = {"moves_per_s": round(c32["moves"] / el32, 2), "sims_per_sec": round(c32["sims"] / el32, 1), "ms_per_step": round(el32 / 40 * 1e3, 3),
                     "sims_per_move": round(c32["sims"] / max(1, c32["moves"]), 2), "steps": 40, "warmup": 5, "preroll_rounds": pre32,
                     "evaluator": "fp32, library convolutions + fused epilogue kernel"}

@@ -63,3 +63,18 @@ def test_cpu_baseline_calibration_fixture(golden_dir):
     r = doc["ratios"]["go9_p8_s200_10x128"]
     assert 0.8 <= r["ratio"] <= 1.4 and r["reference_moves_per_s"] > 0 and sum(x["moves"] for x in r["runs"]) >= 100
     assert abs(r["ratio"] - r["port_moves_per_s"] / r["reference_moves_per_s"]) < 1e-3
+
+
+def test_bench_measurement_flow_two_ranks_gloo(tmp_path):
+    """The N-rank control flow of bench.py (what the driver runs on 8 GPUs) on 2 gloo ranks with host-twin actors: both ranks leave
+    the pre-roll at the same round although one needs twice as many rounds per move, every collective pairs up (no hang), rank 0
+    gathers samples inside the timed region, totals are sums over ranks and the time is the maximum."""
+    script = os.path.join(ROOT, "tests", "bench_flow_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(tmp_path)], env=env) for r in range(2)]
+    assert all(p.wait(timeout=600) == 0 for p in procs)
+    f0, f1 = (json.load(open(os.path.join(str(tmp_path), f"flow{r}.json"))) for r in range(2))
+    assert f0["preroll"] == f1["preroll"] >= 10
+    assert f0["total_moves"] == f1["total_moves"] == f0["local_moves"] + f1["local_moves"] > 0
+    assert f0["elapsed_max"] == f1["elapsed_max"] == max(f0["elapsed"], f1["elapsed"])
+    assert f0["gathered"] > 0 and f1["gathered"] == 0  # samples arrive on rank 0 only
