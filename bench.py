@@ -387,7 +387,9 @@ def main(argv=None):
                         "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * (4.5 if S_t == 19 else 2.5)),
                         "avg_launch_ms": round(conv["avg_ms"], 4), "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4),
                         "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4), "launches_per_step": 2 * args.blocks,
-                        "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4)}
+                        "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4),
+                        # measured MFMA-only ceiling on post-ReLU-like operands at the 1400 W package limit (profiles/r02_mfma_power_probe.txt)
+                        "power_limited_mfma_only_tflops": 1840.0, "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
         else:
             roofline = engine_roof
         fp32 = None

@@ -268,3 +268,12 @@ def test_gpu_full_size_selfplay_properties():
     c = a.counters()
     assert games >= 1000 and samples > 10000 and c["stalls"] == 0
     assert c["sims"] == c["leaves"] + c["terminal_hits"] and c["games"] >= games and c["moves"] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_sgf_text_matches_reference(golden_dir, monkeypatch):
+    """SURVEY 8f-4 on the device: env.to_sgf() of games replayed through the HIP env kernels equals the reference's SGF text byte for
+    byte (Go incl. a resigned game, Gomoku, comments)."""
+    import sgf_checks as sc
+
+    sc.check_sgf("gpu", golden_dir, monkeypatch)
