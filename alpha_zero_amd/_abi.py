@@ -15,7 +15,7 @@ SYMBOLS = [
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
-                 "nodes_created", "game_rounds", "stalls"]
+                 "nodes_created", "game_rounds", "stalls", "hint_prefetches", "hint_hits"]
 
 
 class AzspConfig(C.Structure):

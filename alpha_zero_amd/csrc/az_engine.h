@@ -7,7 +7,8 @@
 //   alpha_zero/core/pipeline.py  play_and_record_one_game :289-382 (samples, resignation, z back-fill)
 //   alpha_zero/envs/base.py      observation :228-259
 // Data layout (per game, all in HBM):
-//   node record  = [Hdr | N f32[AP] | W f32[AP] | P f32[AP] | child i16[AP]]   (REC bytes, 128-B aligned rows)
+//   node record  = [Hdr | N f32[AP] | W f32[AP] | P f32[AP] | child i16[AP] | hint i16[AP]]   (REC bytes, 128-B aligned rows)
+//                  hint[a] = the node the search last continued to BELOW child a (a prefetch hint only, see descend())
 //                  Hdr carries the position reached by the node, so a descent is an index walk and
 //                  a child position is computed once, when the child is created (the reference
 //                  re-steps a deep-copied env from the root on every simulation: mcts_v2.py:382-402)
@@ -31,7 +32,7 @@ enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FE
 enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
 // statistics counters (u64 each)
 enum { AZC_SIMS = 0, AZC_NODE_VISITS, AZC_BACKUP_EDGES, AZC_LEAVES, AZC_DUP_LEAVES, AZC_TERMINAL_HITS, AZC_MOVES,
-       AZC_GAMES, AZC_ROOT_EVALS, AZC_NODES_CREATED, AZC_ROUNDS, AZC_STALLS, AZC_COUNT = 16 };
+       AZC_GAMES, AZC_ROOT_EVALS, AZC_NODES_CREATED, AZC_ROUNDS, AZC_STALLS, AZC_HINT_PREFETCH, AZC_HINT_HITS, AZC_COUNT = 16 };
 
 AZ_HD u64 az_bits_f64(double v) {
     u64 b;
@@ -49,7 +50,8 @@ struct AzCfg {
     double eps, alpha, resign_threshold;
     RuleCfg rc;
     u64 seed;
-    int rank, pad_;
+    int rank, dbg;  // dbg: timing diagnostics from AZSP_DEBUG_SELECT (tools/sel_abl.sh): 8 = no speculative prefetch, 16 / 32 = observation
+                    // planes twice, 64 = arg-max twice, 128 = rules step twice; none of them changes a result
 };
 
 struct AzMem {
@@ -161,6 +163,7 @@ typedef u64 __attribute__((may_alias)) u64a;  // word copies of typed records (n
 template <int AP, int HW> struct StagedRec {
     float rN[AP], rW[AP], rP[AP];
     int16_t rC[AP];
+    int16_t rH[AP];  // prefetch hints (never read by the search arithmetic)
     u64a hdrw[HW];  // header (position, parent, move, expanded); may_alias words, read back as Hdr
 };
 
@@ -168,10 +171,15 @@ template <int W, int AP, int HW> struct Scratch {
     u64 planes[16][W];          // observation planes being assembled / history shift buffer
     int path[AZ_PATH_CAP];      // (node << 16) | move per edge of the current descent (first AZ_PATH_CAP levels)
     int anc[8];                 // node id at level (depth & 7): the last 8 nodes of the descent, for the history planes
-    double pi[AP];              // search policy of the move being finished
-    double cdf[AP];             // its running sum (np.cumsum order)
-    float tmpf[AP];             // float32 policy terms (Gomoku)
-    int16_t parent[AZ_LDS_NODES];
+    union {  // phase-private scratch: the end-of-move work and the select phase never overlap within a wave's launch
+        struct {
+            double pi[AP];              // search policy of the move being finished
+            double cdf[AP];             // its running sum (np.cumsum order)
+            float tmpf[AP];             // float32 policy terms (Gomoku)
+            int16_t parent[AZ_LDS_NODES];
+        };
+        StagedRec<AP, HW> nxt;  // select: speculatively staged record of the node the descent will probably reach one level further down
+    };
     StagedRec<AP, HW> root;     // the root's record: staged ONCE per round, kept current in LDS while the P descents update it
     StagedRec<AP, HW> cur;      // the record of the node the current descent is looking at (levels >= 1)
     double rP64[AP];            // float64 root priors (noisy root only)
@@ -205,7 +213,7 @@ template <class Wv, int N, int GAME> struct Engine {
     static constexpr int HDR = ((int)sizeof(Hdr) + 127) / 128 * 128;
     static constexpr int HW = ((int)sizeof(Hdr) + 7) / 8;
     typedef Scratch<W, AP, HW> SC;
-    static constexpr int REC = (HDR + 3 * AP * 4 + AP * 2 + 127) / 128 * 128;
+    static constexpr int REC = (HDR + 3 * AP * 4 + 2 * AP * 2 + 127) / 128 * 128;
     static constexpr int GREC = ((int)sizeof(GR) + 127) / 128 * 128;
 
     const AzCfg& c;
@@ -214,6 +222,41 @@ template <class Wv, int N, int GAME> struct Engine {
     SC& sc;
     GR& gr;
     u64 cnt[AZC_COUNT];
+    // Hot wave-uniform scalars of the GameRec, cached in registers for the duration of a select / backup phase: every `gr.x` is a
+    // global-memory access (a load + wait + readfirstlane, i.e. an L2 round trip in the middle of a dependent chain).  The first
+    // version read root_fresh / root_noisy / the pb_c table inside EVERY arg-max and n_free / root_W in every leaf; doing the arg-max
+    // twice showed it cost 36 % of the select kernel (tools/sel_abl.sh).  hot_load() / hot_store() bracket the phase.
+    int hs_root, hs_rootN, hs_nfree, hs_fresh, hs_noisy;
+    double hs_rootW;
+    int hs_tabN;        // the visit count the cached root table entries below belong to (-1: none)
+    double hs_tabPbc;
+    float hs_tabSq;
+
+    AZ_HD void hot_load() {
+        hs_root = Wv::uni(gr.root);
+        hs_rootN = Wv::uni(gr.root_N);
+        hs_nfree = Wv::uni(gr.n_free);
+        hs_fresh = Wv::uni(gr.root_fresh);
+        hs_noisy = Wv::uni(gr.root_noisy);
+        hs_rootW = Wv::uni(gr.root_W);
+        hs_tabN = -1;
+    }
+    AZ_HD void hot_store() {
+        if (Wv::first()) {
+            gr.root = hs_root;
+            gr.root_N = hs_rootN;
+            gr.n_free = hs_nfree;
+            gr.root_W = hs_rootW;
+        }
+        Wv::sync();
+    }
+    // pb_c(n) and sqrt(n) of a node with n visits (host tables, azsp_set_tables): a global load each -- issued by the caller as early
+    // as n is known so that it overlaps the staging of the node's record
+    AZ_HD void table_entry(int n, bool fresh, double& pbc, float& sq) const {
+        const int ti = n < c.tab_len ? n : c.tab_len - 1;
+        pbc = Wv::uni(fresh ? m.pbc_py[ti] : m.pbc_np[ti]);
+        sq = Wv::uni(m.sqrt32[ti]);
+    }
 
     AZ_HD Engine(const AzCfg& c_, const AzMem& m_, int g_, SC& sc_)
         : c(c_), m(m_), g(g_), sc(sc_), gr(*(GR*)(m_.games + (size_t)g_ * GREC)) {
@@ -227,6 +270,7 @@ template <class Wv, int N, int GAME> struct Engine {
     AZ_HD float* rowW(int node) const { return (float*)(rec(node) + HDR + AP * 4); }
     AZ_HD float* rowP(int node) const { return (float*)(rec(node) + HDR + 2 * AP * 4); }
     AZ_HD int16_t* rowC(int node) const { return (int16_t*)(rec(node) + HDR + 3 * AP * 4); }
+    AZ_HD int16_t* rowH(int node) const { return (int16_t*)(rec(node) + HDR + 3 * AP * 4 + AP * 2); }
     AZ_HD double* rootP() const { return m.rootP + (size_t)g * AP; }
     AZ_HD int* leaf_path(int slot) const { return m.leaf_path + ((size_t)g * c.P + slot) * AZ_PATH_CAP; }
     AZ_HD void fail(int code) const {
@@ -244,15 +288,14 @@ template <class Wv, int N, int GAME> struct Engine {
     }
 
     // ---- node pool --------------------------------------------------------------------------
-    AZ_HD int alloc_node() {
-        if (Wv::uni(gr.n_free) <= 0) {
+    AZ_HD int alloc_node() {  // (select phase: between hot_load() and hot_store())
+        if (hs_nfree <= 0) {
             fail(AZ_ERR_NODES);
             return 0;
         }
-        const int pos = Wv::uni(gr.n_free) - 1, rel = pos - Wv::uni(sc.free_base);
+        const int pos = hs_nfree - 1, rel = pos - Wv::uni(sc.free_base);
         const int idx = Wv::uni((rel >= 0 && rel < AZ_FREE_PREFETCH) ? (int)sc.freetop[rel] : (int)m.free_stack[(size_t)g * c.max_nodes + pos]);
-        if (Wv::first()) gr.n_free -= 1;
-        Wv::sync();
+        hs_nfree -= 1;
         cnt[AZC_NODES_CREATED]++;
         return idx;
     }
@@ -317,11 +360,9 @@ template <class Wv, int N, int GAME> struct Engine {
 
     // ---- row arithmetic (operand precision of the NumPy original) ----------------------------
     // root W: Python float while the root is fresh, np.float32 after a re-root (mcts_v2.py:439-443)
-    AZ_HD void root_add_W(double v) {
-        if (Wv::first()) {
-            if (gr.root_fresh) gr.root_W = gr.root_W + v;
-            else gr.root_W = (double)((float)gr.root_W + (float)v);
-        }
+    AZ_HD void root_add_W(double v) {  // (between hot_load() and hot_store())
+        if (hs_fresh) hs_rootW = hs_rootW + v;
+        else hs_rootW = (double)((float)hs_rootW + (float)v);
     }
     // Apply `delta` to W (and +1 to N when count) on every edge of a path and on the root slot.
     // Edge d (0 = root's child) receives delta * (-1)^(depth-1-d); the root receives delta*(-1)^depth.
@@ -364,7 +405,7 @@ template <class Wv, int N, int GAME> struct Engine {
             }
             root_add_W((double)v);
         }
-        if (count && Wv::first()) gr.root_N += 1;
+        if (count) hs_rootN += 1;
         if (count) cnt[AZC_BACKUP_EDGES] += (u64)depth + 1;
         Wv::sync();
     }
@@ -378,6 +419,7 @@ template <class Wv, int N, int GAME> struct Engine {
         const float* rw = rowW(node);
         const float* rp = rowP(node);
         const int16_t* rc = rowC(node);
+        const int16_t* rh = rowH(node);
         const u64a* hw = (const u64a*)rec(node);
         const double* rp64 = rootP();
         Wv::lanes([&](int lane) {
@@ -387,21 +429,62 @@ template <class Wv, int N, int GAME> struct Engine {
                 dst.rW[a] = rw[a];
                 dst.rP[a] = rp[a];
                 dst.rC[a] = rc[a];
+                dst.rH[a] = rh[a];
                 if (with_root_p) sc.rP64[a] = rp64[a];
+            }
+        });
+        Wv::sync();
+    }
+    // Two records in ONE burst: the node the descent moves to and the node it will probably reach next (its hint).  All loads of
+    // both records are issued before the first LDS store, so the pair costs one HBM / L2 round trip.
+    AZ_HD void stage_two(int na, SR& da, int nb, SR& db) {
+        const unsigned char* ra = rec(na);
+        const unsigned char* rb = rec(nb);
+        Wv::lanes([&](int lane) {
+            u64a ha = 0, hb = 0;
+            if (lane < HW) {
+                ha = ((const u64a*)ra)[lane];
+                hb = ((const u64a*)rb)[lane];
+            }
+            float an[EPL], aw[EPL], ap[EPL], bn[EPL], bw[EPL], bp[EPL];
+            int16_t ac[EPL], ah[EPL], bc[EPL], bh[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int a = lane + AZ_WAVE * j;
+                if (a < AP) {
+                    an[j] = ((const float*)(ra + HDR))[a];
+                    aw[j] = ((const float*)(ra + HDR + AP * 4))[a];
+                    ap[j] = ((const float*)(ra + HDR + 2 * AP * 4))[a];
+                    ac[j] = ((const int16_t*)(ra + HDR + 3 * AP * 4))[a];
+                    ah[j] = ((const int16_t*)(ra + HDR + 3 * AP * 4 + AP * 2))[a];
+                    bn[j] = ((const float*)(rb + HDR))[a];
+                    bw[j] = ((const float*)(rb + HDR + AP * 4))[a];
+                    bp[j] = ((const float*)(rb + HDR + 2 * AP * 4))[a];
+                    bc[j] = ((const int16_t*)(rb + HDR + 3 * AP * 4))[a];
+                    bh[j] = ((const int16_t*)(rb + HDR + 3 * AP * 4 + AP * 2))[a];
+                }
+            }
+            if (lane < HW) {
+                da.hdrw[lane] = ha;
+                db.hdrw[lane] = hb;
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int a = lane + AZ_WAVE * j;
+                if (a < AP) {
+                    da.rN[a] = an[j], da.rW[a] = aw[j], da.rP[a] = ap[j], da.rC[a] = ac[j], da.rH[a] = ah[j];
+                    db.rN[a] = bn[j], db.rW[a] = bw[j], db.rP[a] = bp[j], db.rC[a] = bc[j], db.rH[a] = bh[j];
+                }
             }
         });
         Wv::sync();
     }
     static AZ_HD const Hdr& hdr_of(const SR& r) { return *(const Hdr*)r.hdrw; }
 
-    AZ_HD int puct_argmax(const SR& r, bool at_root, int n_self) {
+    AZ_HD int puct_argmax(const SR& r, bool at_root, double pbc64, float sq32) {
         const S& s = hdr_of(r).st;
-        int ti = n_self < c.tab_len ? n_self : c.tab_len - 1;
-        const bool fresh = at_root && Wv::uni(gr.root_fresh);
-        const double pbc64 = Wv::uni(fresh ? m.pbc_py[ti] : m.pbc_np[ti]);
         const float pbc32 = (float)pbc64;
-        const float sq32 = Wv::uni(m.sqrt32[ti]);
-        const bool noisy = at_root && Wv::uni(gr.root_noisy);
+        const bool noisy = at_root && hs_noisy;
         u64 lg[W];
         for (int i = 0; i < W; ++i) lg[i] = Wv::uni(s.legal[i]);
         const bool pass_ok = GAME == AZ_GO && !(Wv::uni((int)s.flags) & AZF_TERMINAL);
@@ -433,13 +516,29 @@ template <class Wv, int N, int GAME> struct Engine {
     // One descent from the root.  Returns 0 = leaf reached (unexpanded, non-terminal), 1 = terminal.
     // On return `leaf_state` holds the leaf's position (used for the observation planes).
     AZ_HD int descend(int& node_out, int& depth_out, S& leaf_state) {
-        const int root = Wv::uni(gr.root);
-        int node = root, depth = 0, n_self = Wv::uni(gr.root_N);
+        const int root = hs_root;
+        int node = root, depth = 0, n_self = hs_rootN;
+        if (hs_tabN != hs_rootN) {  // the root's table entries change only when its visit count does (terminal backups)
+            table_entry(hs_rootN, hs_fresh != 0, hs_tabPbc, hs_tabSq);
+            hs_tabN = hs_rootN;
+        }
+        double pbc64 = hs_tabPbc;
+        float sq32 = hs_tabSq;
+        // Speculation (performance only, never changes what is selected): every edge remembers the node the search last continued
+        // to below its child (`hint`).  Moving to a child, its record AND the record of its hinted successor are fetched in one
+        // burst; if the next arg-max then picks that successor, its record is already in LDS and a tree level costs no memory
+        // round trip.  A prefetched record is only used when its node index equals the authoritative child index, and nothing
+        // writes a node record between the prefetch and its use (one wave owns the game), so a stale hint merely wastes a load.
+        int cur_is_nxt = 0;   // which LDS record holds `node` at levels >= 1: 0 = sc.cur, 1 = sc.nxt
+        int spec = -1;        // node whose record sits in the OTHER record (valid when >= 0)
         for (;;) {
-            const SR& r = depth == 0 ? sc.root : sc.cur;  // the root record lives in LDS for the whole round
-            const int mv = puct_argmax(r, depth == 0, n_self);
+            const SR& r = depth == 0 ? sc.root : (cur_is_nxt ? sc.nxt : sc.cur);  // the root record lives in LDS for the whole round
+            int mv = puct_argmax(r, depth == 0, pbc64, sq32);
+            if (c.dbg & 64) mv = puct_argmax(r, depth == 0, pbc64, sq32 + (mv < 0 ? 1.0f : 0.0f));  // diagnostics: the arg-max twice
             int child = Wv::uni((int)r.rC[mv]);
+            const int hint = Wv::uni((int)r.rH[mv]);
             n_self = Wv::uni((int)r.rN[mv]);
+            table_entry(n_self, false, pbc64, sq32);  // the child's pb_c / sqrt: in flight while its record is staged
             if (Wv::first()) {
                 if (depth < AZ_PATH_CAP) {
                     sc.path[depth] = (node << 16) | mv;
@@ -456,6 +555,7 @@ template <class Wv, int N, int GAME> struct Engine {
                 child = alloc_node();
                 S ns;
                 R::template step<GAME>(hdr_of(r).st, mv, c.rc, ns);
+                if (c.dbg & 128) R::template step<GAME>(hdr_of(r).st, mv, c.rc, ns);  // diagnostics: the rules step twice
                 if (Wv::first()) {
                     Hdr& h = hdr(child);
                     h.st = ns;
@@ -465,15 +565,34 @@ template <class Wv, int N, int GAME> struct Engine {
                     rowC(node)[mv] = (int16_t)child;
                     if (node == root) sc.root.rC[mv] = (int16_t)child;
                 }
+                note_hint(depth - 1, child);
                 leaf_state = ns;
                 node_out = child;
                 depth_out = depth;
                 Wv::sync();
                 return (ns.flags & AZF_TERMINAL) ? 1 : 0;
             }
+            note_hint(depth - 1, child);
             node = child;
-            stage_node(node, sc.cur, false);
-            const Hdr& h = hdr_of(sc.cur);
+            if (depth >= 2 && spec == child) {
+                cur_is_nxt ^= 1;  // predicted: the record is already staged in the other buffer
+                spec = -1;
+                cnt[AZC_HINT_HITS]++;
+            } else {
+                SR& dst = depth == 1 ? sc.cur : (cur_is_nxt ? sc.nxt : sc.cur);
+                if (depth == 1) cur_is_nxt = 0;
+                SR& oth = cur_is_nxt ? sc.cur : sc.nxt;
+                if (hint >= 0 && hint != node && hint < c.max_nodes && !(c.dbg & 8)) {
+                    stage_two(node, dst, hint, oth);
+                    spec = hint;
+                    cnt[AZC_HINT_PREFETCH]++;
+                } else {
+                    stage_node(node, dst, false);
+                    spec = -1;
+                }
+            }
+            const SR& cr = cur_is_nxt ? sc.nxt : sc.cur;
+            const Hdr& h = hdr_of(cr);
             const int hflags = Wv::uni((int)h.st.flags), hexp = Wv::uni((int)h.expanded);
             if ((hflags & AZF_TERMINAL) || !hexp) {
                 leaf_state = R::uni_state(h.st);
@@ -484,6 +603,17 @@ template <class Wv, int N, int GAME> struct Engine {
             }
         }
     }
+    // The descent just moved from the node of path level `lvl` to `succ`: remember it on the edge ABOVE that node (the hint of the
+    // grandparent's edge), in memory and in the LDS copy of the root record.
+    AZ_HD void note_hint(int lvl, int succ) {
+        if (lvl < 1 || lvl > AZ_PATH_CAP) return;
+        if (Wv::first()) {
+            const int e = sc.path[lvl - 1];
+            const int gp = e >> 16, gmv = e & 0xffff;
+            rowH(gp)[gmv] = (int16_t)succ;
+            if (gp == hs_root) sc.root.rH[gmv] = (int16_t)succ;
+        }
+    }
 
     // Select-phase path update (virtual loss / terminal backup) from the values captured during the descent: plain stores,
     // no read-modify-write round trip.  The captured W / N ARE the memory contents (only this wave touches its game, and
@@ -491,10 +621,10 @@ template <class Wv, int N, int GAME> struct Engine {
     AZ_HD void path_apply(int depth, int leaf, float delta, bool flip, bool count) {
         if (depth > AZ_PATH_CAP) {  // rare deep path: parent-link walk in memory, then refresh the LDS copy of the root
             path_update(sc.path, depth, leaf, delta, flip, count);
-            stage_node(Wv::uni(gr.root), sc.root, false);
+            stage_node(hs_root, sc.root, false);
             return;
         }
-        const int root = Wv::uni(gr.root);
+        const int root = hs_root;
         Wv::lanes([&](int lane) {
             if (lane < depth) {
                 const int e = sc.path[lane];
@@ -511,7 +641,7 @@ template <class Wv, int N, int GAME> struct Engine {
             }
         });
         root_add_W((double)((flip && (depth & 1)) ? -delta : delta));
-        if (count && Wv::first()) gr.root_N += 1;
+        if (count) hs_rootN += 1;
         if (count) cnt[AZC_BACKUP_EDGES] += (u64)depth + 1;
         Wv::sync();
     }
@@ -558,23 +688,35 @@ template <class Wv, int N, int GAME> struct Engine {
         const int sub = (int)(r - tile * TBF);
         uint16_t* base = (uint16_t*)feat + tile * (size_t)(4 * TBF * NP * 8) + (size_t)sub * NP * 8;
         const u32 black = me == 0 ? 0x3F80u : 0u;
+        // One lane per POSITION (81 positions: lanes 0-63, then 0-16): the 16 plane words of its 64-position group are
+        // wave-uniform LDS reads (broadcast), a stone is one bit-field extract, two planes make one dword (bf16 1.0 = 0x3F80) with two
+        // multiply-adds, a chunk is one 16-byte store.  (The first version walked (chunk, position) pairs with 8 per-lane 64-bit
+        // shifts each: 54 % of the select kernel, tools/sel_abl.sh.)
         Wv::lanes([&](int lane) {
-            for (int e = lane; e < 3 * NP; e += AZ_WAVE) {
-                const int cc = e / NP, p = e - cc * NP;
-                u32 d[4] = {0u, 0u, 0u, 0u};
-                if (cc < 2) {
-                    for (int i = 0; i < 8; ++i) {
-                        const u32 bit = (u32)((sc.planes[cc * 8 + i][p >> 6] >> (p & 63)) & 1ull);
-                        d[i >> 1] |= (bit ? 0x3F80u : 0u) << ((i & 1) * 16);
+            for (int p = lane; p < NP; p += AZ_WAVE) {
+                const int w = p >> 6, b = p & 63;
+                const bool hi_half = b >= 32;
+                const u32 sh = (u32)(b & 31);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    u32 d[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u64 w0 = sc.planes[cc * 8 + 2 * k][w], w1 = sc.planes[cc * 8 + 2 * k + 1][w];
+                        const u32 x0 = hi_half ? (u32)(w0 >> 32) : (u32)w0, x1 = hi_half ? (u32)(w1 >> 32) : (u32)w1;
+                        d[k] = ((x0 >> sh) & 1u) * 0x3F80u + ((x1 >> sh) & 1u) * 0x3F800000u;
                     }
-                } else {
-                    d[0] = black;
+                    u32* o = (u32*)(base + ((size_t)cc * TBF * NP + p) * 8);
+                    o[0] = d[0];
+                    o[1] = d[1];
+                    o[2] = d[2];
+                    o[3] = d[3];
                 }
-                u32* o = (u32*)(base + ((size_t)cc * TBF * NP + p) * 8);
-                o[0] = d[0];
-                o[1] = d[1];
-                o[2] = d[2];
-                o[3] = d[3];
+                u32* o = (u32*)(base + ((size_t)2 * TBF * NP + p) * 8);
+                o[0] = black;
+                o[1] = 0u;
+                o[2] = 0u;
+                o[3] = 0u;
             }
         });
     }
@@ -598,9 +740,10 @@ template <class Wv, int N, int GAME> struct Engine {
         if (Wv::first()) sc.free_base = -(1 << 30);  // no staged free-stack window yet
         Wv::sync();
         const int status = Wv::uni(gr.status);
+        hot_load();
         if (status == AZS_NEED_ROOT) {
             // mcts_v2.py:364-368: the root position itself is evaluated first
-            if (gr.root < 0) {
+            if (hs_root < 0) {
                 const int r = alloc_node();
                 if (Wv::first()) {
                     Hdr& h = hdr(r);
@@ -608,11 +751,11 @@ template <class Wv, int N, int GAME> struct Engine {
                     h.parent = -1;
                     h.move = -1;
                     h.expanded = 0;
-                    gr.root = r;
                 }
+                hs_root = r;
                 Wv::sync();
             }
-            gather_planes(gr.root, -1, gr.env.to_play);  // the root IS the real position: hist[0..7]
+            gather_planes(hs_root, -1, gr.env.to_play);  // the root IS the real position: hist[0..7]
             write_features(feat, 0, gr.env.to_play);
             Wv::lanes([&](int lane) {
                 if (lane < c.P) vrow[lane] = lane == 0 ? 1 : 0;
@@ -622,14 +765,14 @@ template <class Wv, int N, int GAME> struct Engine {
                 gr.n_leaves = 0;
             }
             cnt[AZC_ROOT_EVALS]++;
-            Wv::sync();
+            hot_store();
             return;
         }
         int nleaf = 0;
         if (status == AZS_SEARCH && !Wv::uni(gr.noise_pending)) {
             int attempts = 0;
             {  // the next pops of the free stack, staged once per round
-                const int base = gr.n_free - AZ_FREE_PREFETCH;
+                const int base = hs_nfree - AZ_FREE_PREFETCH;
                 const int16_t* fs = m.free_stack + (size_t)g * c.max_nodes;
                 Wv::lanes([&](int lane) {
                     const int i = base + lane;
@@ -643,7 +786,7 @@ template <class Wv, int N, int GAME> struct Engine {
                     for (int t = lane; t < 16 * W; t += AZ_WAVE) lh[t] = gh[t];
                 });
                 Wv::sync();
-                stage_node(Wv::uni(gr.root), sc.root, Wv::uni(gr.root_noisy) != 0);
+                stage_node(hs_root, sc.root, hs_noisy != 0);
             }
             // mcts_v2.py:572: up to P leaves in at most 2P attempts, one after another (each descent
             // sees the virtual losses of the previous ones); uct_search (:378-418) is the P == 1 case
@@ -658,8 +801,8 @@ template <class Wv, int N, int GAME> struct Engine {
                     // mcts_v2.py:407-411 / :604-608: back up -reward, node stays unexpanded
                     cnt[AZC_TERMINAL_HITS]++;
                     path_apply(depth, node, (float)(-(int)leaf.reward), true, true);
-                    if (!c.parallel_mode && Wv::uni(gr.root_N) < c.budget) attempts = 0;  // uct_search keeps looping (:378)
-                    if (!c.parallel_mode && Wv::uni(gr.root_N) >= c.budget) break;
+                    if (!c.parallel_mode && hs_rootN < c.budget) attempts = 0;  // uct_search keeps looping (:378)
+                    if (!c.parallel_mode && hs_rootN >= c.budget) break;
                     continue;
                 }
                 if (c.parallel_mode) path_apply(depth, node, 1.0f, false, false);  // add_virtual_loss :453-467
@@ -674,6 +817,11 @@ template <class Wv, int N, int GAME> struct Engine {
                 const int me = leaf.to_play;
                 gather_planes(node, depth, me, &leaf);
                 write_features(feat, nleaf, me);
+                if (c.dbg & 16) {  // the same planes once more: the launch time grows by exactly their cost
+                    gather_planes(node, depth, me, &leaf);
+                    write_features(feat, nleaf, me);
+                }
+                if (c.dbg & 32) write_features(feat, nleaf, me);
                 nleaf++;
                 cnt[AZC_LEAVES]++;
             }
@@ -682,7 +830,7 @@ template <class Wv, int N, int GAME> struct Engine {
             if (lane < c.P) vrow[lane] = lane < nleaf ? 1 : 0;
         });
         if (Wv::first()) gr.n_leaves = nleaf;
-        Wv::sync();
+        hot_store();
     }
 
     // ---- expand + backup phase (mcts_v2.py:188-232, :616-625) -----------------------------------
@@ -691,12 +839,14 @@ template <class Wv, int N, int GAME> struct Engine {
         float* rw = rowW(node);
         float* rp = rowP(node);
         int16_t* rc = rowC(node);
+        int16_t* rh = rowH(node);
         Wv::lanes([&](int lane) {
             for (int a = lane; a < AP; a += AZ_WAVE) {
                 rp[a] = a < A ? prior[a] : 0.0f;  // stored unmasked, not renormalised (:209)
                 rn[a] = 0.0f;
                 rw[a] = 0.0f;
                 rc[a] = -1;
+                rh[a] = -1;
             }
         });
         if (Wv::first()) hdr(node).expanded = 1;
@@ -719,6 +869,8 @@ template <class Wv, int N, int GAME> struct Engine {
             return;
         }
         const int nl = Wv::uni(gr.n_leaves);
+        if (nl == 0) return;
+        hot_load();
         for (int s = 0; s < nl; ++s) {
             const int node = Wv::uni((int)gr.leaf_node[s]), depth = Wv::uni((int)gr.leaf_depth[s]);
             const int* lp = leaf_path(s);
@@ -731,7 +883,7 @@ template <class Wv, int N, int GAME> struct Engine {
             path_update(lp, depth, node, values[row0 + s], true, true);
         }
         if (Wv::first()) gr.n_leaves = 0;
-        Wv::sync();
+        hot_store();
     }
 
     // ---- Dirichlet noise at the root (mcts_v2.py:235-262) ---------------------------------------

@@ -57,16 +57,56 @@ struct WaveDev {
         }
         return v;
     }
+    // ---- wave-wide reductions on the DPP network (VALU latency) instead of ds_bpermute butterflies (an LDS round trip per
+    // step): quad swaps, half-row / row mirrors, then row_bcast15 / row_bcast31 carry the row results to lane 63.  The select
+    // kernel's arg-max spent 12 dependent bpermute steps per tree level in the first version (tools/sel_abl.sh: 30 % of the launch).
+    template <int CTRL, int ROW_MASK> static AZ_D u32 dpp(u32 own, u32 v) {
+        return (u32)__builtin_amdgcn_update_dpp((int)own, (int)v, CTRL, ROW_MASK, 0xF, false);
+    }
+    template <int CTRL, int ROW_MASK> static AZ_D u64 max_step_u64(u64 v) {
+        const u32 lo = (u32)v, hi = (u32)(v >> 32);
+        const u64 o = ((u64)dpp<CTRL, ROW_MASK>(hi, hi) << 32) | dpp<CTRL, ROW_MASK>(lo, lo);
+        return o > v ? o : v;
+    }
+    static AZ_D u64 max_u64(u64 v) {  // every lane contributes; the result is wave-uniform
+        v = max_step_u64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+        v = max_step_u64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+        v = max_step_u64<0x141, 0xF>(v);  // row_half_mirror
+        v = max_step_u64<0x140, 0xF>(v);  // row_mirror: every lane of a 16-lane row holds the row maximum
+        v = max_step_u64<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+        v = max_step_u64<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave maximum
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, 63), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63);
+        return ((u64)hi << 32) | lo;
+    }
+    template <int CTRL, int ROW_MASK> static AZ_D u32 min_step_u32(u32 v) {
+        const u32 o = dpp<CTRL, ROW_MASK>(v, v);
+        return o < v ? o : v;
+    }
+    static AZ_D u32 min_u32(u32 v) {
+        v = min_step_u32<0xB1, 0xF>(v);
+        v = min_step_u32<0x4E, 0xF>(v);
+        v = min_step_u32<0x141, 0xF>(v);
+        v = min_step_u32<0x140, 0xF>(v);
+        v = min_step_u32<0x142, 0xA>(v);
+        v = min_step_u32<0x143, 0xC>(v);
+        return (u32)__builtin_amdgcn_readlane((int)v, 63);
+    }
+    // IEEE double -> unsigned key with the same order (no NaNs reach the search: scores are finite)
+    static AZ_D u64 order_key(double x) {
+        u64 b;
+        __builtin_memcpy(&b, &x, sizeof b);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    }
     // f(lane, score&, idx&): the lane's best candidate (idx < 0: none).  Returns the index with the
     // largest score, lowest index on ties (np.argmax semantics, mcts_v2.py:178).
     template <class F> static AZ_D int argmax_first(F&& f) {
         double s = -1.0e300;
         int idx = -1;
         f(lane(), s, idx);
-        if (idx < 0) s = -1.0e300;
-        double m = max_f64(s);
-        int cand = (idx >= 0 && s == m) ? idx : 0x7fffffff;
-        return __builtin_amdgcn_readfirstlane(min_i32(cand));
+        const u64 key = idx >= 0 ? order_key(s) : 0ull;  // 0 sorts below every finite score
+        const u64 m = max_u64(key);
+        const u32 cand = (idx >= 0 && key == m) ? (u32)idx : 0x7fffffffu;
+        return (int)min_u32(cand);
     }
     static AZ_D int bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
     // Tell the compiler that `v` is wave-uniform (it is, by construction: loaded through a uniform address or

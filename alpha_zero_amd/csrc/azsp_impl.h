@@ -651,6 +651,7 @@ int azsp_create(const AzspConfig* p, void** out) {
     c.rc.komi = p->komi;
     c.seed = p->seed;
     c.rank = p->rank;
+    c.dbg = getenv("AZSP_DEBUG_SELECT") ? atoi(getenv("AZSP_DEBUG_SELECT")) : 0;
     c.stage_cap = p->stop_after_move ? 1 : (p->game == AZSP_GAME_GO ? c.rc.max_steps : h->NP);
 
     const size_t G = (size_t)c.G;

@@ -439,6 +439,8 @@ def main(argv=None):
             "sims_per_move": round(total_sims / max(1.0, total_moves), 2),
             "select_nodes_per_sim": round(cnt["node_visits"] / max(1, cnt["sims"]), 3),
             "backup_nodes_per_sim": round(cnt["backup_edges"] / max(1, cnt["sims"]), 3),
+            "select_hint_prefetches_per_sim": round(cnt.get("hint_prefetches", 0) / max(1, cnt["sims"]), 3),
+            "select_hint_hit_rate": round(cnt.get("hint_hits", 0) / max(1, cnt.get("hint_prefetches", 0)), 3),
             "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds,
             "fp32_moves_per_s": fp32["moves_per_s"] if fp32 else None, "fp32_companion": fp32,
             "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,

@@ -204,7 +204,8 @@ int azsp_harvest_extra(void* engine, int32_t* extra_host);
 int azsp_set_actor_state(void* engine, double resign_threshold, int32_t training_steps);
 
 /* counters_host uint64[16]: simulations, best_child calls, backup edges, leaves, duplicate leaves, terminal hits,
- * moves, games, root evaluations, nodes created, game-rounds, buffer stalls. */
+ * moves, games, root evaluations, nodes created, game-rounds, buffer stalls, speculative record prefetches of the select phase and
+ * how many of them were used. */
 int azsp_counters(void* engine, uint64_t* counters_host, int32_t reset, void* stream);
 
 /* Dihedral-8 transform of a batch (no engine needed): op 0 identity, 1 h-flip, 2 v-flip, 3/4/5 = rot90/180/270
