@@ -218,12 +218,10 @@ def test_gpu_parallel_evaluation_games_match_reference(golden_dir):
     ac.check_parallel_arena("gpu", golden_dir)
 
 
-@pytest.mark.gpu
-def test_gpu_full_size_selfplay_properties():
-    """BASELINE size (9x9 Go, G = 4096, 200 sims, P = 8, 10x128 bf16 on the hand-written evaluator): size-independent properties of
-    everything the actor emits over 600 rounds -- every harvested game is a legal alternation of colours from the empty board, z is
-    +1 for the winner's samples and -1 for the loser's, every pi is a distribution over legal points of its own position (stones
-    of the sample's planes are never played on), lengths are within max_steps, counters are consistent, no stall / fault."""
+def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, min_games):
+    """Size-independent properties of everything the actor emits: every harvested game alternates colours, z is +1 for the winner's
+    samples and -1 for the loser's, every pi is a distribution that never puts mass on an occupied point of its own position,
+    lengths are within max_steps, counters are consistent, no stall / fault."""
     import torch
 
     from alpha_zero_amd import _lib
@@ -231,32 +229,33 @@ def test_gpu_full_size_selfplay_properties():
     from alpha_zero_amd.core.pipeline import SelfPlayActor
 
     torch.manual_seed(1)
-    net = AlphaZeroNet((17, 9, 9), 82, 10, 128, 128)
-    a = SelfPlayActor(net, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8, device="cuda", net_dtype=torch.bfloat16,
+    NP = n * n
+    net = AlphaZeroNet((17, n, n), NP + 1, blocks, filters, filters)
+    a = SelfPlayActor(net, game="go", board_size=n, num_games=G, num_simulations=sims, num_parallel=8, device="cuda", net_dtype=torch.bfloat16,
                       binding=_lib.load())
     assert a.tiled_features
-    # short games so that thousands finish: random openings of 100..150 plies, then the search plays them out
+    # short games so that many finish: long random openings, then the search plays them out
     rng = np.random.Generator(np.random.PCG64(5))
-    plies = rng.integers(100, 151, size=4096)
+    plies = rng.integers(open_lo, open_hi + 1, size=G)
     out = a.engine.env_step(None)
     for t in range(int(plies.max())):
-        legal = out["legal"][:, :81].astype(bool)
+        legal = out["legal"][:, :NP].astype(bool)
         r = rng.random(legal.shape) * legal
         acts = np.where((plies > t) & legal.any(axis=1) & (out["scalars"][:, 5] == 0), r.argmax(axis=1), -2).astype(np.int32)
         out = a.engine.env_step(acts)
     games = samples = 0
-    for _ in range(12):
+    for _ in range(rounds // 50):
         a.run_rounds(50)
         st, pi, z, rows = a.harvest_tensors()
         if not len(rows):
             continue
         stc, pic, zc = st.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
         assert np.all(np.isin(zc, (-1.0, 0.0, 1.0))) and np.allclose(pic.sum(axis=1), 1.0, atol=1e-4)
-        occupied = (stc[:, 0] + stc[:, 1]).reshape(len(stc), 81) > 0   # planes 0 / 1: the current position's stones
-        assert not np.any((pic[:, :81] > 0) & occupied)               # no visit on an occupied point
+        occupied = (stc[:, 0] + stc[:, 1]).reshape(len(stc), NP) > 0   # planes 0 / 1: the current position's stones
+        assert not np.any((pic[:, :NP] > 0) & occupied)               # no visit on an occupied point
         for row in rows:
             s0, ln = int(row[0]), int(row[1])
-            assert 0 < ln <= 162
+            assert 0 < ln <= 2 * NP
             black = stc[s0:s0 + ln, 16, 0, 0]
             assert np.all(black[1:] != black[:-1])
             if int(row[2]) != 0:
@@ -266,8 +265,20 @@ def test_gpu_full_size_selfplay_properties():
         games += len(rows)
         samples += len(zc)
     c = a.counters()
-    assert games >= 1000 and samples > 10000 and c["stalls"] == 0
+    assert games >= min_games and samples > 10 * min_games and c["stalls"] == 0
     assert c["sims"] == c["leaves"] + c["terminal_hits"] and c["games"] >= games and c["moves"] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_selfplay_properties():
+    """BASELINE size: 9x9 Go, G = 4096, 200 sims, P = 8, 10x128 bf16 on the hand-written evaluator, 600 rounds."""
+    _selfplay_properties(9, 4096, 200, 10, 128, 100, 150, 600, 1000)
+
+
+@pytest.mark.gpu
+def test_gpu_go19_selfplay_properties():
+    """19x19 boards on the C5-shaped evaluator kernels (256 filters, fewer blocks and simulations so that games finish)."""
+    _selfplay_properties(19, 256, 32, 2, 256, 560, 700, 400, 100)
 
 
 @pytest.mark.gpu
