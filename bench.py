@@ -16,7 +16,7 @@ work, selection of the next P leaves per game, observation planes, and the netwo
 All inputs live in HBM; nothing crosses PCIe inside the timed region except the harvests of finished games.
 
 Before --warmup / --steps apply, an untimed, argument-independent PRE-ROLL brings the engine to its steady state: slots start
-from staggered random openings, then rounds run until every slot has committed >= 2 searched moves and >= 150 rounds have passed
+from staggered random openings, then rounds run until every slot has committed >= 2 searched moves and >= 300 rounds have passed
 (a fresh tree needs 26 rounds to its first move; afterwards inherited sub-trees of different sizes de-phase the slots), so that
 move completions are spread evenly over rounds and a 20-round window measures the same moves/s as a 300-round one.  The timed
 region always contains at least one harvest + gather (every min(--harvest-every, --steps) rounds).
@@ -79,7 +79,7 @@ def parse_args(argv=None):
     ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
-    ap.add_argument("--preroll-rounds", type=int, default=150, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
+    ap.add_argument("--preroll-rounds", type=int, default=300, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
     ap.add_argument("--preroll-moves", type=int, default=2, help="every slot must have committed this many searched moves before timing")
     ap.add_argument("--harvest-every", type=int, default=50)
     ap.add_argument("--cpu-seconds", type=float, default=60.0)
