@@ -423,9 +423,6 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         unit(CpInt<3>{});
         yprev = ybase;
     }
-#ifdef CP_PROBE_CYCLES
-    if (threadIdx.x == 0) CP_PROBE_CYCLES[blockIdx.x] = (long long)it;
-#endif
     // epilogue of the very last unit (accumulator set 1, column tiles 6 and 7)
     if (it > 0) {
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[1][0]), "+v"(acc[1][1]));

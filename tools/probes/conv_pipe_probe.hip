@@ -5,7 +5,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-__device__ long long* g_cyc;
 #include "../../alpha_zero_amd/csrc/az_conv.h"
 
 __global__ void k_fill(unsigned short* p, size_t n, unsigned seed, int mode) {
