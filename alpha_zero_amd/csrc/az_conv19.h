@@ -210,7 +210,9 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
             cv_f32x16 acc[3];
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {  // fragments of steps 0..2 are already in flight
+#ifndef CP_ABL_NO_FRAG  // (ablation switch of tools/probes/conv19_probe.hip, never defined in the product build)
                 if (t + 3 < NSTEP) load_step(bp, t + 3);
+#endif
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
@@ -218,7 +220,9 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
                     else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
                 }
                 // the next tile's DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the previous barrier)
+#ifndef CP_ABL_NO_DMA
                 if (u == 0 && t % 3 == 1 && t / 3 < NPIECE) dma_piece(nsrc, ndst, has_next, t / 3);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (u == 1) {

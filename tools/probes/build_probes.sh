@@ -12,3 +12,7 @@ for v in FULL NO_DMA DMA_MASK0 DMA_SAMESRC NO_EPI NO_STORE NO_RESLOAD NO_FRAG; d
 done
 /opt/rocm/bin/hipcc $F -DCP_ABL_NO_DMA -DCP_ABL_NO_EPI -DCP_ABL_NO_RESLOAD -o conv_pipe_probe_MFMA_FRAG conv_pipe_probe.hip
 /opt/rocm/bin/hipcc $F -DCP_ABL_NO_DMA -DCP_ABL_NO_EPI -DCP_ABL_NO_RESLOAD -DCP_ABL_NO_FRAG -o conv_pipe_probe_MFMA_ONLY conv_pipe_probe.hip
+for v in FULL NO_FRAG NO_DMA; do
+  D=""; [ $v != FULL ] && D="-DCP_ABL_$v"
+  /opt/rocm/bin/hipcc $F $D -o conv19_probe_$v conv19_probe.hip
+done
