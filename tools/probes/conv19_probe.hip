@@ -29,9 +29,19 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    const int variant = argc > 3 ? atoi(argv[3]) : 0;  // 0: launch B (addend in place), 1: launch A plain (no addend), 2: launch A with a residual tensor
+    unsigned short* r2 = nullptr;
+    if (variant == 2) { hipMalloc(&r2, n * 2); hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, r2, n, 5u, mode); }
     auto launch = [&] {
-        hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), dim3(256), dim3(256), 0, 0, (const unsigned char*)x, w, bias, (const unsigned char*)y, (unsigned char*)y,
-                           boards, 1, 0, 256, 128, 32, 16);
+        if (variant == 0)
+            hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), dim3(256), dim3(256), 0, 0, (const unsigned char*)x, w, bias, (const unsigned char*)y, (unsigned char*)y,
+                               boards, 1, 0, 256, 128, 32, 16);
+        else if (variant == 1)
+            hipLaunchKernelGGL((k_conv3x3_hb19<false, 16>), dim3(256), dim3(256), 0, 0, (const unsigned char*)x, w, bias, (const unsigned char*)nullptr, (unsigned char*)y,
+                               boards, 0, 1, 256, 0, 32, 0);
+        else
+            hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), dim3(256), dim3(256), 0, 0, (const unsigned char*)x, w, bias, (const unsigned char*)r2, (unsigned char*)y,
+                               boards, 0, 1, 256, 0, 32, 0);
     };
     for (int i = 0; i < 3; ++i) launch();
     hipDeviceSynchronize();
@@ -43,6 +53,6 @@ int main(int argc, char** argv) {
     hipEventElapsedTime(&ms, e0, e1);
     ms /= 10;
     const double flops = 2.0 * boards * 361 * 256 * 128 * 9;
-    printf("half-convolution launch, %d boards, data mode %d: %.4f ms  %.1f TFLOP/s\n", boards, mode, ms, flops / ms / 1e9);
+    printf("half-convolution launch (variant %d), %d boards, data mode %d: %.4f ms  %.1f TFLOP/s\n", variant, boards, mode, ms, flops / ms / 1e9);
     return 0;
 }
