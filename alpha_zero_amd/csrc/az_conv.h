@@ -374,7 +374,12 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: its unit-0 epilogue stores were skipped
                     CV_BARRIER();
                 }
-#ifndef CP_ABL_NO_FRAG
+#if defined(CP_ABL_HALF_FRAG)  // timing only: every second k-step re-uses stale fragments (half the LDS stream, wrong results)
+                if constexpr ((t & 1) == 0) {
+                    if constexpr (t + 3 < NSTEP) load_step(b0, b1, t + 3, (u * NSTEP + t + 3) & 3);
+                    else load_step(nb0, nb1, t + 3 - NSTEP, (u * NSTEP + t + 3) & 3);
+                }
+#elif !defined(CP_ABL_NO_FRAG)
                 if constexpr (t + 3 < NSTEP) load_step(b0, b1, t + 3, (u * NSTEP + t + 3) & 3);
                 else load_step(nb0, nb1, t + 3 - NSTEP, (u * NSTEP + t + 3) & 3);
 #endif

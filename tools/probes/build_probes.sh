@@ -6,7 +6,7 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-strict-aliasing -
 /opt/rocm/bin/hipcc $F -o mfma_power_probe mfma_power_probe.hip
 /opt/rocm/bin/hipcc $F -o mfma_reuse_probe mfma_reuse_probe.hip
 /opt/rocm/bin/hipcc $F -o mfma_lds_probe mfma_lds_probe.hip
-for v in FULL NO_DMA DMA_MASK0 DMA_SAMESRC NO_EPI NO_STORE NO_RESLOAD NO_FRAG; do
+for v in FULL NO_DMA DMA_MASK0 DMA_SAMESRC NO_EPI NO_STORE NO_RESLOAD NO_FRAG HALF_FRAG; do
   D=""; [ $v != FULL ] && D="-DCP_ABL_$v"
   /opt/rocm/bin/hipcc $F $D -o conv_pipe_probe_$v conv_pipe_probe.hip
 done
