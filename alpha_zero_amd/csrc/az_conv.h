@@ -168,6 +168,10 @@ __device__ __forceinline__ unsigned cw_pk_max_i16(unsigned a, unsigned b) {
 // instructions per k-step, the B-fragment ring runs on across unit and tile boundaries, the next tile's LDS-DMA pieces ride in units
 // 0-2, and the only synchronisation per tile is one barrier (3 k-steps before the end of unit 3, when every read of the
 // current buffer has been issued) behind an exactly counted s_waitcnt vmcnt(N) that leaves the younger stores in flight.
+#ifndef CP_RING
+#define CP_RING 4  // slots of the B-fragment ring: a k-step's fragments are requested CP_RING - 1 k-steps ahead (6 measured the same:
+                  // the stream is not waiting on fragment latency, profiles/r02_conv_ablation.txt)
+#endif
 template <int V> struct CpInt {
     static constexpr int value = V;
 };
@@ -205,7 +209,7 @@ template <int NSTEP> struct CpSched {  // static schedule of one unit's k-steps 
         const int k = (t - E0) / PSTRIDE;
         return k < 8 ? k : -1;
     }
-    static constexpr int BAR_STEP = NSTEP - 3;  // unit 3: barrier before the first fragment loads of the next tile
+    static constexpr int BAR_STEP = NSTEP - (CP_RING - 1);  // unit 3: barrier before the first fragment loads of the next tile
     static constexpr int RL0 = NSTEP >= 72 ? 40 : 0;  // first k-step of the unit's residual loads (late: the two sets' live ranges barely overlap)
     // VMEM operations issued after the last DMA piece and before the barrier: stores of unit 1's epilogue still to come in unit 2,
     // unit 3's residual loads (8, k-steps 0-3) and the stores of unit 2's epilogue (all before BAR_STEP)
@@ -279,7 +283,7 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     for (int ct = 0; ct < 8; ++ct)
         lmap[ct] = (unsigned)((cw_map.cell[ct * 32 + l31] - CT_CELL0) * 16 + hi * CT_LBLK) | ((unsigned)cw_map.pos[ct * 32 + l31] << 16);
 
-    cv_bf16x8 bb[4][2];  // ring of B fragments: k-step s of the running unit lives in slot s & 3
+    cv_bf16x8 bb[CP_RING][2];  // ring of B fragments: running k-step s lives in slot s % CP_RING
     // k-step s of a unit: tap s / KS = constant cell offset, cin chunks 2 (s % KS) + hi; `slot` = (running k-step count) & 3
     auto load_step = [&](const unsigned char* b0, const unsigned char* b1, int s, int slot) {
         const int tap = s / KS, ks = s % KS;
@@ -287,7 +291,7 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         bb[slot][0] = *(const cv_bf16x8*)(b0 + off);
         bb[slot][1] = *(const cv_bf16x8*)(b1 + off);
     };
-    static_assert((4 * NSTEP) % 4 == 0, "a tile's k-steps keep the ring phase");
+    static_assert((4 * NSTEP) % CP_RING == 0, "a tile's k-steps keep the ring phase");
 
     {   // first tile: all pieces at once, then the first fragments
         const unsigned char* src = x + (size_t)blockIdx.x * XTILE;
@@ -295,9 +299,8 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         for (int i = 0; i < NPIECE; ++i) dma_piece(src, lds0, true, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CV_BARRIER();
-        load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), 0, 0);
-        load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), 1, 1);
-        load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), 2, 2);
+#pragma unroll
+        for (int i = 0; i < CP_RING - 1; ++i) load_step(lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), i, i);
     }
     cv_f32x16 acc[2][2];   // [unit parity][column tile]
     cv_u32x2 rr[2][2][4];  // residual of the unit: [unit parity][column tile][register quad]
@@ -376,17 +379,17 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                 }
 #if defined(CP_ABL_HALF_FRAG)  // timing only: every second k-step re-uses stale fragments (half the LDS stream, wrong results)
                 if constexpr ((t & 1) == 0) {
-                    if constexpr (t + 3 < NSTEP) load_step(b0, b1, t + 3, (u * NSTEP + t + 3) & 3);
-                    else load_step(nb0, nb1, t + 3 - NSTEP, (u * NSTEP + t + 3) & 3);
+                    if constexpr (t + CP_RING - 1 < NSTEP) load_step(b0, b1, t + CP_RING - 1, (u * NSTEP + t + CP_RING - 1) % CP_RING);
+                    else load_step(nb0, nb1, t + CP_RING - 1 - NSTEP, (u * NSTEP + t + CP_RING - 1) % CP_RING);
                 }
 #elif !defined(CP_ABL_NO_FRAG)
-                if constexpr (t + 3 < NSTEP) load_step(b0, b1, t + 3, (u * NSTEP + t + 3) & 3);
-                else load_step(nb0, nb1, t + 3 - NSTEP, (u * NSTEP + t + 3) & 3);
+                if constexpr (t + CP_RING - 1 < NSTEP) load_step(b0, b1, t + CP_RING - 1, (u * NSTEP + t + CP_RING - 1) % CP_RING);
+                else load_step(nb0, nb1, t + CP_RING - 1 - NSTEP, (u * NSTEP + t + CP_RING - 1) % CP_RING);
 #endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if constexpr (t < 64) cw_mfma_a(acc[q][j], wf[t], bb[(u * NSTEP + t) & 3][j]);
-                    else cw_mfma_v(acc[q][j], wf[t], bb[(u * NSTEP + t) & 3][j]);
+                    if constexpr (t < 64) cw_mfma_a(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
+                    else cw_mfma_v(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
                 }
                 // ---- riders of this k-step -------------------------------------------------------------------------------------
                 if constexpr (t == NSTEP - 6) acc[pq][0] = *bias_ptr;  // next unit's accumulators start from the bias
