@@ -112,6 +112,7 @@ class InferenceNet(nn.Module):
         self.binding = binding if channels_last else None
         self.use_fused_conv = True
         self.use_tiled_tower = True
+        self.use_fused_block = True  # 64-filter towers: azsp_resblock_tiled instead of two azsp_conv3x3_tiled launches per block
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.stem_pad = net.conv_block[0].padding[0]
         with torch.no_grad():
@@ -167,10 +168,11 @@ class InferenceNet(nn.Module):
             self.use_fused_fc = True
 
     def _tiled_tower_ok(self, x):
-        """Shapes with a weight-stationary tower kernel (azsp_conv3x3_tiled): 9x9 planes x 128 filters (Go 9x9), 17x17 planes x 64
-        filters (the 13x13 Gomoku network after its pad-3 stem) and 19x19 planes x 256 filters (the jumbo Go network)."""
+        """Shapes with a weight-stationary tower kernel (azsp_conv3x3_tiled / azsp_resblock_tiled): 9x9 planes x 128 filters (Go 9x9),
+        17x17 planes x 64 filters (the 13x13 Gomoku network after its pad-3 stem), 9x9 planes x 64 filters (the reference's 9x9_12b64
+        run) and 19x19 planes x 256 filters (the jumbo Go network)."""
         return (self.binding is not None and self.use_fused_conv and self.use_tiled_tower and x.is_cuda and x.dtype == torch.bfloat16
-                and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17), (256, 19))
+                and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17), (64, 9), (256, 19))
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     def _conv(self, x, i, res=None):
@@ -211,6 +213,13 @@ class InferenceNet(nn.Module):
     def _blocks_tiled(self, a, m, o, B, S, C, st):
         """All residual blocks on tiled buffers; returns the buffer holding the tower output."""
         dll, ck = self.binding.dll, self._ck
+        if self.use_fused_block and (C, S) in ((64, 17), (64, 9)):
+            # 64 filters: both filter banks of a block fit in a CU's registers -> one launch per ResNetBlock, intermediate in LDS
+            for i in range(self.n_blocks):
+                ck(dll.azsp_resblock_tiled(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), self.wp[2 * i + 1].data_ptr(),
+                                           self.b32[2 * i + 1].data_ptr(), o.data_ptr(), B, S, C, st), "azsp_resblock_tiled")
+                a, o = o, a
+            return a
         for i in range(self.n_blocks):
             ck(dll.azsp_conv3x3_tiled(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
                "azsp_conv3x3_tiled")
@@ -226,14 +235,14 @@ class InferenceNet(nn.Module):
             return "hand-written: tiled stem / tower / head / FC kernels (libazsp)"
         if torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and self.binding is not None:
             s = board_size + 2 * (self.stem_pad - 1)
-            if (self.filters, s) in ((128, 9), (64, 17), (256, 19)):
+            if (self.filters, s) in ((128, 9), (64, 17), (64, 9), (256, 19)):
                 return "hand-written tower (azsp_conv3x3_tiled) behind a library stem and heads"
         return f"library convolutions + azsp_bias_act epilogue (no hand-written kernel for {self.filters} filters on {board_size}x{board_size}, {self.dtype})"
 
     def supports_tiled_features(self, board_size, device):
-        """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled): 9x9 Go with 128
-        filters (pad-1 stem), 13x13 Gomoku with 64 filters (pad-3 stem, 17x17 planes) and 19x19 Go with 256 filters."""
-        shape_ok = (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 13, 3), (256, 19, 1))
+        """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled): 9x9 Go with 128 or
+        64 filters (pad-1 stem), 13x13 Gomoku with 64 filters (pad-3 stem, 17x17 planes) and 19x19 Go with 256 filters."""
+        shape_ok = (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 9, 1), (64, 13, 3), (256, 19, 1))
         return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and shape_ok
                 and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
 

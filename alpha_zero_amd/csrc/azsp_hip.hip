@@ -99,16 +99,22 @@ static int cu_count() {
 }
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* st) {
-    if (S == C6_S && C == C6_C) {  // 17x17 planes, 64 filters (13x13 Gomoku network): one board per tile
+    if (C == C6_C && (S == 17 || S == 9)) {  // 64 filters: 17x17 planes (13x13 Gomoku network, one board per tile) or 9x9 Go (three boards per tile)
         const int n_cu = cu_count();
         if (n_cu < 0) return -1;
-        const unsigned grid = (unsigned)(boards < n_cu ? boards : n_cu);
-        if (res)
-            hipLaunchKernelGGL((k_conv3x3_t64<true, 8>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
-                               bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
-        else
-            hipLaunchKernelGGL((k_conv3x3_t64<false, 8>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
-                               bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+        const long long ntiles = S == 17 ? boards : (boards + 2) / 3;
+        const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(CW_THREADS);
+#define AZ_T64(GEO, RES)                                                                                                                   \
+    hipLaunchKernelGGL((k_conv3x3_t64<C6Geo<GEO>, RES, 8>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, \
+                       bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu)
+        if (S == 17) {
+            if (res) AZ_T64(17, true);
+            else AZ_T64(17, false);
+        } else {
+            if (res) AZ_T64(9, true);
+            else AZ_T64(9, false);
+        }
+#undef AZ_T64
         return AZ_HIP(hipGetLastError());
     }
     if (S == C9_S && C == 256) {  // 19x19 boards, 256 filters (jumbo Go network): two launches, one per 128-channel half of the input
@@ -140,13 +146,33 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
                            (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
     return AZ_HIP(hipGetLastError());
 }
+int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
+                          void* st) {
+    if (C != C6_C || (S != 17 && S != 9)) return 1;
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const long long ntiles = S == 17 ? boards : (boards + 2) / 3;
+    const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(CW_THREADS);  // one persistent workgroup per CU
+    if (S == 17)
+        hipLaunchKernelGGL((k_resblock64<C6Geo<17>>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w1, b1,
+                           (const unsigned short*)w2, b2, (unsigned char*)y, (int)ntiles);
+    else
+        hipLaunchKernelGGL((k_resblock64<C6Geo<9>>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w1, b1,
+                           (const unsigned short*)w2, b2, (unsigned char*)y, (int)ntiles);
+    return AZ_HIP(hipGetLastError());
+}
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
-    if (S == 13 && C == C6_C && pad == 3) {  // Gomoku: 13x13 boards -> 17x17 planes, one board per tile
-        const unsigned grid = (unsigned)(boards < n_cu ? boards : n_cu);
-        hipLaunchKernelGGL((k_conv3x3_t64<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
-                           bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+    if (C == C6_C && ((S == 13 && pad == 3) || (S == 9 && pad == 1))) {  // Gomoku: 13x13 boards -> 17x17 planes; Go 9x9 x 64: three boards per tile
+        const long long ntiles = S == 13 ? boards : (boards + 2) / 3;
+        const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(CW_THREADS);
+        if (S == 13)
+            hipLaunchKernelGGL((k_conv3x3_t64<C6Geo<17>, false, 4>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+                               bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)ntiles, relu);
+        else
+            hipLaunchKernelGGL((k_conv3x3_t64<C6Geo<9>, false, 4>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
+                               bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)ntiles, relu);
         return AZ_HIP(hipGetLastError());
     }
     if (S == C9_S && C == 256 && pad == 1) {  // 19x19 Go: 17 planes (padded to 32) -> 256 filters, one launch

@@ -518,6 +518,8 @@ int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* strea
 // returns 0 ok, 1 unsupported shape, -1 launch error
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* stream);
+int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
+                          void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
@@ -958,6 +960,14 @@ int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const vo
     if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t boards, int32_t S, int32_t C,
+                        void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_resblock_tiled(x, w1, b1, w2, b2, y, (long long)boards, S, C, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -291,12 +291,20 @@ def main(argv=None):
         rows = eng.rows
         S_t = n + 2 * (inf.stem_pad - 1)  # tower planes (17x17 behind the Gomoku pad-3 stem)
         reps = 5
+        fused = inf.use_fused_block and (args.filters, S_t) in ((64, 17), (64, 9))  # one launch per ResNetBlock (azsp_resblock_tiled)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps * inf.n_blocks + 1)]
         torch.cuda.synchronize(dev)
         k = 0
         ev[0].record()
         for _ in range(reps):
             for i in range(inf.n_blocks):  # the forward's own launch sequence, one event after every launch
+                if fused:
+                    assert dll.azsp_resblock_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), inf.wp[2 * i + 1].data_ptr(),
+                                                   inf.b32[2 * i + 1].data_ptr(), o.data_ptr(), rows, S_t, args.filters, st) == 0
+                    k += 1
+                    ev[k].record()
+                    a, o = o, a
+                    continue
                 assert dll.azsp_conv3x3_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
                 k += 1
                 ev[k].record()
@@ -307,8 +315,8 @@ def main(argv=None):
                 a, o = o, a
         torch.cuda.synchronize(dev)
         d = [ev[j].elapsed_time(ev[j + 1]) for j in range(k)]
-        conv = {"launches": k, "avg_ms": float(np.mean(d)), "avg_ms_plain": float(np.mean(d[0::2])), "avg_ms_residual": float(np.mean(d[1::2])),
-                "planes": S_t}
+        conv = {"launches": k, "avg_ms": float(np.mean(d)), "planes": S_t, "fused_block": fused,
+                "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2]))}
 
     if args.split_round and rank == 0:
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -341,18 +349,18 @@ def main(argv=None):
         # expand/backup kernel: prior + value in, P/N/W rows out, N and W read-modify-write per path edge (+ vloss revert)
         bk_bytes = (expanded * (12 * A + 4 * A + 4) + cnt["backup_edges"] * 16 + cnt["leaves"] * 8 * 4.5) / steps
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, tsrc = None, None
         prof = os.path.join(ROOT, "profiles", "select_kernel_pmc.json")
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
                 if pj.get("games") == args.games and pj.get("board") == n:
-                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic, tsrc = pj.get("hbm_bytes_per_launch"), "from_profiles: profiles/select_kernel_pmc.json (separate rocprofv3 --pmc pass, not this run)"
             except Exception:
                 traffic = None
         engine_roof = {"kernel": "k_game<OpSelect> (PUCT descents + virtual loss + observation planes)", "bound": "hbm",
                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                       "traffic": traffic, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4),
+                       "traffic": traffic, "traffic_source": tsrc, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4),
                        "share_of_step": round(k_ms / (elapsed_max / steps * 1e3), 4),
                        "backup_kernels": {"avg_ms": round(bk_ms, 4), "alg_bytes_per_launch": round(bk_bytes),
                                           "achieved_GBs": round(bk_bytes / (bk_ms * 1e-3) / 1e9, 2)}}
@@ -369,27 +377,44 @@ def main(argv=None):
             # convolution (padding taps counted, the usual convention): 2 * rows * N^2 * C * C * 9 flop.
             rows = args.games * args.parallel
             S_t = conv["planes"]
-            conv_flops = 2.0 * rows * S_t * S_t * args.filters * args.filters * 9
+            fused = conv["fused_block"]
+            convs_per_launch = 2 if fused else 1
+            conv_flops = 2.0 * rows * S_t * S_t * args.filters * args.filters * 9 * convs_per_launch
             tf = conv_flops / (conv["avg_ms"] * 1e-3) / 1e12
-            ctraffic = None
-            cprof = os.path.join(ROOT, "profiles", "conv_kernel_pmc.json" if S_t == 9 else "conv64_kernel_pmc.json")
+            # HBM traffic per launch is NOT measured in this run: it comes from a separate `rocprofv3 --pmc` pass (the guide's recipe:
+            # counters in their own run) whose summary is committed under profiles/ -- labelled as such in `traffic_source`
+            ctraffic, csrc = None, None
+            cname = "block64_kernel_pmc.json" if fused else ("conv_kernel_pmc.json" if (S_t == 9 and args.filters == 128) else "conv64_kernel_pmc.json")
+            cprof = os.path.join(ROOT, "profiles", cname)
             if os.path.exists(cprof):
                 try:
                     pj = json.load(open(cprof))
                     if pj.get("rows") == rows and pj.get("board") == n and pj.get("channels") == args.filters:
-                        ctraffic = pj.get("hbm_bytes_per_launch")
+                        ctraffic, csrc = pj.get("hbm_bytes_per_launch"), "from_profiles: profiles/" + cname + " (separate rocprofv3 --pmc pass, not this run)"
                 except Exception:
                     ctraffic = None
-            kname = {9: "k_conv3x3_tiled", 17: "k_conv3x3_t64", 19: "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get(S_t, "conv3x3")
-            roofline = {"kernel": kname + " (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)",
+            if fused:
+                kname = "k_resblock64 (one whole ResNetBlock per launch: both 3x3 convolutions, intermediate activation in LDS, skip from the resident input tile)"
+                passes = 2.0   # x in, y out
+            else:
+                kname = {(9, 128): "k_conv3x3_tiled", (17, 64): "k_conv3x3_t64", (9, 64): "k_conv3x3_t64",
+                         (19, 256): "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get((S_t, args.filters), "conv3x3")
+                kname += " (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)"
+                passes = 4.5 if S_t == 19 else 2.5
+            launches_per_step = args.blocks * (1 if fused else 2)
+            roofline = {"kernel": kname,
                         "bound": "mfma",
-                        "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5), "traffic": ctraffic,
-                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * (4.5 if S_t == 19 else 2.5)),
-                        "avg_launch_ms": round(conv["avg_ms"], 4), "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4),
-                        "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4), "launches_per_step": 2 * args.blocks,
-                        "share_of_step": round(2 * args.blocks * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4),
-                        # measured MFMA-only ceiling on post-ReLU-like operands at the 1400 W package limit (profiles/r02_mfma_power_probe.txt)
-                        "power_limited_mfma_only_tflops": 1840.0, "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
+                        "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5), "traffic": ctraffic, "traffic_source": csrc,
+                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * passes),
+                        "avg_launch_ms": round(conv["avg_ms"], 4),
+                        "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4) if conv["avg_ms_plain"] is not None else None,
+                        "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4) if conv["avg_ms_residual"] is not None else None,
+                        "launches_per_step": launches_per_step,
+                        "share_of_step": round(launches_per_step * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4),
+                        # annotation, not a measurement of this run: the MFMA-only ceiling on post-ReLU-like operands at the 1400 W package
+                        # limit, measured by tools/probes/mfma_power_probe.hip
+                        "power_limited_mfma_only_tflops": {"value": 1840.0, "source": "from_profiles: profiles/r02_mfma_power_probe.txt"},
+                        "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
         else:
             roofline = engine_roof
         fp32 = None

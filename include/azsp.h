@@ -30,6 +30,7 @@
  *                                     (utils/transformation.py:34-110)
  *   azsp_bias_act                     BatchNorm + residual add + ReLU after each convolution (core/network.py:42-82)
  *   azsp_conv3x3_tiled                a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
+ *   azsp_resblock_tiled               a whole ResNetBlock of a 64-filter tower in one launch (intermediate activation in LDS)
  *   azsp_tile_layout / azsp_tiled_bytes the tower's resident activation layout
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
@@ -234,10 +235,19 @@ int azsp_tile_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t
 /* Fused 3x3 convolution of the residual tower (core/network.py:42-82, eval mode, BatchNorm folded) on the tiled layout:
  * y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y tiled bf16, w_packed [9 taps (ky*3+kx)][C out][C in] bf16, bias
  * float[C].  Weight-stationary MFMA kernels, the filter bank stays in the registers of persistent workgroups.  On the device:
- * (S, C) = (9, 128) 9x9 Go, (17, 64) the 13x13 Gomoku tower, (19, 256) the jumbo Go tower (two launches per convolution, the
+ * (S, C) = (9, 128) 9x9 Go, (17, 64) the 13x13 Gomoku tower, (9, 64) 9x9 Go with 64 filters, (19, 256) the jumbo Go tower (two launches per convolution, the
  * partial sum lives in y: x and residual must not alias y); AZSP_EINVAL for other shapes. */
 int azsp_conv3x3_tiled(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                        int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+
+/* One whole ResNetBlock (core/network.py:42-82: conv3x3 + BN + ReLU + conv3x3 + BN, + skip, ReLU; eval mode, BatchNorm folded) of a
+ * 64-filter tower in ONE launch on the tiled layout: y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2 + x).  The intermediate
+ * activation stays in LDS and the skip is taken from the input tile already resident there, so a block moves two tensor passes
+ * through HBM instead of five; results are bit-identical to two azsp_conv3x3_tiled calls (same MFMA order, same two bf16 roundings).
+ * w1 / w2 packed [9 taps][64 out][64 in] bf16, b1 / b2 float[64]; y may alias x.  On the device: (S, C) = (17, 64) the 13x13 Gomoku
+ * tower, (9, 64) the 9x9 Go tower with 64 filters (logs/go/9x9_12b64); AZSP_EINVAL for other shapes. */
+int azsp_resblock_tiled(const void* x_dev, const void* w1_packed_dev, const float* bias1_dev, const void* w2_packed_dev, const float* bias2_dev,
+                        void* y_dev, int64_t boards, int32_t board_size, int32_t channels, void* stream);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch
  * tensors and apply_random_transformation): out_states[b] = T_op(ring_states[idx[b]]) cast to state_dtype (AZSP_FEAT_I8 / F32 /
@@ -253,7 +263,7 @@ int azsp_replay_gather(const int8_t* ring_states_dev, const float* ring_pi_dev, 
  * channels: [tile][4][3*S*S][8] bf16, azsp_tiled_bytes(rows, S, 32) bytes); w_packed is [9 taps][C out][32 in] bf16 (input
  * channels 17..31 zero), the output is the tower's tiled layout with planes of board_size + 2 (pad - 1): pad = 1 for Go, pad = 3
  * for Gomoku (core/network.py:101-105: 13x13 boards become 17x17 planes).  Same kernels as azsp_conv3x3_tiled with 4 input chunks;
- * on the device: (board 9, 128 filters, pad 1) and (board 13, 64 filters, pad 3). */
+ * on the device: (board 9, 128 filters, pad 1), (board 9, 64 filters, pad 1), (board 13, 64 filters, pad 3) and (board 19, 256 filters, pad 1). */
 int azsp_stem_tiled(const void* features_tiled_dev, const void* w_packed_dev, const float* bias_dev, void* y_tiled_dev, int64_t boards,
                     int32_t board_size, int32_t channels, int32_t pad, int32_t relu, void* stream);
 /* Both 1x1 head convolutions (core/network.py:131-156: conv1x1 + BatchNorm + ReLU of the policy and the value head) in one

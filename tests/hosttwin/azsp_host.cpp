@@ -68,6 +68,17 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
     host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
     return 0;
 }
+int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
+                          void*) {
+    // plain loops: y = relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x), the intermediate rounded to bf16 like the kernel's LDS image
+    const size_t n = (size_t)boards * S * S * C;
+    std::vector<unsigned short> xn(n), mn(n), yn(n);
+    host_tile_layout((const unsigned short*)x, xn.data(), boards, S, C, 0);
+    cv_host_conv3x3(xn.data(), (const unsigned short*)w1, b1, nullptr, mn.data(), (int)boards, S, C, 1);
+    cv_host_conv3x3(mn.data(), (const unsigned short*)w2, b2, xn.data(), yn.data(), (int)boards, S, C, 1);
+    host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
+    return 0;
+}
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*) {
     // un-tile the 32-channel features, embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1), pad-1 convolution
     const int So = S + 2 * (pad - 1), off = pad - 1;

@@ -234,6 +234,7 @@ def test_gpu_stem_head_tiled_match_torch(boards):
 
     _stem_head_checks(_lib.load(), boards, 128, 9, "cuda")
     _stem_head_checks(_lib.load(), boards, 64, 13, "cuda", pad=3)  # the Gomoku stem / heads (17x17 planes)
+    _stem_head_checks(_lib.load(), boards, 64, 9, "cuda")  # 9x9 Go with 64 filters (three boards per tile)
 
 
 @pytest.mark.gpu
@@ -320,6 +321,130 @@ def test_gpu_gomoku_network_tiled_tower():
     p3, v3 = inf.forward_tiled(eu.tile_features(x).cuda(), 70, 13)
     assert (p3 - p2).abs().max().item() <= 1e-2 and (v3 - v2).abs().max().item() <= 2e-2
     assert (p3.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v3.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
+    p3, v3 = p3.clone(), v3.clone()
+    inf.use_fused_block = False  # two launches per block: the fused block kernel must reproduce them bit for bit
+    p4, v4 = inf.forward_tiled(eu.tile_features(x).cuda(), 70, 13)
+    assert torch.equal(p4, p3) and torch.equal(v4, v3)
+
+
+def _resblock_checks(bnd, boards, C, S, device, bit_exact_vs_two_launches):
+    """azsp_resblock_tiled == relu(conv(relu(conv(x, w1) + b1), w2) + b2 + x): against fp32 torch on the same bf16 operands (the
+    intermediate rounded to bf16, as both kernel paths do) and, bit for bit, against two azsp_conv3x3_tiled launches."""
+    g = torch.Generator().manual_seed(300 + boards)
+    x = torch.randn(boards, C, S, S, generator=g).to(torch.bfloat16).to(device).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(C, C, 3, 3, generator=g) * (0.05 if C >= 64 else 0.2)).to(torch.bfloat16).to(device) for _ in range(2)]
+    bs = [torch.randn(C, generator=g).to(device) for _ in range(2)]
+    wps = [w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous() for w in ws]
+    n = bnd.dll.azsp_tiled_bytes(boards, S, C) // 2
+    xt, mt, y2, yf = (torch.zeros(n, dtype=torch.bfloat16, device=device) for _ in range(4))
+    assert bnd.dll.azsp_tile_layout(x.data_ptr(), xt.data_ptr(), boards, S, C, 1, None) == 0
+    x_before = xt.clone()
+    assert bnd.dll.azsp_resblock_tiled(xt.data_ptr(), wps[0].data_ptr(), bs[0].data_ptr(), wps[1].data_ptr(), bs[1].data_ptr(), yf.data_ptr(),
+                                       boards, S, C, None) == 0
+    assert bnd.dll.azsp_conv3x3_tiled(xt.data_ptr(), wps[0].data_ptr(), bs[0].data_ptr(), None, mt.data_ptr(), boards, S, C, 1, None) == 0
+    assert bnd.dll.azsp_conv3x3_tiled(mt.data_ptr(), wps[1].data_ptr(), bs[1].data_ptr(), xt.data_ptr(), y2.data_ptr(), boards, S, C, 1, None) == 0
+    y = torch.empty_like(x)
+    assert bnd.dll.azsp_tile_layout(yf.data_ptr(), y.data_ptr(), boards, S, C, 0, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    assert torch.equal(xt, x_before)  # the input tile is read-only
+    mid = torch.relu(torch.nn.functional.conv2d(x.float(), ws[0].float(), bs[0].float(), padding=1)).to(torch.bfloat16).float()
+    ref = torch.relu(torch.nn.functional.conv2d(mid, ws[1].float(), bs[1].float(), padding=1) + x.float())
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 1.0 / 64 * max(1.0, ref.abs().max().item()), err  # two bf16 roundings (a flipped rounding of the intermediate moves the output)
+    if bit_exact_vs_two_launches:
+        rows = boards * S * S  # valid positions; the rest of a ragged last tile is unspecified
+        tb = max(1, 256 // (S * S))
+        a = yf.view(-1, C // 8, tb * S * S, 8).permute(0, 2, 1, 3).reshape(-1, C)[:rows]
+        b = y2.view(-1, C // 8, tb * S * S, 8).permute(0, 2, 1, 3).reshape(-1, C)[:rows]
+        assert torch.equal(a, b)
+    # in place (y aliases x): a tile is wholly in LDS before its first output is stored
+    assert bnd.dll.azsp_resblock_tiled(xt.data_ptr(), wps[0].data_ptr(), bs[0].data_ptr(), wps[1].data_ptr(), bs[1].data_ptr(), xt.data_ptr(),
+                                       boards, S, C, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    rows = boards * S * S
+    tb = max(1, 256 // (S * S))
+    assert torch.equal(xt.view(-1, C // 8, tb * S * S, 8).permute(0, 2, 1, 3).reshape(-1, C)[:rows],
+                       yf.view(-1, C // 8, tb * S * S, 8).permute(0, 2, 1, 3).reshape(-1, C)[:rows])
+    assert bnd.dll.azsp_resblock_tiled(xt.data_ptr(), wps[0].data_ptr(), bs[0].data_ptr(), wps[1].data_ptr(), bs[1].data_ptr(), yf.data_ptr(),
+                                       boards, 11, C, None) != 0  # unsupported geometry is refused, never silently computed
+
+
+def test_resblock_abi_host_twin():
+    """azsp_resblock_tiled through the ABI on the host twin (plain loops), tiny shapes."""
+    import engine_util as eu
+
+    b = eu.hosttwin_binding()
+    for boards in (1, 4):
+        g = torch.Generator().manual_seed(boards)
+        C, S = 16, 5
+        x = torch.randn(boards, C, S, S, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        ws = [(torch.randn(C, C, 3, 3, generator=g) * 0.2).to(torch.bfloat16) for _ in range(2)]
+        bs = [torch.randn(C, generator=g) for _ in range(2)]
+        wps = [w.permute(2, 3, 0, 1).reshape(9, C, C).contiguous() for w in ws]
+        n = b.dll.azsp_tiled_bytes(boards, S, C) // 2
+        xt, yt = torch.zeros(n, dtype=torch.bfloat16), torch.zeros(n, dtype=torch.bfloat16)
+        assert b.dll.azsp_tile_layout(x.data_ptr(), xt.data_ptr(), boards, S, C, 1, None) == 0
+        assert b.dll.azsp_resblock_tiled(xt.data_ptr(), wps[0].data_ptr(), bs[0].data_ptr(), wps[1].data_ptr(), bs[1].data_ptr(), yt.data_ptr(),
+                                         boards, S, C, None) == 0
+        y = torch.empty_like(x)
+        assert b.dll.azsp_tile_layout(yt.data_ptr(), y.data_ptr(), boards, S, C, 0, None) == 0
+        mid = torch.relu(torch.nn.functional.conv2d(x.float(), ws[0].float(), bs[0].float(), padding=1)).to(torch.bfloat16).float()
+        ref = torch.relu(torch.nn.functional.conv2d(mid, ws[1].float(), bs[1].float(), padding=1) + x.float())
+        assert (y.float() - ref).abs().max().item() <= 1.0 / 64 * max(1.0, ref.abs().max().item())
+    assert b.dll.azsp_resblock_tiled(None, None, None, None, None, None, 1, 17, 64, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 2, 5, 255, 256, 257, 513, 1000, 3000])
+def test_gpu_resblock_gomoku_shape(boards):
+    """k_resblock64<17> (one launch per ResNetBlock, 17x17 planes x 64 filters): vs torch, and bit-identical to the two-launch path.
+    Board counts around one / two tiles per CU exercise the first-tile, has-next and last-tile paths of the persistent loop."""
+    from alpha_zero_amd import _lib
+
+    _resblock_checks(_lib.load(), boards, 64, 17, "cuda", True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 3, 4, 7, 767, 768, 770, 1539, 5000])
+def test_gpu_resblock_go9_64_shape(boards):
+    """k_resblock64<9> / k_conv3x3_t64<9> (9x9 planes x 64 filters, three boards per tile): the reference's 9x9_12b64 network shape."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    _tiled_roundtrip_and_conv(bnd, boards, 64, 9, "cuda")
+    _resblock_checks(bnd, boards, 64, 9, "cuda", True)
+
+
+@pytest.mark.gpu
+def test_gpu_go9_64_network_tiled_forward():
+    """9x9 Go with 64 filters (logs/go/9x9_12b64/run.log:1: 11 blocks x 64): the whole evaluator on the engine's tiled features (stem,
+    fused residual blocks, heads, FC) vs the same InferenceNet on the library path and vs the fp32 module."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(12)
+    net = AlphaZeroNet((17, 9, 9), 82, 4, 64, 64)
+    with torch.no_grad():
+        net.policy_head[4].weight.mul_(0.2)
+        net.value_head[6].weight.mul_(0.3)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    assert inf.supports_tiled_features(9, "cuda") and "hand-written" in inf.evaluator_path(9, "cuda")
+    x = (torch.rand(100, 17, 9, 9) > 0.6).float()
+    p1, v1 = inf.forward_tiled(eu.tile_features(x).cuda(), 100, 9)
+    p2, v2 = inf(x.cuda())  # NCHW entry: library stem, tiled fused tower
+    inf.use_tiled_tower = False
+    p3, v3 = inf(x.cuda())  # library convolutions throughout
+    inf.use_tiled_tower = True
+    assert (p1 - p2).abs().max().item() <= 1e-2 and (v1 - v2).abs().max().item() <= 2e-2
+    assert (p1 - p3).abs().max().item() <= 1e-2 and (v1 - v3).abs().max().item() <= 2e-2
+    logits, vr = net.eval()(x)
+    assert (p1.cpu() - torch.softmax(logits, -1)).abs().max().item() <= 2e-2 and (v1.cpu() - vr.squeeze(1)).abs().max().item() <= 3e-2
+    # fused blocks == two launches per block, bit for bit, through the whole forward
+    inf.use_fused_block = False
+    p4, v4 = inf.forward_tiled(eu.tile_features(x).cuda(), 100, 9)
+    assert torch.equal(p4, p1) and torch.equal(v4, v1)
 
 
 def test_tiled_bytes_rule_host_twin():

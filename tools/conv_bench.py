@@ -48,7 +48,34 @@ def lib(r):
     return t
 
 
+w2 = (torch.randn(C, C, 3, 3, generator=g) * 0.05).to(torch.bfloat16).cuda()
+wp2 = w2.permute(2, 3, 0, 1).reshape(9, C, C).contiguous()
+
+
+def block_fused(r):  # one whole ResNetBlock per launch (64-filter towers only)
+    assert b.dll.azsp_resblock_tiled(xt.data_ptr(), wp.data_ptr(), bias.data_ptr(), wp2.data_ptr(), bias.data_ptr(), yt.data_ptr(), B, S, C, st) == 0
+
+
+def block_two_launches(r):
+    b.dll.azsp_conv3x3_tiled(xt.data_ptr(), wp.data_ptr(), bias.data_ptr(), None, rt.data_ptr(), B, S, C, 1, st)
+    b.dll.azsp_conv3x3_tiled(rt.data_ptr(), wp2.data_ptr(), bias.data_ptr(), xt.data_ptr(), yt.data_ptr(), B, S, C, 1, st)
+
+
 flops = 2.0 * B * S * S * C * C * 9
+if C == 64:
+    for name, f in (("block_fused", block_fused), ("block_2_launches", block_two_launches)):
+        for _ in range(5):
+            f(None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            f(None)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"{name:16s} (2 convolutions)  {ms:8.3f} ms  {2 * flops / ms / 1e9:8.1f} TFLOP/s")
+    b.dll.azsp_tile_layout(res.data_ptr(), rt.data_ptr(), B, S, C, 1, st)  # block_two_launches used rt as its intermediate
 for name, f in (("tiled_ws", tiled), ("miopen+epilogue", lib), ("tile_layout", layout)):
     for r in (None, res):
         for _ in range(5):
