@@ -70,6 +70,7 @@ class Engine:
 
     def __init__(self, binding: Binding, cfg: EngineConfig, device="cuda"):
         self.b, self.cfg, self.device = binding, cfg, torch.device(device)
+        self.on_launch = None
         c = AzspConfig()
         c.game = _abi.GAME_GO if cfg.game == "go" else _abi.GAME_GOMOKU
         c.board_size, c.num_games, c.num_parallel, c.num_simulations = cfg.board_size, cfg.num_games, cfg.num_parallel, cfg.num_simulations
@@ -113,7 +114,10 @@ class Engine:
 
     def _stream(self):
         if self.device.type == "cuda":
-            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            cur = torch.cuda.current_stream(self.device)
+            if self.on_launch is not None:  # SelfPlayActor: joins its two half-batch streams before anything runs on another stream
+                self.on_launch(cur)
+            return C.c_void_p(cur.cuda_stream)
         return None
 
     def close(self):
@@ -171,11 +175,19 @@ class Engine:
         n = np.ascontiguousarray(noise, dtype=np.float64).reshape(self.G, self.A) if noise is not None else None
         self._ck(self.b.dll.azsp_begin_move(self.h, n.ctypes.data if n is not None else None, int(warm_up), self._stream()), "azsp_begin_move")
 
-    def select(self):
-        self._ck(self.b.dll.azsp_select(self.h, self.features.data_ptr(), self.valid.data_ptr(), self._stream()), "azsp_select")
+    def select(self, g0=None, g1=None):
+        """Select the next leaves of all games, or (g0, g1 given, g0 % 32 == 0) of the games [g0, g1) only."""
+        if g0 is None:
+            self._ck(self.b.dll.azsp_select(self.h, self.features.data_ptr(), self.valid.data_ptr(), self._stream()), "azsp_select")
+        else:
+            self._ck(self.b.dll.azsp_select_range(self.h, self.features.data_ptr(), self.valid.data_ptr(), g0, g1, self._stream()), "azsp_select_range")
 
-    def expand_backup(self):
-        self._ck(self.b.dll.azsp_expand_backup(self.h, self.priors.data_ptr(), self.values.data_ptr(), self._stream()), "azsp_expand_backup")
+    def expand_backup(self, g0=None, g1=None):
+        if g0 is None:
+            self._ck(self.b.dll.azsp_expand_backup(self.h, self.priors.data_ptr(), self.values.data_ptr(), self._stream()), "azsp_expand_backup")
+        else:
+            self._ck(self.b.dll.azsp_expand_backup_range(self.h, self.priors.data_ptr(), self.values.data_ptr(), g0, g1, self._stream()),
+                     "azsp_expand_backup_range")
 
     def round(self):
         """expand/backup with the current priors/values, then select the next leaves into features/valid."""

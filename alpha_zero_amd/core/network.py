@@ -197,13 +197,29 @@ class InferenceNet(nn.Module):
             y.add_(res)
         return F.relu_(y)
 
-    def _tiled_buffers(self, B, S, C, device):
+    def _tiled_buffers(self, B, S, C, device, slot=0):
+        """Three rotating tower buffers (block input, middle, block output) per `slot`: forwards that may be in flight at the same time
+        (SelfPlayActor's two half-batches on two streams) use different slots and never share scratch memory."""
         n = self.binding.dll.azsp_tiled_bytes(B, S, C) // 2
-        key = (n, device)
-        if getattr(self, "_tiled_key", None) != key:  # three rotating buffers: block input, middle, block output
-            self._tiled = [torch.zeros(n, dtype=torch.bfloat16, device=device) for _ in range(3)]
-            self._tiled_key = key
-        return self._tiled
+        cache = self.__dict__.setdefault("_tiled_cache", {})
+        key = (slot, n, str(device))
+        if key not in cache:
+            for k in [k for k in cache if k[0] == slot]:  # a slot holds one size at a time
+                del cache[k]
+            cache[key] = [torch.zeros(n, dtype=torch.bfloat16, device=device) for _ in range(3)]
+        if slot == 0:
+            self._tiled = cache[key]  # (bench.py replays the tower on the activations of the last full-batch forward)
+        return cache[key]
+
+    def _head_buffers(self, B, k1, k2, device, slot=0):
+        cache = self.__dict__.setdefault("_head_cache", {})
+        key = (slot, B, str(device))
+        if key not in cache:
+            for k in [k for k in cache if k[0] == slot]:
+                del cache[k]
+            cache[key] = (torch.zeros((B + 1, k1), dtype=torch.bfloat16, device=device), torch.zeros((B + 1, k2), dtype=torch.bfloat16, device=device),
+                          torch.empty((B, self.num_actions), dtype=torch.float32, device=device), torch.empty((B,), dtype=torch.float32, device=device))
+        return cache[key]
 
     @staticmethod
     def _ck(rc, what):
@@ -247,35 +263,31 @@ class InferenceNet(nn.Module):
                 and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
 
     @torch.no_grad()
-    def forward_tiled(self, feat, rows, board_size, priors_out=None, values_out=None):
-        """feat: the engine's AZSP_FEAT_BF16_TILED feature tensor for `rows` leaf positions.  Stem, tower and the 1x1 head
-        convolutions run on the tiled layout in hand-written kernels; only the small fully connected layers are library GEMMs."""
+    def forward_tiled(self, feat, rows, board_size, priors_out=None, values_out=None, slot=0):
+        """feat: the engine's AZSP_FEAT_BF16_TILED feature tensor for `rows` leaf positions (or a tile-aligned slice of it).  Stem,
+        tower, the 1x1 head convolutions and the fully connected layers run on the tiled layout in hand-written kernels.  `slot`
+        selects the scratch buffers (see _tiled_buffers)."""
         import ctypes
 
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream)
         B, C = rows, self.filters
         S = board_size + 2 * (self.stem_pad - 1)  # planes of the tower (network.py:101-105: the Gomoku stem pads by 3)
-        a, m, o = self._tiled_buffers(B, S, C, feat.device)
+        a, m, o = self._tiled_buffers(B, S, C, feat.device, slot)
         ck(dll.azsp_stem_tiled(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, board_size, C, self.stem_pad, 1, st),
            "azsp_stem_tiled")
         a = self._blocks_tiled(a, m, o, B, S, C, st)
         k1, k2 = self.fc_wp.shape[1], self.fc_w1.shape[1]  # head-plane rows padded to the k-steps of azsp_fc_heads (zero padding)
-        if getattr(self, "_head_key", None) != (B, feat.device):
-            self._pol = torch.zeros((B + 1, k1), dtype=torch.bfloat16, device=feat.device)
-            self._val = torch.zeros((B + 1, k2), dtype=torch.bfloat16, device=feat.device)
-            self._pri = torch.empty((B, self.num_actions), dtype=torch.float32, device=feat.device)
-            self._v = torch.empty((B,), dtype=torch.float32, device=feat.device)
-            self._head_key = (B, feat.device)
-        ck(dll.azsp_head_tiled(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), self._pol.data_ptr(), self._val.data_ptr(),
+        pol, val, pri_buf, v_buf = self._head_buffers(B, k1, k2, feat.device, slot)
+        ck(dll.azsp_head_tiled(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), pol.data_ptr(), val.data_ptr(),
                                B, S, C, self.npol, self.nval, k1, k2, st), "azsp_head_tiled")
         nt = ((self.num_actions + 31) // 32, (self.fc_width + 31) // 32)
         fused_fc = self.use_fused_fc and nt in ((3, 2), (3, 4), (6, 2), (6, 4), (12, 8))
         if not fused_fc:
-            return self._fc_heads(self._pol[:B, : self.npol * S * S], self._val[:B, : self.nval * S * S], priors_out, values_out)
-        pri = priors_out if priors_out is not None else self._pri
-        v = values_out if values_out is not None else self._v
-        ck(dll.azsp_fc_heads(self._pol.data_ptr(), self._val.data_ptr(), self.fc_wp.data_ptr(), self.fc_bp.data_ptr(), k1 // 16, self.fc_w1.data_ptr(),
+            return self._fc_heads(pol[:B, : self.npol * S * S], val[:B, : self.nval * S * S], priors_out, values_out)
+        pri = priors_out if priors_out is not None else pri_buf
+        v = values_out if values_out is not None else v_buf
+        ck(dll.azsp_fc_heads(pol.data_ptr(), val.data_ptr(), self.fc_wp.data_ptr(), self.fc_bp.data_ptr(), k1 // 16, self.fc_w1.data_ptr(),
                              self.fc_b1.data_ptr(), k2 // 16, self.fc_w2.data_ptr(), ctypes.c_float(self.fc_b2), pri.data_ptr(), v.data_ptr(), B,
                              self.num_actions, self.fc_width, st), "azsp_fc_heads")
         return pri, v

@@ -50,8 +50,7 @@ struct AzCfg {
     double eps, alpha, resign_threshold;
     RuleCfg rc;
     u64 seed;
-    int rank, dbg;  // dbg: timing diagnostics from AZSP_DEBUG_SELECT (tools/sel_abl.sh): 8 = no speculative prefetch, 16 / 32 = observation
-                    // planes twice, 64 = arg-max twice, 128 = rules step twice; none of them changes a result
+    int rank;
 };
 
 struct AzMem {
@@ -534,7 +533,6 @@ template <class Wv, int N, int GAME> struct Engine {
         for (;;) {
             const SR& r = depth == 0 ? sc.root : (cur_is_nxt ? sc.nxt : sc.cur);  // the root record lives in LDS for the whole round
             int mv = puct_argmax(r, depth == 0, pbc64, sq32);
-            if (c.dbg & 64) mv = puct_argmax(r, depth == 0, pbc64, sq32 + (mv < 0 ? 1.0f : 0.0f));  // diagnostics: the arg-max twice
             int child = Wv::uni((int)r.rC[mv]);
             const int hint = Wv::uni((int)r.rH[mv]);
             n_self = Wv::uni((int)r.rN[mv]);
@@ -555,7 +553,6 @@ template <class Wv, int N, int GAME> struct Engine {
                 child = alloc_node();
                 S ns;
                 R::template step<GAME>(hdr_of(r).st, mv, c.rc, ns);
-                if (c.dbg & 128) R::template step<GAME>(hdr_of(r).st, mv, c.rc, ns);  // diagnostics: the rules step twice
                 if (Wv::first()) {
                     Hdr& h = hdr(child);
                     h.st = ns;
@@ -582,7 +579,7 @@ template <class Wv, int N, int GAME> struct Engine {
                 SR& dst = depth == 1 ? sc.cur : (cur_is_nxt ? sc.nxt : sc.cur);
                 if (depth == 1) cur_is_nxt = 0;
                 SR& oth = cur_is_nxt ? sc.cur : sc.nxt;
-                if (hint >= 0 && hint != node && hint < c.max_nodes && !(c.dbg & 8)) {
+                if (hint >= 0 && hint != node && hint < c.max_nodes) {
                     stage_two(node, dst, hint, oth);
                     spec = hint;
                     cnt[AZC_HINT_PREFETCH]++;
@@ -817,11 +814,6 @@ template <class Wv, int N, int GAME> struct Engine {
                 const int me = leaf.to_play;
                 gather_planes(node, depth, me, &leaf);
                 write_features(feat, nleaf, me);
-                if (c.dbg & 16) {  // the same planes once more: the launch time grows by exactly their cost
-                    gather_planes(node, depth, me, &leaf);
-                    write_features(feat, nleaf, me);
-                }
-                if (c.dbg & 32) write_features(feat, nleaf, me);
                 nleaf++;
                 cnt[AZC_LEAVES]++;
             }

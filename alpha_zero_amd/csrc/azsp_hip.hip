@@ -13,11 +13,11 @@ static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
 
 template <int N, int GAME, class Op>
-__global__ void __launch_bounds__(256) k_game(const AzCfg c, const AzMem m, const Op op) {
+__global__ void __launch_bounds__(256) k_game(const AzCfg c, const AzMem m, const Op op, const int g0, const int g1) {
     __shared__ typename Engine<WaveDev, N, GAME>::SC sc[4];
     const int wave = (int)(threadIdx.x >> 6);
-    const int g = (int)blockIdx.x * 4 + wave;
-    if (g >= c.G) return;
+    const int g = g0 + (int)blockIdx.x * 4 + wave;  // games [g0, g1): a sub-range launch (g0 % 32 == 0) keeps every game on its XCD
+    if (g >= g1) return;
     Engine<WaveDev, N, GAME> e(c, m, g, sc[wave]);
     op(e);
 }
@@ -64,9 +64,9 @@ int set_device(int dev) {
     return AZ_HIP(hipSetDevice(dev));
 }
 const char* backend_error() { return hipGetErrorString(g_last); }
-template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* st) {
-    const dim3 grid((unsigned)((c.G + 3) / 4)), block(256);
-    hipLaunchKernelGGL((k_game<N, GAME, Op>), grid, block, 0, (hipStream_t)st, c, m, op);
+template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* st, int g0, int g1) {
+    const dim3 grid((unsigned)((g1 - g0 + 3) / 4)), block(256);
+    hipLaunchKernelGGL((k_game<N, GAME, Op>), grid, block, 0, (hipStream_t)st, c, m, op, g0, g1);
     return AZ_HIP(hipGetLastError());
 }
 int launch_dihedral(const DihedralArgs& a, long long total, void* st) {

@@ -511,7 +511,7 @@ int zero(void* dst, size_t n, void* stream);
 int sync(void* stream);
 int set_device(int dev);
 const char* backend_error();
-template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream);
+template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream, int g0, int g1);  // games [g0, g1)
 int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
 int launch_bias_act(const BiasActArgs& a, void* stream);
 int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* stream);
@@ -545,11 +545,12 @@ template <class T> static T* az_new(AzHandle* h, size_t count) {
     return (T*)p;
 }
 
-template <class Op> static int az_run(AzHandle* h, const Op& op, void* stream) {
+template <class Op> static int az_run(AzHandle* h, const Op& op, void* stream, int g0 = 0, int g1 = -1) {
     int rc = AZSP_EINVAL;
+    if (g1 < 0) g1 = h->cfg.G;
     switch (h->cfg.game * 100 + h->cfg.n) {
 #define AZ_CASE(NN, GG) \
-    case (GG) * 100 + (NN): rc = azb::launch<NN, GG, Op>(h->cfg, h->mem, op, stream); break;
+    case (GG) * 100 + (NN): rc = azb::launch<NN, GG, Op>(h->cfg, h->mem, op, stream, g0, g1); break;
         AZ_FOR_EACH_VARIANT(AZ_CASE)
 #undef AZ_CASE
         default: break;
@@ -653,7 +654,6 @@ int azsp_create(const AzspConfig* p, void** out) {
     c.rc.komi = p->komi;
     c.seed = p->seed;
     c.rank = p->rank;
-    c.dbg = getenv("AZSP_DEBUG_SELECT") ? atoi(getenv("AZSP_DEBUG_SELECT")) : 0;
     c.stage_cap = p->stop_after_move ? 1 : (p->game == AZSP_GAME_GO ? c.rc.max_steps : h->NP);
 
     const size_t G = (size_t)c.G;
@@ -814,6 +814,24 @@ int azsp_expand_backup(void* e, const float* priors, const float* values, void* 
     int rc = az_run(h, op, stream);
     if (rc) return rc;
     return az_run(h, OpEndMove(), stream);
+}
+
+static int az_range_ok(AzHandle* h, int32_t g0, int32_t g1) { return h && g0 >= 0 && g0 < g1 && g1 <= h->cfg.G && g0 % 32 == 0; }
+
+int azsp_select_range(void* e, void* feat, uint8_t* valid, int32_t g0, int32_t g1, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !feat || !valid || !az_range_ok(h, g0, g1)) return AZSP_EINVAL;
+    OpSelect op = {feat, valid};
+    return az_run(h, op, stream, g0, g1);
+}
+
+int azsp_expand_backup_range(void* e, const float* priors, const float* values, int32_t g0, int32_t g1, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !priors || !values || !az_range_ok(h, g0, g1)) return AZSP_EINVAL;
+    OpBackup op = {priors, values};
+    int rc = az_run(h, op, stream, g0, g1);
+    if (rc) return rc;
+    return az_run(h, OpEndMove(), stream, g0, g1);
 }
 
 int azsp_round(void* e, const float* priors, const float* values, void* feat, uint8_t* valid, void* stream) {

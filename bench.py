@@ -78,6 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="serial rounds on one stream instead of two half-batch streams (SelfPlayActor overlap_engine)")
     ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
     ap.add_argument("--preroll-rounds", type=int, default=300, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
     ap.add_argument("--preroll-moves", type=int, default=2, help="every slot must have committed this many searched moves before timing")
@@ -86,6 +87,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = all usable host cores (cgroup quota aware)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-evaluator companion measurement (fp32_moves_per_s)")
+    ap.add_argument("--no-fresh-tree", action="store_true",
+                    help="skip the sub-tree-reuse-off companion measurement (fresh_tree_moves_per_s, SURVEY 8d's upper-work variant)")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable torch.backends.cudnn.benchmark (MIOpen find) for the convs")
     ap.add_argument("--split-round", action="store_true", help="diagnostic: launch expand/backup and select as two kernels and time each")
     ap.add_argument("--launch-check", action="store_true",
@@ -130,8 +133,14 @@ def launch_check(world, rank, local_rank):
 # ---- the measurement flow (module level: tests/bench_flow_worker.py drives exactly these functions under gloo, 2 ranks, with a
 # host-twin actor, so the N-rank control flow the driver runs on 8 GPUs -- paired collectives, synchronised pre-roll exit, gather
 # inside the timed region, max-over-ranks timing -- is exercised on CPU; bench.py itself only ever builds GPU actors) -------------
+def pg_active():
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier(world, dev):
-    if world > 1:
+    if pg_active():  # every launcher-started run has a process group, a single-rank one included
         import torch.distributed as dist
 
         dist.barrier()
@@ -139,11 +148,16 @@ def barrier(world, dev):
         torch.cuda.synchronize(dev)
 
 
+HG_MS = []  # wall-clock of every harvest + gather of this rank (host side, includes the harvest's own stream synchronisation)
+
+
 def harvest_and_gather(act):
     from alpha_zero_amd.core.gather import gather_samples
 
+    t0 = time.perf_counter()
     st, pi, z, games = act.harvest_tensors()
     res = gather_samples(st, pi, z, games, dst=0)
+    HG_MS.append((time.perf_counter() - t0) * 1e3)
     return 0 if res is None else int(res[0].shape[0])
 
 
@@ -164,7 +178,7 @@ def preroll(act, args, world, dev, min_rounds=None):
             st, _ = e.status()
             moved = np.where(st[:, 5] > done0, args.preroll_moves, st[:, 1] - ply0)
             ok = torch.tensor([1.0 if moved.min() >= args.preroll_moves else 0.0], device=dev)
-            if world > 1:  # all ranks leave the pre-roll together (their harvest / gather calls must stay paired)
+            if pg_active():  # all ranks leave the pre-roll together (their harvest / gather calls must stay paired)
                 import torch.distributed as dist
 
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -183,9 +197,11 @@ def timed(act, args, world, dev, warmup, steps):
     barrier(world, dev)
     harvest_and_gather(act)
     act.counters(reset=True)
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if dev.type == "cuda" else [None] * steps
+    serial = dev.type == "cuda" and not getattr(act, "overlap", False)  # per-kernel events only mean something in the serial mode
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if serial else [None] * steps
     gathered = 0
     barrier(world, dev)
+    del HG_MS[:]
     t0 = time.perf_counter()
     for i in range(steps):
         act.run_round(evs[i])
@@ -199,13 +215,31 @@ def reduce_totals(cnt, elapsed, world, dev):
     """Whole-job totals: moves / sims / evaluations summed over ranks, elapsed = MAX over ranks."""
     tot = torch.tensor([float(cnt["moves"]), float(cnt["sims"]), float(cnt["leaves"])], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if pg_active():
         import torch.distributed as dist
 
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_moves, total_sims, total_evals = (float(x) for x in tot.tolist())
     return float(tmax.item()), total_moves, total_sims, total_evals
+
+
+def per_rank_report(cnt, elapsed, world, dev):
+    """What every rank did inside its own timed region, so that an N-GPU line explains itself: moves/s per rank (own clock), and the
+    mean wall-clock of one harvest + gather call (the only inter-rank exchange of the data path) per rank."""
+    mine = torch.tensor([cnt["moves"] / max(elapsed, 1e-9), float(np.mean(HG_MS)) if HG_MS else 0.0, float(np.max(HG_MS)) if HG_MS else 0.0,
+                         float(len(HG_MS))], dtype=torch.float64, device=dev)
+    rows = [mine]
+    if pg_active():
+        import torch.distributed as dist
+
+        rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+    t = torch.stack(rows).cpu().numpy()
+    return {"moves_per_s": [round(float(v), 1) for v in t[:, 0]], "min_moves_per_s": round(float(t[:, 0].min()), 1),
+            "max_moves_per_s": round(float(t[:, 0].max()), 1), "harvest_gather_ms_mean": [round(float(v), 3) for v in t[:, 1]],
+            "harvest_gather_ms_max": round(float(t[:, 2].max()), 3), "harvest_gather_calls": int(t[0, 3]),
+            "harvest_gather_share_of_time": round(float((t[:, 1] * t[:, 3]).max() / max(elapsed * 1e3, 1e-9)), 5)}
 
 
 def main(argv=None):
@@ -234,12 +268,14 @@ def main(argv=None):
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} has no HIP device ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    rccl_ranks = 1
-    if world > 1:
+    rccl_ranks, process_group = 1, None
+    if "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ:
+        # started by a launcher (torch.distributed.run), with ANY world size: rendezvous over RCCL.  A single-rank group is still a
+        # group -- barriers, the count all_gather and the packed sample gather all execute (tests/test_nccl_single_rank.py)
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=dev)
-        rccl_ranks = dist.get_world_size()
+        rccl_ranks, process_group = dist.get_world_size(), dist.get_backend()
 
     from alpha_zero_amd.core.network import AlphaZeroNet
     from alpha_zero_amd.core.pipeline import SelfPlayActor
@@ -251,11 +287,12 @@ def main(argv=None):
     DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
     torch.backends.cudnn.benchmark = not args.no_miopen_find
 
-    def make_actor(dtype_name):
+    def make_actor(dtype_name, reuse_tree=True):
         """Engine + evaluator in the steady state: staggered openings, then the argument-independent pre-roll."""
         act = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
                             warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=DT[dtype_name],
-                            use_graph=not args.no_graph)
+                            use_graph=not args.no_graph, engine_kw=None if reuse_tree else {"reuse_tree": False},
+                            overlap_engine=False if args.no_overlap else None)
         e = act.engine
         if args.stagger > 0:  # mixed game phases from the first round (documented in DESIGN.md "Measurement")
             rng = np.random.Generator(np.random.PCG64(1234 + rank))
@@ -272,11 +309,23 @@ def main(argv=None):
     eng = actor.engine
     preroll_rounds = preroll(actor, args, world, dev)
     elapsed, cnt, evs, samples_at_root = timed(actor, args, world, dev, args.warmup, args.steps)
+    overlapped = bool(getattr(actor, "overlap", False))
+    if overlapped:
+        # two half-batch streams: the kernels of the halves interleave, so the per-kernel durations come from a short SERIAL pass
+        # (whole batch, one stream) after the timed region; `value` / `ms_per_step` are from the overlapped timed region above
+        actor.overlap = False
+        actor.run_rounds(3)
+        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(20)]
+        for ev4 in evs:
+            actor.run_round(ev4)
+        torch.cuda.synchronize(dev)
+        actor.overlap = True
     bk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # expand/backup + end-of-move kernels
     k_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))   # select kernel (the dominant hand-written kernel)
     nn_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
 
     elapsed_max, total_moves, total_sims, total_evals = reduce_totals(cnt, elapsed, world, dev)
+    ranks = per_rank_report(cnt, elapsed, world, dev)
     if total_moves <= 0:
         raise SystemExit("bench.py: no move was committed inside the timed region -- the pre-roll did not reach the steady state")
 
@@ -319,6 +368,7 @@ def main(argv=None):
                 "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2]))}
 
     if args.split_round and rank == 0:
+        actor.overlap = False
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ta = tb = 0.0
         for _ in range(20):
@@ -332,6 +382,7 @@ def main(argv=None):
             ta += ea[0].elapsed_time(ea[1]) / 20
             tb += ea[1].elapsed_time(ea[2]) / 20
         print(json.dumps({"split_round_ms": {"expand_backup_endmove": round(ta, 4), "select_features": round(tb, 4)}}), flush=True)
+        actor.overlap = overlapped
     if rank == 0:
         # ---- roofline of the dominant hand-written kernel: the fused round kernel (HBM bound) ----------
         e_bytes = {"bf16": 2, "fp16": 2, "fp32": 4}[args.net_dtype]
@@ -361,7 +412,7 @@ def main(argv=None):
         engine_roof = {"kernel": "k_game<OpSelect> (PUCT descents + virtual loss + observation planes)", "bound": "hbm",
                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                        "traffic": traffic, "traffic_source": tsrc, "alg_bytes_per_launch": round(alg_bytes), "avg_launch_ms": round(k_ms, 4),
-                       "share_of_step": round(k_ms / (elapsed_max / steps * 1e3), 4),
+                       "share_of_step": round(k_ms / (bk_ms + k_ms + nn_ms), 4),
                        "backup_kernels": {"avg_ms": round(bk_ms, 4), "alg_bytes_per_launch": round(bk_bytes),
                                           "achieved_GBs": round(bk_bytes / (bk_ms * 1e-3) / 1e9, 2)}}
         flops_eval = net_flops_per_eval(n, A, args.blocks, args.filters, args.filters, game != "go")
@@ -370,7 +421,7 @@ def main(argv=None):
         nn_roof = {"kernel": "whole evaluator forward on G*P rows (stem + tower + heads)", "bound": "mfma",
                    "achieved": round(nn_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                    "frac": round(nn_tflops / peak, 5), "avg_forward_ms": round(nn_ms, 3),
-                   "share_of_step": round(nn_ms / (elapsed_max / steps * 1e3), 4),
+                   "share_of_step": round(nn_ms / (bk_ms + k_ms + nn_ms), 4),
                    "batch_fill": round((cnt["leaves"] + cnt["root_evals"]) / (steps * args.games * args.parallel), 4)}
         if conv is not None:
             # the step's dominant kernel: 2 * blocks launches per forward.  Algorithmic work per launch = the dense 3x3
@@ -410,7 +461,7 @@ def main(argv=None):
                         "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4) if conv["avg_ms_plain"] is not None else None,
                         "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4) if conv["avg_ms_residual"] is not None else None,
                         "launches_per_step": launches_per_step,
-                        "share_of_step": round(launches_per_step * conv["avg_ms"] / (elapsed_max / steps * 1e3), 4),
+                        "share_of_step": round(launches_per_step * conv["avg_ms"] / (bk_ms + k_ms + nn_ms), 4),
                         # annotation, not a measurement of this run: the MFMA-only ceiling on post-ReLU-like operands at the 1400 W package
                         # limit, measured by tools/probes/mfma_power_probe.hip
                         "power_limited_mfma_only_tflops": {"value": 1840.0, "source": "from_profiles: profiles/r02_mfma_power_probe.txt"},
@@ -421,7 +472,6 @@ def main(argv=None):
         if world == 1 and args.net_dtype != "fp32" and not args.no_fp32:
             # the reference's evaluator precision (pipeline.py:91-123 runs the network in fp32): same engine, same workload, fp32
             # network (library convolutions + fused epilogue kernel), shorter pre-roll and window -- a companion number, not `value`
-            del evs
             a32 = make_actor("fp32")
             pre32 = preroll(a32, args, world, dev, min_rounds=60)
             el32, c32, ev32, _ = timed(a32, args, world, dev, 5, 40)
@@ -429,6 +479,20 @@ def main(argv=None):
                     "sims_per_move": round(c32["sims"] / max(1, c32["moves"]), 2), "steps": 40, "warmup": 5, "preroll_rounds": pre32,
                     "evaluator": "fp32, library convolutions + fused epilogue kernel"}
             del a32, ev32
+            torch.cuda.empty_cache()
+        fresh = None
+        if world == 1 and not args.no_fresh_tree:
+            # SURVEY 8d's "fresh-tree" variant: sub-tree reuse off (mcts_v2.py:436-446 never runs), every move pays the full budget of
+            # sims + P root visits instead of inheriting the chosen child's (mcts_v2.py:378 semantics discounted in `value`).  Without
+            # inheritance every move takes the same number of rounds, so the slots stay in phase: the window is 5 whole move periods.
+            period = (args.sims + args.parallel + args.parallel - 1) // args.parallel + 1
+            af = make_actor(args.net_dtype, reuse_tree=False)
+            af.run_rounds(2 * period)
+            elf, cf, evf, _ = timed(af, args, world, dev, period, 5 * period)
+            fresh = {"moves_per_s": round(cf["moves"] / elf, 2), "sims_per_sec": round(cf["sims"] / elf, 1), "sims_per_move": round(cf["sims"] / max(1, cf["moves"]), 2),
+                     "ms_per_step": round(elf / (5 * period) * 1e3, 3), "steps": 5 * period, "warmup": period, "reuse_tree": False,
+                     "note": "same engine / evaluator / workload with sub-tree reuse disabled: the upper-work variant, labelled, never `value`"}
+            del af, evf
             torch.cuda.empty_cache()
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -452,9 +516,10 @@ def main(argv=None):
         line = {
             "metric": "self-play moves/sec (whole node), 9x9 Go @ 200 sims/move" if (game == "go" and n == 9 and args.sims == 200)
             else f"self-play moves/sec (whole node), {n}x{n} {game} @ {args.sims} sims/move",
-            "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
+            "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "process_group": process_group,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.net_dtype, "data": "synthetic",
+            "dtype": f"{args.net_dtype} evaluator / f32-f64 tree", "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
                                    f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",
                        "evaluator": actor.evaluator_path,
@@ -466,14 +531,20 @@ def main(argv=None):
             "backup_nodes_per_sim": round(cnt["backup_edges"] / max(1, cnt["sims"]), 3),
             "select_hint_prefetches_per_sim": round(cnt.get("hint_prefetches", 0) / max(1, cnt["sims"]), 3),
             "select_hint_hit_rate": round(cnt.get("hint_hits", 0) / max(1, cnt.get("hint_prefetches", 0)), 3),
-            "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds,
+            "overlap": {"engine_behind_forward": overlapped, "halves": getattr(actor, "_halves", None),
+                        "serial_step_ms": round(bk_ms + k_ms + nn_ms, 3), "hidden_ms_per_step": round(bk_ms + k_ms + nn_ms - elapsed_max / steps * 1e3, 3),
+                        "note": "per-kernel durations (roofline, engine_roofline, nn_roofline) are measured in a serial pass after the timed region"
+                        if overlapped else "serial rounds"},
+            "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds, "per_rank": ranks,
+            "dup_leaf_rate": round(cnt["dup_leaves"] / max(1, cnt["leaves"]), 5), "terminal_hit_rate": round(cnt["terminal_hits"] / max(1, cnt["sims"]), 5),
             "fp32_moves_per_s": fp32["moves_per_s"] if fp32 else None, "fp32_companion": fp32,
+            "fresh_tree_moves_per_s": fresh["moves_per_s"] if fresh else None, "fresh_tree_companion": fresh,
             "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg_active():
         import torch.distributed as dist
 
         dist.barrier()

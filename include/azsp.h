@@ -158,6 +158,12 @@ int azsp_begin_move(void* engine, const double* noise_host, int32_t warm_up, voi
 
 int azsp_select(void* engine, void* features_dev, uint8_t* valid_dev, void* stream);
 int azsp_expand_backup(void* engine, const float* priors_dev, const float* values_dev, void* stream);
+/* The same two phases for the games [g0, g1) only (g0 % 32 == 0; the tensors are the full-batch ones, indexed by game as above).
+ * Games never interact during a search (mcts_v2.py:568-625 runs per game), so disjoint ranges may run on different streams in any
+ * order with bit-identical results: SelfPlayActor runs two half-batches on two streams so that the select / backup kernels of one
+ * half execute while the other half's leaf batch is inside the evaluator. */
+int azsp_select_range(void* engine, void* features_dev, uint8_t* valid_dev, int32_t g0, int32_t g1, void* stream);
+int azsp_expand_backup_range(void* engine, const float* priors_dev, const float* values_dev, int32_t g0, int32_t g1, void* stream);
 int azsp_round(void* engine, const float* priors_dev, const float* values_dev, void* features_dev, uint8_t* valid_dev,
                void* stream);
 

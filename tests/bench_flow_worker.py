@@ -30,7 +30,8 @@ dev = torch.device("cpu")
 pre = bench.preroll(act, args, world, dev)
 elapsed, cnt, evs, gathered = bench.timed(act, args, world, dev, warmup=3, steps=240)
 emax, moves, simsum, evals = bench.reduce_totals(cnt, elapsed, world, dev)
-json.dump(dict(preroll=pre, local_moves=cnt["moves"], total_moves=moves, elapsed=elapsed, elapsed_max=emax, gathered=gathered),
+ranks = bench.per_rank_report(cnt, elapsed, world, dev)
+json.dump(dict(preroll=pre, local_moves=cnt["moves"], total_moves=moves, elapsed=elapsed, elapsed_max=emax, gathered=gathered, per_rank=ranks),
           open(os.path.join(outdir, f"flow{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()

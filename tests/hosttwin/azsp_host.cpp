@@ -21,8 +21,8 @@ int zero(void* d, size_t n, void*) { memset(d, 0, n); return 0; }
 int sync(void*) { return 0; }
 int set_device(int) { return 0; }
 const char* backend_error() { return "host twin"; }
-template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void*) {
-    for (int g = 0; g < c.G; ++g) {
+template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void*, int g0, int g1) {
+    for (int g = g0; g < g1; ++g) {
         typename Engine<WaveHost, N, GAME>::SC sc;
         Engine<WaveHost, N, GAME> e(c, m, g, sc);
         op(e);

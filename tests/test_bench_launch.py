@@ -78,3 +78,8 @@ def test_bench_measurement_flow_two_ranks_gloo(tmp_path):
     assert f0["total_moves"] == f1["total_moves"] == f0["local_moves"] + f1["local_moves"] > 0
     assert f0["elapsed_max"] == f1["elapsed_max"] == max(f0["elapsed"], f1["elapsed"])
     assert f0["gathered"] > 0 and f1["gathered"] == 0  # samples arrive on rank 0 only
+    # the per-rank report every rank computes from an all_gather: identical on both ranks, one entry per rank, own-clock moves/s
+    assert f0["per_rank"] == f1["per_rank"] and len(f0["per_rank"]["moves_per_s"]) == 2
+    for r, f in enumerate((f0, f1)):
+        assert abs(f0["per_rank"]["moves_per_s"][r] - f["local_moves"] / f["elapsed"]) <= 0.06
+    assert f0["per_rank"]["harvest_gather_calls"] == 240 // 7 and min(f0["per_rank"]["harvest_gather_ms_mean"]) > 0

@@ -288,3 +288,41 @@ def test_gpu_sgf_text_matches_reference(golden_dir, monkeypatch):
     import sgf_checks as sc
 
     sc.check_sgf("gpu", golden_dir, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,n,filters", [("go", 9, 128), ("gomoku", 13, 64)])
+def test_gpu_two_half_batch_streams_equal_serial_rounds(game, n, filters):
+    """SelfPlayActor(overlap_engine=True) -- two half-batches on two streams, engine kernels of one half behind the other half's
+    forward (azsp_select_range / azsp_expand_backup_range) -- produces exactly the games of the serial actor: same production
+    randomness (Philox keyed by seed, slot, game, ply), same evaluations (a row's evaluation is batch independent), so every harvested
+    sample, game record and counter is bit-identical.  Games never interact inside a search (mcts_v2.py:568-625 runs per game)."""
+    import numpy as np
+    import torch
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    A = n * n + (1 if game == "go" else 0)
+    torch.manual_seed(4)
+    net = AlphaZeroNet((17, n, n), A, 2, filters, 64, gomoku=(game != "go"))
+    out = []
+    for overlap in (False, True):
+        act = SelfPlayActor(net, game=game, board_size=n, num_games=1184, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0,
+                            seed=7, device="cuda", overlap_engine=overlap, engine_kw={"max_steps": 24})
+        assert act.overlap == overlap
+        if overlap:
+            g0 = act._halves[0][1]
+            assert g0 % 32 == 0 and (g0 * 8) % max(1, 256 // (n * n)) == 0 and 0 < g0 < 1184
+        parts = []
+        for _ in range(6):
+            act.run_rounds(40)
+            st, pi, z, games = act.harvest_tensors(clone=True)
+            parts.append((st.cpu(), pi.cpu(), z.cpu(), games.copy()))
+        cnt = act.counters()
+        out.append((torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]),
+                    np.concatenate([p[3] for p in parts]), cnt))
+        del act
+    (s0, p0, z0, g0_, c0), (s1, p1, z1, g1_, c1) = out
+    assert s0.shape[0] > 5000 and len(g0_) > 300
+    assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(g0_, g1_)
+    assert {k: v for k, v in c0.items() if not k.startswith("hint")} == {k: v for k, v in c1.items() if not k.startswith("hint")}

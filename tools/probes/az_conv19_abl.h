@@ -1,3 +1,5 @@
+// PROBE COPY (tools/probes): the round-2 kernel source with its timing-ablation switches (CP_ABL_*), used by conv_pipe_probe.hip /
+// conv19_probe.hip only.  The product headers under alpha_zero_amd/csrc carry no ablation code.
 // az_conv19.h -- weight-stationary 3x3 convolution of the 256-filter residual tower on 19x19 boards (the reference's jumbo Go
 // configuration, alpha_zero/training_go_jumbo.py:46: 20 blocks x 256 filters; BASELINE config C5).
 //     y = act(conv3x3(x, w) + bias [+ addend])     x, y, addend in the tiled layout [board][32 chunks][361 positions][8 ch] bf16
@@ -24,7 +26,7 @@
 //     lanes); unused slots repeat a cell and are never stored.
 //   * epilogue straight from the accumulators, 8-byte slots, bias as the C operand of the first MFMA.
 #pragma once
-#include "az_conv.h"
+#include "az_conv_abl.h"
 
 #if defined(__HIPCC__)
 #define C9_S 19
@@ -210,7 +212,9 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
             cv_f32x16 acc[3];
 #pragma unroll
             for (int t = 0; t < NSTEP; ++t) {  // fragments of steps 0..2 are already in flight
+#ifndef CP_ABL_NO_FRAG  // (ablation switch of tools/probes/conv19_probe.hip, never defined in the product build)
                 if (t + 3 < NSTEP) load_step(bp, t + 3);
+#endif
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
@@ -218,7 +222,9 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
                     else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
                 }
                 // the next tile's DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the previous barrier)
+#ifndef CP_ABL_NO_DMA
                 if (u == 0 && t % 3 == 1 && t / 3 < NPIECE) dma_piece(nsrc, ndst, has_next, t / 3);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (u == 1) {

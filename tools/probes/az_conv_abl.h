@@ -1,3 +1,5 @@
+// PROBE COPY (tools/probes): the round-2 kernel source with its timing-ablation switches (CP_ABL_*), used by conv_pipe_probe.hip /
+// conv19_probe.hip only.  The product headers under alpha_zero_amd/csrc carry no ablation code.
 // az_conv.h -- fused 3x3 convolution of the leaf evaluator's residual tower for gfx950:
 //     y = relu(conv3x3(x, w) + bias [+ residual])      x, y, residual: [boards][9][9][128] bf16 (channels-last)
 // (reference: alpha_zero/core/network.py:42-82 ResNetBlock in eval mode, BatchNorm folded into w / bias).
@@ -168,8 +170,10 @@ __device__ __forceinline__ unsigned cw_pk_max_i16(unsigned a, unsigned b) {
 // instructions per k-step, the B-fragment ring runs on across unit and tile boundaries, the next tile's LDS-DMA pieces ride in units
 // 0-2, and the only synchronisation per tile is one barrier (3 k-steps before the end of unit 3, when every read of the
 // current buffer has been issued) behind an exactly counted s_waitcnt vmcnt(N) that leaves the younger stores in flight.
+#ifndef CP_RING
 #define CP_RING 4  // slots of the B-fragment ring: a k-step's fragments are requested CP_RING - 1 k-steps ahead (6 measured the same:
                   // the stream is not waiting on fragment latency, profiles/r02_conv_ablation.txt)
+#endif
 template <int V> struct CpInt {
     static constexpr int value = V;
 };
@@ -335,7 +339,11 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
         if (ph == 2) {
             const unsigned gq = (lmap[mb + j] >> 16) * 16u + (unsigned)(hi * 8);
             const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(ev[0], ev[1]), lo16), cw_pk_max_i16(cw_pk_bf16(ev[2], ev[3]), lo16)};
+#ifndef CP_ABL_NO_STORE
             if (store_ok) *(cv_u32x2*)(out + rq * CT_GBLK + gq) = o;
+#else
+            if (o.x == 0x12345u && store_ok) *(cv_u32x2*)(out + rq * CT_GBLK + gq) = o;  // keeps the arithmetic alive
+#endif
         }
     };
 
@@ -371,8 +379,15 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: its unit-0 epilogue stores were skipped
                     CV_BARRIER();
                 }
+#if defined(CP_ABL_HALF_FRAG)  // timing only: every second k-step re-uses stale fragments (half the LDS stream, wrong results)
+                if constexpr ((t & 1) == 0) {
+                    if constexpr (t + CP_RING - 1 < NSTEP) load_step(b0, b1, t + CP_RING - 1, (u * NSTEP + t + CP_RING - 1) % CP_RING);
+                    else load_step(nb0, nb1, t + CP_RING - 1 - NSTEP, (u * NSTEP + t + CP_RING - 1) % CP_RING);
+                }
+#elif !defined(CP_ABL_NO_FRAG)
                 if constexpr (t + CP_RING - 1 < NSTEP) load_step(b0, b1, t + CP_RING - 1, (u * NSTEP + t + CP_RING - 1) % CP_RING);
                 else load_step(nb0, nb1, t + CP_RING - 1 - NSTEP, (u * NSTEP + t + CP_RING - 1) % CP_RING);
+#endif
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if constexpr (t < 64) cw_mfma_a(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
@@ -381,7 +396,11 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                 // ---- riders of this k-step -------------------------------------------------------------------------------------
                 if constexpr (t == NSTEP - 6) acc[pq][0] = *bias_ptr;  // next unit's accumulators start from the bias
                 if constexpr (t == NSTEP - 5) acc[pq][1] = *bias_ptr;
+#ifdef CP_ABL_NO_RESLOAD
+                if constexpr (false) {
+#else
                 if constexpr (RES && t >= SC::RL0 && t < SC::RL0 + 4) {  // this unit's residual, two 8-byte loads per k-step (used by the epilogue inside the next unit)
+#endif
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int s = (t - SC::RL0) * 2 + k, j = s >> 2, rq = s & 3;
@@ -389,12 +408,22 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                         rr[q][j][rq] = *(const cv_u32x2*)(rbase + rq * CT_GBLK + gq);
                     }
                 }
+#ifndef CP_ABL_NO_DMA  // CP_ABL_*: ablation switches of tools/probes/conv_pipe_probe.hip, never defined in the product build
+#if defined(CP_ABL_DMA_MASK0)
+                if constexpr (SC::dma_at(u, t, NPIECE) >= 0) dma_piece(nsrc, ndst, false, SC::dma_at(u, t, NPIECE));
+#elif defined(CP_ABL_DMA_SAMESRC)
+                if constexpr (SC::dma_at(u, t, NPIECE) >= 0) dma_piece(x + (size_t)blockIdx.x * XTILE, ndst, has_next, SC::dma_at(u, t, NPIECE));
+#else
                 if constexpr (SC::dma_at(u, t, NPIECE) >= 0) dma_piece(nsrc, ndst, has_next, SC::dma_at(u, t, NPIECE));
+#endif
+#endif
+#ifndef CP_ABL_NO_EPI
                 if constexpr (RES) {
                     if constexpr (SC::res_at(t) >= 0) epi(pq, pmb, pout, SC::res_at(t) / 3, SC::res_at(t) % 3, pstore);
                 } else if constexpr (SC::plain_at(t) >= 0) {
                     epi(pq, pmb, pout, SC::plain_at(t), 2, pstore);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<NSTEP>::type{});
         };

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
-#include "../../alpha_zero_amd/csrc/az_conv19.h"
+#include "az_conv19_abl.h"  // frozen round-2 copy of alpha_zero_amd/csrc/az_conv19.h with the ablation switches
 
 __global__ void k_fill(unsigned short* p, size_t n, unsigned seed, int mode) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

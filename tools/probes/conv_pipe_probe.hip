@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../../alpha_zero_amd/csrc/az_conv.h"
+#include "az_conv_abl.h"  // frozen round-2 copy of alpha_zero_amd/csrc/az_conv.h with the ablation switches (the product header has none)
 
 __global__ void k_fill(unsigned short* p, size_t n, unsigned seed, int mode) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
