@@ -246,6 +246,9 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     for (int i = tid; i < 2 * LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    // the zero cells must be final before ANY wave's LDS-DMA piece can land: the waves of a workgroup do not start in the same cycle
+    // (seen under two concurrent streams: a late wave's zeroing wiped cells another wave's first pieces had already filled)
+    CV_BARRIER();
 
     cv_bf16x8 wf[NSTEP];
 #pragma unroll

@@ -9,7 +9,7 @@
 //     LDS by exactly one wave and feeds four MFMAs (the four 16-cout tiles).
 //   * v_mfma_f32_16x16x32_bf16: a column tile is 16 positions; 289 positions = 20 column tiles (5 per wave; 31 slots of 320 repeat a
 //     position, never masked), 243 positions = 16 column tiles (4 per wave, 13 repeats).  k-step = one tap x 32 input channels.
-//   * LDS image per 8-channel chunk: a strip of 16-byte cells with zero cells between board rows (17x17: cell(y, x) = 19 + 18 y + x;
+//   * LDS image per 8-channel chunk: a strip of 16-byte cells with zero cells between board rows (17x17: cell(y, x) = 20 + 19 y + x;
 //     9x9: cell(b, y, x) = 11 + 101 b + 10 y + x as in az_conv.h): a tap (dy, dx) is the constant cell offset PITCH dy + dx, every B
 //     address is a per-lane base + an immediate; no VALU in the k-loop.  The strip size is a multiple of 256 B, so the four 8-channel
 //     groups of a B fragment (lanes l, l+16, l+32, l+48 read neighbouring strips) fall on the same banks and a ds_read_b128 lane group
@@ -26,9 +26,14 @@
 
 template <int S_> struct C6Geo;
 template <> struct C6Geo<17> {
-    static constexpr int S = 17, TB = 1, P2 = 289, PITCH = 18, CELL0 = 19;
-    static constexpr int CELLS = 352;  // 19 + 17 * 18 + 19 = 344, rounded up to a multiple of 16 (strip = multiple of 256 B)
-    static constexpr int NCT = 20;     // column tiles of 16 positions
+    // Row pitch 19 (two zero cells between board rows), not 18: cell mod 16 = (4 + 3 y + x) mod 16, and since 3 is coprime to 16 the
+    // residue a row holds twice (x = 0 and x = 16) moves through all 16 classes -- every class has 18 cells, one has 19.  The
+    // residue-class map then fills 18 column tiles completely and leaves ONE position for tile 18 (289 = 16 * 18 + 1).  (With pitch
+    // 18 the doubled residues are all odd: classes of 17 / 19 / 20 cells, 17 positions spread over three part-filled tiles.)
+    static constexpr int S = 17, TB = 1, P2 = 289, PITCH = 19, CELL0 = 20;
+    static constexpr int CELLS = 368;  // 20 + 17 * 19 - 2 + 20 = 361 with the tap reach, rounded up to a multiple of 16 (strip = multiple of 256 B)
+    static constexpr int NCT = 20;     // column tiles of 16 positions (k_conv3x3_t64: 5 per wave; tile 19 only repeats positions)
+    static constexpr int NCT_REAL = 19;  // tiles that hold a position of their own: 18 full ones + tile 18 with one
     static constexpr int STEM_S = 13, STEM_OFF = 2;  // the stem's input board and its offset in the plane (pad-3 stem, network.py:101-105)
     static constexpr int cell_of(int p) { return CELL0 + PITCH * (p / S) + p % S; }
     // position index inside an input tile of in_s x in_s boards embedded at (off, off) of the plane that `cell` belongs to, or -1
@@ -43,6 +48,7 @@ template <> struct C6Geo<9> {
     static constexpr int S = 9, TB = 3, P2 = 243, PITCH = 10, BPITCH = 101, CELL0 = 11;
     static constexpr int CELLS = 320;  // 11 + 2 * 101 + 100 = 313, rounded up to a multiple of 16
     static constexpr int NCT = 16;
+    static constexpr int NCT_REAL = 16;  // 243 = 16 * 15 + 3: tile 15 holds three positions of its own
     static constexpr int STEM_S = 9, STEM_OFF = 0;
     static constexpr int cell_of(int p) { return CELL0 + BPITCH * (p / 81) + PITCH * ((p % 81) / 9) + p % 9; }
     static constexpr int pos_of_cell(int cell, int in_s, int off) {
@@ -59,6 +65,7 @@ typedef __attribute__((ext_vector_type(4))) float c6_f32x4;
 // has more than NCT of the tile's cells); the unfilled slots repeat the first position of a residue the tile still lacks.
 template <class G> struct Cw64Map {
     unsigned short cell[G::NCT * 16], pos[G::NCT * 16];
+    int real_tiles;  // column tiles that hold at least one position of their own (the later ones only repeat positions)
     bool ok;
 };
 template <class G> constexpr Cw64Map<G> cw64_make_map() {
@@ -76,6 +83,7 @@ template <class G> constexpr Cw64Map<G> cw64_make_map() {
         m.pos[k * 16 + fill[k]] = (unsigned short)p;
         fill[k]++;
         used[k][r] = true;
+        if (k + 1 > m.real_tiles) m.real_tiles = k + 1;
     }
     for (int k = 0; k < G::NCT; ++k)
         for (int r = 0; r < 16 && fill[k] < 16; ++r) {
@@ -106,6 +114,8 @@ template <class G> constexpr Cw64Map<G> cw64_make_map() {
 static __device__ const Cw64Map<C6Geo<17>> cw64_map17 = cw64_make_map<C6Geo<17>>();
 static __device__ const Cw64Map<C6Geo<9>> cw64_map9 = cw64_make_map<C6Geo<9>>();
 static_assert(cw64_make_map<C6Geo<17>>().ok && cw64_make_map<C6Geo<9>>().ok, "column-tile maps must cover every position conflict-free");
+static_assert(cw64_make_map<C6Geo<17>>().real_tiles == C6Geo<17>::NCT_REAL && cw64_make_map<C6Geo<9>>().real_tiles == C6Geo<9>::NCT_REAL,
+              "k_resblock64 computes the column tiles [0, NCT_REAL): every position must live in one of them");
 template <class G> __device__ __forceinline__ const Cw64Map<G>& cw64_map() {
     if constexpr (G::S == 17) return cw64_map17;
     else return cw64_map9;
@@ -301,35 +311,43 @@ k_conv3x3_t64(const unsigned char* __restrict__ x, const unsigned short* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_resblock64<G>: one whole ResNetBlock (alpha_zero/core/network.py:42-82, eval mode, BatchNorm folded) of a 64-filter tower in ONE
+// k_resblock64<G, R>: one whole ResNetBlock (alpha_zero/core/network.py:42-82, eval mode, BatchNorm folded) of a 64-filter tower in ONE
 // launch:      y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2 + x)
 // The layer-at-a-time kernel above is HBM-bound by construction (230 flop/B: profiles/r01_pmc_conv64.txt, 4.8 TB/s on the skip
 // layers); here the intermediate activation never leaves the CU and the skip comes from the input tile that is already in LDS,
 // so a block moves 2 tensor passes (x in, y out) instead of 5.
 //   * both filter banks are register-resident: wave (h = wave & 1, ph = wave >> 1) holds couts [32 h, 32 h + 32) of BOTH
-//     convolutions (2 x 36 A fragments = 288 registers) and computes them for the column tiles of position half ph.
+//     convolutions (2 x 36 A fragments = 288 registers) and computes them for the column tiles 2 m + ph of position half ph.
+//     Its two 16-cout tiles sit in "slots": slot s = cout tile 2 h + (s ^ ph).
+//   * 17x17: the residue-class map fills 18 column tiles and leaves ONE position for tile 18 (289 = 16 * 18 + 1).  That tile is
+//     SHARED: every wave computes it for its slot-0 cout tile only (the four waves' slot 0 are the four cout tiles), so a wave does
+//     9 tiles x 2 slots + 1 = 19 MFMA columns per k-step and convolution instead of the 20 of an even split (-5 % matrix work,
+//     perfectly balanced).  9x9: 16 tiles, 8 per wave, no shared tile.
 //   * LDS: x double buffer (LDS-DMA of the next tile under this tile's MFMAs) + ONE intermediate image with the same zero-cell
 //     layout, written by the first convolution's epilogue (ds_write_b64 of the bf16-rounded ReLU) and read by the second one.
-//   * a tile is 2 NU units of 2 column tiles x 2 cout tiles (4 independent accumulators, 18 k-steps of 4 MFMAs); two accumulator
-//     sets: the epilogue of unit i - 1 (mid write / skip add, rounding, ReLU, 8-byte global stores) rides in the MFMA stream of
-//     unit i, the B-fragment ring (R slots) runs on across units and tiles.  Only the last unit of the first convolution has an
-//     exposed epilogue (the intermediate image must be complete before the second convolution starts).
+//   * a tile is 2 NU units of 2 column tiles x 2 slots (4 independent accumulators, 18 k-steps of 4 MFMAs; the last unit of a 17x17
+//     convolution is the wave's ninth tile + the shared tile's slot 0: 3 MFMAs per k-step); two accumulator sets: the epilogue of
+//     unit i - 1 (mid write / skip add, rounding, ReLU, 8-byte global stores) rides in the MFMA stream of unit i, the B-fragment
+//     ring (R slots) runs on across units and tiles.  Only the last unit of the first convolution has an exposed epilogue (the
+//     intermediate image must be complete before the second convolution starts).
 //   * three barriers per tile: B1 (start of unit 1: every wave is done with the previous intermediate image and the previous
 //     tile's skip reads -> the image may be overwritten, the next tile's DMA may start), B2 (intermediate image complete), M (start
 //     of the last unit, behind a counted vmcnt: the next tile has landed; the ring's prefetch then crosses into it).
 //   * arithmetic (MFMA shape, k order, bias as the C operand of the first k-step, one bf16 rounding of the intermediate and of the
 //     output) is exactly that of two k_conv3x3_t64 launches: results are bit-identical to the layer-at-a-time path.
-template <class G> __global__ void __launch_bounds__(CW_THREADS, 1)
+template <class G, int R = 4> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w1, const float* __restrict__ b1,
              const unsigned short* __restrict__ w2, const float* __restrict__ b2, unsigned char* __restrict__ y, int ntiles) {
-    constexpr int NU = G::NCT / 4, NUNIT = 2 * NU;          // units per convolution / per tile (2 column tiles each)
+    constexpr bool SHARED = G::NCT_REAL % 2 == 1;           // an odd tile count: the last tile is shared by the four waves
+    constexpr int NOWN = G::NCT_REAL / 2;                    // column tiles a wave owns (both slots)
+    constexpr int NU = (NOWN + (SHARED ? 1 : 0) + 1) / 2, NUNIT = 2 * NU;  // units per convolution / per tile (2 column tiles each)
     constexpr int KS = 18;                                   // k-steps per unit: 9 taps x 2 halves of 32 input channels
     constexpr int LBLK = G::CELLS * 16, LBUF = C6_NCH * LBLK;
     constexpr int GBLK = G::P2 * 16, TILE = C6_NCH * GBLK;
     constexpr int NP = (G::CELLS + 63) / 64, NPIECE = 2 * NP;  // wave q moves strips 2 q, 2 q + 1
-    constexpr int R = 4;                                     // B-fragment ring slots: a k-step's fragments are requested R - 1 k-steps ahead
     constexpr int VM_AT_M = 4 * (NU - 2);                    // vector-memory operations younger than the last DMA piece at barrier M: the
                                                              // stores of the second convolution's units 0 .. NU - 3 (riding in units NU + 1 .. 2 NU - 2)
+    static_assert(NOWN + (SHARED ? 1 : 0) == NUNIT, "units are pairs of column tiles");
     static_assert((NUNIT * KS) % R == 0, "a tile's k-steps keep the ring phase");
     static_assert(NU >= 4 && NPIECE <= 12, "the next tile's pieces ride in units 1-3");
     static_assert(3 * LBUF <= 160 * 1024, "x double buffer + intermediate image");
@@ -341,21 +359,21 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
     CV_BARRIER();  // the zero cells are final before any LDS-DMA piece can land
     unsigned char* const MID = lds + 2 * LBUF;
 
-    // A fragments: f = 36 conv + 2 s + q2, k-step s = (tap, input half), cout tile q2: lane (cout = 32 h + 16 q2 + l15, cin = 32 half + 8 kg .. + 8)
+    // A fragments: f = 36 conv + 2 s + slot, k-step s = (tap, input half): lane (cout = 16 (2 h + (slot ^ ph)) + l15, cin = 32 half + 8 kg .. + 8)
     cv_bf16x8 wf[72];
 #pragma unroll
     for (int f = 0; f < 72; ++f) {
-        const int s = (f % 36) >> 1, q2 = f & 1;
+        const int s = (f % 36) >> 1, ct = 2 * h + ((f & 1) ^ ph);
         const unsigned short* w = f < 36 ? w1 : w2;
-        wf[f] = *(const cv_bf16x8*)(w + ((size_t)((s >> 1) * C6_C + 32 * h + 16 * q2 + l15)) * C6_C + (s & 1) * 32 + kg * 8);
+        wf[f] = *(const cv_bf16x8*)(w + ((size_t)((s >> 1) * C6_C + 16 * ct + l15)) * C6_C + (s & 1) * 32 + kg * 8);
     }
-    c6_f32x4 bv[2][2];  // bias in the D layout (rows = couts 32 h + 16 q2 + 4 kg + e): the C operand of a unit's first k-step
+    c6_f32x4 bv[2][2];  // bias in the D layout (rows = couts 16 ct + 4 kg + e): the C operand of a unit's first k-step
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2)
+        for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[c][q2][e] = (c ? b2 : b1)[32 * h + 16 * q2 + 4 * kg + e];
+            for (int e = 0; e < 4; ++e) bv[c][sl][e] = (c ? b2 : b1)[16 * (2 * h + (sl ^ ph)) + 4 * kg + e];
 
     unsigned dsrc[NP];
     unsigned long long dmask[NP];
@@ -376,17 +394,23 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
                      : "memory");
     };
 
-    // this lane's 2 NU column tiles (unit u, j: local tile m = 2 u + j = column tile 2 m + ph): B-fragment base offset ((-1, -1)
-    // neighbour, own 8-channel group; low 16 bits) and the position (high 16 bits)
+    // this lane's column tiles, local tile m = 2 u + j: own tiles m < NOWN = column tile 2 m + ph, then (17x17) the shared tile:
+    // B-fragment base offset ((-1, -1) neighbour, own 8-channel group; low 16 bits) and the position (high 16 bits)
     unsigned lmap[NUNIT];
 #pragma unroll
     for (int m = 0; m < NUNIT; ++m) {
-        const int idx = (2 * m + ph) * 16 + l15;
+        const int idx = (m < NOWN ? 2 * m + ph : G::NCT_REAL - 1) * 16 + l15;
         lmap[m] = (unsigned)((cw64_map<G>().cell[idx] - G::CELL0) * 16 + kg * LBLK) | ((unsigned)cw64_map<G>().pos[idx] << 16);
     }
-    // the 8-byte slot of (position, couts 32 h + 16 q2 + 4 kg .. + 4): chunk 4 h + 2 q2 + kg / 2, half kg % 2
-    const int wconst = G::CELL0 * 16 + ((kg >> 1) + 4 * h - kg) * LBLK + (kg & 1) * 8;  // + (lmap & 0xffff) = offset inside an LDS image
-    const unsigned gconst = (unsigned)(((kg >> 1) + 4 * h) * GBLK + (kg & 1) * 8);        // + 16 position = offset inside a global tile
+    // the 8-byte slot of (position, couts 16 ct + 4 kg .. + 4), ct = 2 h + (slot ^ ph): chunk 2 ct + kg / 2, half kg % 2
+    int wconst[2];       // + (lmap & 0xffff) = offset inside an LDS image
+    unsigned gconst[2];  // + 16 position = offset inside a global tile
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int chunk = 2 * (2 * h + (sl ^ ph)) + (kg >> 1);
+        wconst[sl] = G::CELL0 * 16 + (chunk - kg) * LBLK + (kg & 1) * 8;
+        gconst[sl] = (unsigned)(chunk * GBLK + (kg & 1) * 8);
+    }
 
     cv_bf16x8 bb[R][2];
     auto load_step = [&](const unsigned char* p0, const unsigned char* p1, int s, int slot) {  // s = 2 tap + half
@@ -412,36 +436,36 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
     }
     asm volatile("" : : "v"(bv[0][0]), "v"(bv[1][1]), "v"(lmap[0]), "v"(lmap[NUNIT - 1]), "v"(dsrc[0]), "v"(dsrc[NP - 1]));
 
-    c6_f32x4 acc[2][2][2];  // [unit parity][column tile j][cout tile q2]
-    cv_u32x2 rr[2][4];      // skip values of a second-convolution unit: [unit parity][quad s = 2 j + q2]
+    c6_f32x4 acc[2][2][2];  // [unit parity][column tile j][slot]
+    cv_u32x2 rr[2][4];      // skip values of a second-convolution unit: [unit parity][quad q = 2 j + slot]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            acc[a][s >> 1][s & 1] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            rr[a][s] = (cv_u32x2){0u, 0u};
+        for (int q = 0; q < 4; ++q) {
+            acc[a][q >> 1][q & 1] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            rr[a][q] = (cv_u32x2){0u, 0u};
         }
     float ev[4];  // one epilogue quad between its phases
 
-    // epilogue of a first-convolution unit, quad s: ReLU, one bf16 rounding, 8 bytes into the intermediate image
-    auto epi_mid = [&](int set, int m0, int s) {
-        const int j = s >> 1, q2 = s & 1;
-        const c6_f32x4 v = acc[set][j][q2];
-        const int ofs = (int)(lmap[m0 + j] & 0xffffu) + wconst + q2 * (2 * LBLK);
+    // epilogue of a first-convolution unit, quad q = 2 j + slot: ReLU, one bf16 rounding, 8 bytes into the intermediate image
+    auto epi_mid = [&](int set, int m0, int q) {
+        const int j = q >> 1, sl = q & 1;
+        const c6_f32x4 v = acc[set][j][sl];
+        const int ofs = (int)(lmap[m0 + j] & 0xffffu) + wconst[sl];
         *(cv_u32x2*)(MID + ofs) = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(v[0], v[1]), 0u), cw_pk_max_i16(cw_pk_bf16(v[2], v[3]), 0u)};
     };
-    // epilogue of a second-convolution unit, quad s, phase ph3: skip add (plain v_add_f32, see az_conv.h), rounding, ReLU, 8-byte store
-    auto epi_out = [&](int set, int m0, unsigned char* out, int s, int ph3, bool store_ok) {
-        const int j = s >> 1, q2 = s & 1;
-        const cv_u32x2 r2 = rr[set][s];
+    // epilogue of a second-convolution unit, quad q, phase ph3: skip add (plain v_add_f32, see az_conv.h), rounding, ReLU, 8-byte store
+    auto epi_out = [&](int set, int m0, unsigned char* out, int q, int ph3, bool store_ok) {
+        const int j = q >> 1, sl = q & 1;
+        const cv_u32x2 r2 = rr[set][q];
         if (ph3 == 0) {
-            ev[0] = cw_add_f32(acc[set][j][q2][0], cv_bf16_lo(r2.x));
-            ev[1] = cw_add_f32(acc[set][j][q2][1], cv_bf16_hi(r2.x));
+            ev[0] = cw_add_f32(acc[set][j][sl][0], cv_bf16_lo(r2.x));
+            ev[1] = cw_add_f32(acc[set][j][sl][1], cv_bf16_hi(r2.x));
         } else if (ph3 == 1) {
-            ev[2] = cw_add_f32(acc[set][j][q2][2], cv_bf16_lo(r2.y));
-            ev[3] = cw_add_f32(acc[set][j][q2][3], cv_bf16_hi(r2.y));
+            ev[2] = cw_add_f32(acc[set][j][sl][2], cv_bf16_lo(r2.y));
+            ev[3] = cw_add_f32(acc[set][j][sl][3], cv_bf16_hi(r2.y));
         } else {
-            const unsigned gq = (lmap[m0 + j] >> 16) * 16u + gconst + (unsigned)(q2 * (2 * GBLK));
+            const unsigned gq = (lmap[m0 + j] >> 16) * 16u + gconst[sl];
             const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(ev[0], ev[1]), 0u), cw_pk_max_i16(cw_pk_bf16(ev[2], ev[3]), 0u)};
             if (store_ok) *(cv_u32x2*)(out + gq) = o;
         }
@@ -465,6 +489,8 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
             constexpr int pi = (i + NUNIT - 1) % NUNIT, pconv = pi / NU, pu = pi % NU;  // the unit whose epilogue rides here
             constexpr int ni = (i + 1) % NUNIT, nconv = ni / NU, nu = ni % NU;          // the unit the ring runs on into
             constexpr bool cross = (i + 1 == NU);  // first -> second convolution: the intermediate image is not complete yet
+            // quads of a unit: 4, or 3 in the unit that ends a 17x17 convolution (column tile j = 1 is the shared tile: slot 0 only)
+            constexpr int nq = (SHARED && u == NU - 1) ? 3 : 4, pnq = (SHARED && pu == NU - 1) ? 3 : 4;
             const unsigned char* img = conv ? MID : Xs;
             const unsigned char* nimg = nconv ? MID : (i + 1 == NUNIT ? Xn : Xs);
             const unsigned char* b0 = img + (lmap[2 * u] & 0xffffu);
@@ -482,20 +508,19 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
                 if constexpr (t + R - 1 < KS) load_step(b0, b1p, t + R - 1, (i * KS + t + R - 1) % R);
                 else if constexpr (!cross) load_step(nb0, nb1, t + R - 1 - KS, (i * KS + t + R - 1) % R);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int q2 = 0; q2 < 2; ++q2) {
-                        constexpr int fb = conv * 36 + 2 * t;
-                        if constexpr (t == 0) c6_mfma_ac(acc[set][j][q2], wf[fb + q2], bb[(i * KS + t) % R][j], bv[conv][q2]);
-                        else if constexpr (fb < 64) c6_mfma_a(acc[set][j][q2], wf[fb + q2], bb[(i * KS + t) % R][j]);
-                        else c6_mfma_v(acc[set][j][q2], wf[fb + q2], bb[(i * KS + t) % R][j]);
-                    }
+                for (int q = 0; q < nq; ++q) {
+                    const int j = q >> 1, sl = q & 1;
+                    constexpr int fb = conv * 36 + 2 * t;
+                    if constexpr (t == 0) c6_mfma_ac(acc[set][j][sl], wf[fb + sl], bb[(i * KS + t) % R][j], bv[conv][sl]);
+                    else if constexpr (fb < 64) c6_mfma_a(acc[set][j][sl], wf[fb + sl], bb[(i * KS + t) % R][j]);
+                    else c6_mfma_v(acc[set][j][sl], wf[fb + sl], bb[(i * KS + t) % R][j]);
+                }
                 // ---- riders of this k-step ---------------------------------------------------------------------------------
                 if constexpr (conv == 1 && t < 2) {  // this unit's skip values from the resident x tile (used by its epilogue inside the next unit)
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const int s = 2 * t + k, j = s >> 1, q2 = s & 1;
-                        rr[set][s] = *(const cv_u32x2*)(Xs + ((int)(lmap[2 * u + j] & 0xffffu) + wconst + q2 * (2 * LBLK)));
+                        const int q = 2 * t + k, j = q >> 1, sl = q & 1;
+                        if (q < nq) rr[set][q] = *(const cv_u32x2*)(Xs + ((int)(lmap[2 * u + j] & 0xffffu) + wconst[sl]));
                     }
                 }
                 if constexpr (i >= 1 && i <= 3 && (t == 2 || t == 6 || t == 11 || t == 15)) {  // the next tile's DMA pieces
@@ -503,9 +528,9 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
                     if constexpr (p < NPIECE) dma_piece(nsrc, ndst, has_next, p);
                 }
                 if constexpr (pconv == 0 && i != NU) {  // previous unit belongs to the first convolution: its outputs go to the intermediate image
-                    if constexpr (t >= 4 && t <= 13 && (t - 4) % 3 == 0) epi_mid(pset, 2 * pu, (t - 4) / 3);
+                    if constexpr (t >= 4 && t <= 13 && (t - 4) % 3 == 0 && (t - 4) / 3 < pnq) epi_mid(pset, 2 * pu, (t - 4) / 3);
                 } else if constexpr (pconv == 1) {
-                    if constexpr (t >= 3 && t <= 14) epi_out(pset, 2 * pu, pout, (t - 3) / 3, (t - 3) % 3, pstore);
+                    if constexpr (t >= 3 && t <= 14 && (t - 3) / 3 < pnq) epi_out(pset, 2 * pu, pout, (t - 3) / 3, (t - 3) % 3, pstore);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<KS>::type{});
@@ -513,7 +538,7 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
                 // the last unit of the first convolution: exposed epilogue, then B2 (intermediate image complete) and the ring restarts
                 asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[set][0][0]), "+v"(acc[set][0][1]), "+v"(acc[set][1][0]), "+v"(acc[set][1][1]));
 #pragma unroll
-                for (int s = 0; s < 4; ++s) epi_mid(set, 2 * u, s);
+                for (int q = 0; q < nq; ++q) epi_mid(set, 2 * u, q);
                 CV_BARRIER();
 #pragma unroll
                 for (int s = 0; s < R - 1; ++s) load_step(MID + (lmap[0] & 0xffffu), MID + (lmap[1] & 0xffffu), s, ((i + 1) * KS + s) % R);
@@ -527,10 +552,10 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
     if (it > 0) {
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[1][0][0]), "+v"(acc[1][0][1]), "+v"(acc[1][1][0]), "+v"(acc[1][1][1]));
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            epi_out(1, 2 * (NU - 1), yprev, s, 0, true);
-            epi_out(1, 2 * (NU - 1), yprev, s, 1, true);
-            epi_out(1, 2 * (NU - 1), yprev, s, 2, true);
+        for (int q = 0; q < (SHARED ? 3 : 4); ++q) {
+            epi_out(1, 2 * (NU - 1), yprev, q, 0, true);
+            epi_out(1, 2 * (NU - 1), yprev, q, 1, true);
+            epi_out(1, 2 * (NU - 1), yprev, q, 2, true);
         }
     }
 }

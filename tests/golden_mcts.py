@@ -9,8 +9,10 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def names():
-    return sorted(os.path.basename(f)[5:-4] for f in glob.glob(os.path.join(GOLDEN, "mcts_*.npz")))
+def names(real_network=False):
+    """Goldens recorded with the synthetic hash evaluator (tests/synth_eval.py), or (real_network=True) the ones recorded with the
+    reference's shipped checkpoint as evaluator (tests/realnet_checks.py)."""
+    return sorted(n for n in (os.path.basename(f)[5:-4] for f in glob.glob(os.path.join(GOLDEN, "mcts_*.npz"))) if ("ckpt" in n) == real_network)
 
 
 class MctsGolden:

@@ -357,3 +357,42 @@ def check_actor_loop(device, binding, tmp_path):
 
 def test_actor_loop_hot_swap_threshold_and_ckpt_event(tmp_path):
     check_actor_loop("cpu", eu.hosttwin_binding(), tmp_path)
+
+
+def test_game_range_rounds_equal_whole_batch_rounds():
+    """azsp_select_range / azsp_expand_backup_range (host twin): rounds run as two disjoint game ranges, in either order, give exactly
+    the games of whole-batch rounds -- the property SelfPlayActor's two half-batch streams rely on (mcts_v2.py:568-625 is per game).
+    Ranges that do not start on a multiple of 32 games are refused."""
+    def play(order):
+        a = _actor(G=72, sims=12, P=4, seed=5)
+        e = a.engine
+        by_uid = {}
+        for r in range(160):
+            if order is None:
+                a.run_round()
+            else:
+                for g0, g1 in order:
+                    e.expand_backup(g0, g1)
+                    e.select(g0, g1)
+                a._forward()
+            if (r + 1) % 20 == 0:
+                st, pi, z, games = a.harvest_tensors()
+                for row in games:
+                    s0, ln = int(row[0]), int(row[1])
+                    by_uid[int(row[11])] = (st[s0:s0 + ln].clone(), pi[s0:s0 + ln].clone(), z[s0:s0 + ln].clone(), row[1:].copy())
+        return by_uid, a.counters(), e
+
+    whole, c0, _ = play(None)
+    for order in ([(0, 32), (32, 72)], [(64, 72), (0, 64)]):
+        part, c1, e = play(order)
+        assert len(whole) >= 30 and whole.keys() == part.keys() and c0 == c1
+        for uid, (s0, p0, z0, r0) in whole.items():
+            s1, p1, z1, r1 = part[uid]
+            assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(r0, r1)
+    for bad in ((8, 72), (0, 73), (32, 32), (-32, 32)):
+        try:
+            e.select(*bad)
+        except Exception as ex:
+            assert "azsp_select_range" in str(ex)
+        else:
+            raise AssertionError(f"range {bad} accepted")

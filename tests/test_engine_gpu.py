@@ -313,16 +313,20 @@ def test_gpu_two_half_batch_streams_equal_serial_rounds(game, n, filters):
         if overlap:
             g0 = act._halves[0][1]
             assert g0 % 32 == 0 and (g0 * 8) % max(1, 256 // (n * n)) == 0 and 0 < g0 < 1184
-        parts = []
+        games_by_uid = {}
         for _ in range(6):
             act.run_rounds(40)
             st, pi, z, games = act.harvest_tensors(clone=True)
-            parts.append((st.cpu(), pi.cpu(), z.cpu(), games.copy()))
-        cnt = act.counters()
-        out.append((torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts]),
-                    np.concatenate([p[3] for p in parts]), cnt))
+            st, pi, z = st.cpu(), pi.cpu(), z.cpu()
+            for row in games:  # the harvest kernel hands out output rows first come first served: key the games by their uid
+                a, ln = int(row[0]), int(row[1])
+                assert int(row[11]) not in games_by_uid
+                games_by_uid[int(row[11])] = (st[a:a + ln].clone(), pi[a:a + ln].clone(), z[a:a + ln].clone(), row[1:].copy())
+        out.append((games_by_uid, act.counters()))
         del act
-    (s0, p0, z0, g0_, c0), (s1, p1, z1, g1_, c1) = out
-    assert s0.shape[0] > 5000 and len(g0_) > 300
-    assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(g0_, g1_)
+    (ga, c0), (gb, c1) = out
+    assert len(ga) > 300 and sum(v[0].shape[0] for v in ga.values()) > 5000 and ga.keys() == gb.keys()
+    for uid, (s0, p0, z0, r0) in ga.items():
+        s1, p1, z1, r1 = gb[uid]
+        assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(r0, r1), uid
     assert {k: v for k, v in c0.items() if not k.startswith("hint")} == {k: v for k, v in c1.items() if not k.startswith("hint")}

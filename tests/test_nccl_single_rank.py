@@ -28,7 +28,7 @@ def test_gpu_gather_and_broadcast_through_single_rank_nccl_group():
     packed wire format round-trips bit-exactly on the device."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py")], env=_env(), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    rep = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert rep["ok"] and rep["backend"] == "nccl" and rep["collectives"]["gather"] >= 1 and rep["collectives"]["broadcast"] == 1
 
 

@@ -1,0 +1,48 @@
+"""Engine + REAL trained network vs the reference's uct_search + the same network (fixed seed: recorded Dirichlet draws / uniforms)."""
+import json
+import os
+
+import pytest
+import torch
+
+import realnet_checks as rc
+
+
+@pytest.mark.parametrize("name", ["gomoku13_ckpt200000_p1_s100", "gomoku13_ckpt200000_p1_s100_fresh", "gomoku13_ckpt200000_p8_s200"])
+def test_host_twin_search_with_shipped_checkpoint_matches_reference_exactly(name):
+    """CPU tier: the engine source (host twin) + the shipped checkpoint evaluated by torch-CPU fp32, the arithmetic the golden run used."""
+    torch.set_num_threads(1)
+    s = rc.check_exact("host", name)
+    assert s["moves_compared"] >= 40
+
+
+@pytest.mark.gpu
+def test_gpu_search_with_shipped_checkpoint_fp32_and_bf16(golden_dir):
+    """GPU tier.  (1) The HIP engine with the golden run's own evaluator arithmetic (fp32 torch-CPU module behind eval_func) equals the
+    reference exactly.  (2) fp32 on the device (InferenceNet fp32: library convolutions + azsp_bias_act) differs from the CPU's fp32 in
+    the last bits, so a PUCT arg-max can flip: teacher-forced on the reuse-free golden every move is an independent comparison; stated
+    tolerance: >= 90 % of the moves identical (pi to 1e-6, same sampled move), all moves |pi - pi_ref|_inf <= 0.08, |root_Q - ref| <=
+    0.02.  (3) bf16 hand-written kernels (checkpoint widened 40 -> 64 filters): reported, with loose bounds."""
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.network import InferenceNet, widen_network
+
+    net = rc.load_shipped()
+    out = {}
+    for name in ("gomoku13_ckpt200000_p1_s100", "gomoku13_ckpt200000_p8_s200"):
+        out["cpu_evaluator_" + name] = rc.check_exact("gpu", name)
+    inf32 = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    recs, total = rc.run_golden("gpu", "gomoku13_ckpt200000_p1_s100_fresh", rc.inference_eval_func(inf32, 13, tiled=False), teacher_forced=True)
+    s32 = rc.summarize(recs, total)
+    out["fp32_device_teacher_forced"] = s32
+    inf16 = InferenceNet(widen_network(net, 64), dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    assert inf16.supports_tiled_features(13, "cuda")
+    recs, total = rc.run_golden("gpu", "gomoku13_ckpt200000_p1_s100_fresh", rc.inference_eval_func(inf16, 13, tiled=True), teacher_forced=True)
+    s16 = rc.summarize(recs, total)
+    out["bf16_kernels_teacher_forced"] = s16
+    recs, total = rc.run_golden("gpu", "gomoku13_ckpt200000_p1_s100", rc.inference_eval_func(inf32, 13, tiled=False), teacher_forced=False)
+    out["fp32_device_free_run_with_reuse"] = rc.summarize(recs, total)
+    os.makedirs(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "realnet_search_parity.json"), "w"), indent=1)
+    assert s32["moves_compared"] == s32["moves_in_golden"] >= 40
+    assert s32["exact_moves"] >= 0.9 * s32["moves_compared"] and s32["max_dpi"] <= 0.08 and s32["max_dq"] <= 0.02, s32
+    assert s16["same_move"] >= 0.8 and s16["top1"] >= 0.8 and s16["mean_dpi"] <= 0.05 and s16["mean_dq"] <= 0.03, s16

@@ -46,6 +46,14 @@ CONFIGS = {
     "gomoku13_p8_s200": dict(game="gomoku", n=13, sims=200, parallel=8, games=2, seed=22, max_moves=40),
     "gomoku7_p8_s64": dict(game="gomoku", n=7, sims=64, parallel=8, games=3, seed=23),
     "gomoku7_p1_s40": dict(game="gomoku", n=7, sims=40, parallel=1, games=3, seed=24),
+    # REAL network: the reference's own create_mcts_player (pipeline.py:83-163: fp32 eval_position on the CPU) with the shipped, trained
+    # checkpoint checkpoints/gomoku/13x13/training_steps_200000.ckpt = BASELINE C1 (13x13 Gomoku, uct_search, 100 sims).  With sub-tree
+    # reuse (the actor's behaviour) and without (every move an independent search of the recorded position: a later move stays
+    # comparable even when an earlier search differed by an arg-max flip between two fp32 implementations of the network).
+    "gomoku13_ckpt200000_p1_s100": dict(game="gomoku", n=13, sims=100, parallel=1, games=6, seed=41, max_moves=44, ckpt="training_steps_200000.ckpt"),
+    "gomoku13_ckpt200000_p1_s100_fresh": dict(game="gomoku", n=13, sims=100, parallel=1, games=6, seed=42, max_moves=44, reuse=False,
+                                              ckpt="training_steps_200000.ckpt"),
+    "gomoku13_ckpt200000_p8_s200": dict(game="gomoku", n=13, sims=200, parallel=8, games=5, seed=43, max_moves=40, ckpt="training_steps_200000.ckpt"),
     # deterministic, no-noise evaluation mode (pipeline.py:834: root_noise=False, deterministic=True, no reuse)
     "go5_p1_s40_det": dict(game="go", n=5, sims=40, parallel=1, games=2, seed=17, resign_threshold=-1.0, resign_disabled=True,
                            root_noise=False, deterministic=True, reuse=False),
@@ -73,9 +81,43 @@ def main(name):
     A = env.action_dim
     K = 16  # max uniforms recorded per move
     moves_log = []  # per searched move
+    boards_log = []  # the position every search started from
     cur = {}
     eval_log = []
     eval_func = make_eval_func(A, log=eval_log)
+    root_evals = []  # real network only: (prior, value) of the root position of every searched move
+    if cfg.get("ckpt"):
+        # the reference's own evaluator closure: create_mcts_player builds eval_position (pipeline.py:91-123) around its AlphaZeroNet;
+        # its `act` is never used here -- the closure is picked up from the keyword it passes to uct_search
+        import torch
+        from alpha_zero.core.network import AlphaZeroNet
+
+        torch.set_num_threads(1)
+        st = torch.load(os.path.join(ref_harness.REF_ROOT, "checkpoints", "gomoku", "13x13", cfg["ckpt"]), map_location="cpu", weights_only=False)
+        net = AlphaZeroNet((17, 13, 13), 169, num_res_block=10, num_filters=40, num_fc_units=80, gomoku=True)
+        net.load_state_dict(st["network"])
+        net.eval()
+        grabbed = {}
+
+        class _Grab(Exception):
+            pass
+
+        def grab(**kw):
+            grabbed["eval_func"] = kw["eval_func"]
+            raise _Grab()
+
+        keep = (pipeline.uct_search, pipeline.parallel_uct_search)
+        pipeline.uct_search = pipeline.parallel_uct_search = grab
+        try:
+            pipeline.create_mcts_player(net, torch.device("cpu"), cfg["sims"], cfg["parallel"], True, False)(env, None, 19652.0, 1.25, False)
+        except _Grab:
+            pass
+        pipeline.uct_search, pipeline.parallel_uct_search = keep
+        ref_eval = grabbed["eval_func"]
+
+        def eval_func(obs, batched=False):  # the reference closure + a log of its batch sizes
+            eval_log.append(int(obs.shape[0]) if batched else 1)
+            return ref_eval(obs, batched)
 
     real_dirichlet = np.random.dirichlet
 
@@ -120,6 +162,9 @@ def main(name):
         eval_log.clear()
         if not reuse:
             root_node = None
+        if cfg.get("ckpt"):
+            p0, v0 = ref_eval(env.observation(), False)
+            root_evals.append((np.asarray(p0, dtype=np.float32).copy(), float(v0)))
         root_in = root_node
         n0 = float(root_in.N) if root_in is not None else 0.0
         kw = dict(env=env, eval_func=eval_func, root_node=root_node, c_puct_base=c_puct_base, c_puct_init=c_puct_init,
@@ -129,6 +174,7 @@ def main(name):
         else:
             out = mcts_v2.uct_search(**kw)
         move, pi, root_q, child_q, nxt = out
+        boards_log.append(np.array(env.board, dtype=np.int8).copy())
         moves_log.append(dict(
             game=state["game"], ply=env.steps, warm_up=int(warm_up), root_reused=int(root_in is not None), root_n0=n0,
             noise=cur.get("noise", np.zeros(A)), uniforms=list(cur.get("uniforms", [])), child_N=cur["child_N"],
@@ -184,6 +230,10 @@ def main(name):
     out["to_play"] = np.array([m["to_play"] for m in moves_log], dtype=np.int8)
     out["n_evals"] = np.array([sum(m["evals"]) for m in moves_log], dtype=np.int32)
     out["n_eval_calls"] = np.array([len(m["evals"]) for m in moves_log], dtype=np.int32)
+    if root_evals:
+        out["root_prior"] = np.stack([r[0] for r in root_evals])
+        out["root_value"] = np.array([r[1] for r in root_evals], dtype=np.float64)
+        out["board"] = np.stack(boards_log).astype(np.int8)
     for g, gm in enumerate(games):
         out[f"g{g}_finished"] = np.array(gm["finished"])
         if gm["finished"]:
