@@ -97,16 +97,45 @@ def eval_against_prev_ckpt(env, black_player, white_player, black_elo, white_elo
     return stats
 
 
+class DeviceEvaluator:
+    """An evaluator for play_eval_games_parallel whose leaf rows never leave the device: wraps an InferenceNet (core/network.py).
+    `device_eval(x)` takes the engine's int8 observation rows [B,17,N,N] on the device and returns (priors f32[B,A], values f32[B])
+    on the device; calling the object with (state, batched) numpy arrays honours the reference's eval_func contract
+    (pipeline.py:91-123), so the same object also serves the drop-in searches."""
+
+    def __init__(self, inference_net):
+        self.inf = inference_net
+
+    def device_eval(self, x):
+        import torch
+
+        with torch.no_grad():
+            pri, v = self.inf.forward_planes(x) if hasattr(self.inf, "forward_planes") else self.inf(x)
+        return pri.float(), v.float()
+
+    def __call__(self, state, batched=False):
+        import torch
+
+        x = torch.from_numpy(np.ascontiguousarray(state if batched else state[None, ...])).to(next(self.inf.parameters()).device)
+        pri, v = self.device_eval(x)
+        pri, v = pri.cpu().numpy(), v.cpu().numpy().tolist()
+        pi = [pri[i] for i in range(x.shape[0])]
+        return (pi, v) if batched else (pi[0], v[0])
+
+
 def play_eval_games_parallel(game, board_size, players, num_simulations, num_parallel, c_puct_base, c_puct_init, komi=7.5, num_to_win=5,
-                             binding=None, device="cuda", max_rounds=1 << 20):
+                             binding=None, device="cuda", max_rounds=1 << 20, openings=None):
     """SURVEY 8f-2 "many in parallel": G evaluation games of pipeline.py:815-867 advance in lock-step on ONE engine.
 
     players: one (black_eval, white_eval) pair per game; eval(states int8[B,17,N,N], True) -> (list of pi, list of v) with the
     reference's eval_func contract (pipeline.py:91-123).  Every game is what eval_against_prev_ckpt plays: no root noise, arg-max
     moves, a fresh tree for every move (`root_node=None`, pipeline.py:836), the searching player's own evaluator for all leaves of
-    its search.  The whole game runs inside the engine (search, move, env step, termination, scoring); per round the host only routes
-    the leaf rows of each game to the evaluator of the side to move.  Returns per game dict(moves, game_length, game_result,
-    num_passes, winner) -- the same games, move for move, as G sequential calls (tests/arena_checks.py)."""
+    its search.  The whole game runs inside the engine (search, move, env step, termination, scoring).  Per round the leaf rows of all
+    games whose side to move uses the same evaluator go to it in ONE batch; evaluators with a `device_eval` method (DeviceEvaluator)
+    receive and return device tensors -- their rows are gathered / scattered by index on the device and never pass through the host
+    (only the G side-to-move flags do).  openings: optional list of G move lists played (env.step) before the first search, e.g.
+    random openings for a match between two evaluators.  Returns per game dict(moves, game_length, game_result, num_passes, winner)
+    -- the same games, move for move, as G sequential calls (tests/arena_checks.py); `moves` includes the opening moves."""
     import torch
 
     from .. import _abi, _lib
@@ -119,41 +148,79 @@ def play_eval_games_parallel(game, board_size, players, num_simulations, num_par
                        c_puct_base=c_puct_base, c_puct_init=c_puct_init, root_noise=False, deterministic=True, reuse_tree=False, warm_up_steps=-1,
                        komi=komi, num_to_win=num_to_win, resign_threshold=-1.0, stop_at_game_end=True, feature_dtype=_abi.FEAT_I8)
     eng = Engine(binding, cfg, device=device)
-    eng.reset_games()
-    A, P = eng.A, num_parallel
-    for _ in range(max_rounds):
-        eng.expand_backup()
-        eng.select()
-        st, _ = eng.status()
-        if np.all(st[:, 0] == _abi.ST_IDLE):
-            break
-        valid = eng.valid.cpu().numpy().astype(bool).reshape(G, P)
-        feats = eng.features.cpu().numpy().reshape(G, P, 17, board_size, board_size)
-        pri = np.zeros((G, P, A), dtype=np.float32)
-        val = np.zeros((G, P), dtype=np.float32)
-        for g in range(G):
-            rows = np.flatnonzero(valid[g])
-            if len(rows) == 0:
-                continue
-            ev = players[g][int(st[g, 1]) & 1]  # ply even: black is searching
-            ps, vs = ev(feats[g, rows], True)
-            for r, p_, v_ in zip(rows, ps, vs):
-                pri[g, r], val[g, r] = np.asarray(p_, dtype=np.float32), v_
-        eng.priors.copy_(torch.from_numpy(pri.reshape(G * P, A)))
-        eng.values.copy_(torch.from_numpy(val.reshape(G * P)))
-    else:
-        raise RuntimeError("evaluation games did not finish")
-    got = eng.harvest(sample_capacity=G * eng.geo.stage_capacity, max_games=G, with_moves=True)  # room for every game at full length
-    games, moves = got[3], got[4].cpu().numpy()
-    out = [None] * G
-    for row in games:
-        g, s0, ln = int(row[15]), int(row[0]), int(row[1])
-        stats = game_stats_from_row(row, game, komi)
-        out[g] = dict(moves=[int(m) for m in moves[s0:s0 + ln]], game_length=stats["game_length"], game_result=stats["game_result"],
-                      num_passes=stats.get("num_passes"), winner=int(row[2]))
-    eng.close()
-    assert all(o is not None for o in out)
-    return out
+    try:
+        eng.reset_games()
+        A, P = eng.A, num_parallel
+        if openings is not None:
+            assert len(openings) == G
+            for t in range(max(len(o) for o in openings)):
+                eng.env_step(np.array([o[t] if t < len(o) else -2 for o in openings], dtype=np.int32))
+        # distinct evaluator objects and, per game and colour, which one searches
+        evs, who = [], np.zeros((G, 2), dtype=np.int64)
+        for g, pair in enumerate(players):
+            for c in (0, 1):
+                k = next((i for i, e in enumerate(evs) if e is pair[c]), None)
+                if k is None:
+                    evs.append(pair[c])
+                    k = len(evs) - 1
+                who[g, c] = k
+        on_device = [hasattr(e, "device_eval") for e in evs]
+        for _ in range(max_rounds):
+            eng.expand_backup()
+            eng.select()
+            st, _ = eng.status()
+            if np.all(st[:, 0] == _abi.ST_IDLE):
+                break
+            side = (st[:, 1] & 1).astype(np.int64)                      # ply even: black is searching
+            ev_of_game = who[np.arange(G), side]
+            valid_dev = eng.valid.view(G, P).bool()
+            host_needed = not all(on_device[k] for k in np.unique(ev_of_game))
+            if host_needed:
+                valid = valid_dev.cpu().numpy()
+                feats = eng.features.cpu().numpy().reshape(G, P, 17, board_size, board_size)
+                pri = np.zeros((G, P, A), dtype=np.float32)
+                val = np.zeros((G, P), dtype=np.float32)
+            for k, ev in enumerate(evs):
+                games_k = np.flatnonzero(ev_of_game == k)
+                if len(games_k) == 0:
+                    continue
+                if on_device[k]:  # gather this evaluator's valid leaf rows on the device, evaluate, scatter back
+                    mask = torch.zeros(G, dtype=torch.bool, device=eng.device)
+                    mask[torch.from_numpy(games_k).to(eng.device)] = True
+                    idx = torch.nonzero((valid_dev & mask[:, None]).reshape(-1)).flatten()
+                    if idx.numel() == 0:
+                        continue
+                    p_k, v_k = ev.device_eval(eng.features.index_select(0, idx))
+                    eng.priors.index_copy_(0, idx, p_k.to(eng.priors.dtype))
+                    eng.values.index_copy_(0, idx, v_k.to(eng.values.dtype))
+                    continue
+                gg, rr = np.nonzero(valid[games_k])
+                if len(gg) == 0:
+                    continue
+                ps, vs = ev(feats[games_k[gg], rr], True)   # ONE batch per evaluator and round
+                for g_, r_, p_, v_ in zip(games_k[gg], rr, ps, vs):
+                    pri[g_, r_], val[g_, r_] = np.asarray(p_, dtype=np.float32), v_
+            if host_needed:
+                host_rows = torch.from_numpy(np.flatnonzero(np.repeat(~np.array([on_device[k] for k in ev_of_game]), P))).to(eng.device)
+                if host_rows.numel():
+                    eng.priors.index_copy_(0, host_rows, torch.from_numpy(pri.reshape(G * P, A)).to(eng.device).index_select(0, host_rows))
+                    eng.values.index_copy_(0, host_rows, torch.from_numpy(val.reshape(G * P)).to(eng.device).index_select(0, host_rows))
+        else:
+            raise RuntimeError("evaluation games did not finish")
+        got = eng.harvest(sample_capacity=G * eng.geo.stage_capacity, max_games=G, with_moves=True)  # room for every game at full length
+        games, moves = got[3], got[4].cpu().numpy()
+        out = [None] * G
+        for row in games:
+            g, s0, ln = int(row[15]), int(row[0]), int(row[1])
+            stats = game_stats_from_row(row, game, komi)
+            opening = [int(m) for m in openings[g]] if openings is not None else []
+            out[g] = dict(moves=opening + [int(m) for m in moves[s0:s0 + ln]], game_length=len(opening) + stats["game_length"], game_result=stats["game_result"],
+                          num_passes=stats.get("num_passes"), winner=int(row[2]))
+        if not all(o is not None for o in out):
+            raise RuntimeError("evaluation games did not all reach the harvest")
+        return out
+    finally:
+        eng.close()  # the engine owns device memory and a native handle: released on every path (an evaluator may raise)
 
 
 def eval_many_against_prev_ckpt(game, board_size, players, elos, num_simulations, num_parallel, c_puct_base, c_puct_init, **kw):

@@ -292,6 +292,25 @@ class InferenceNet(nn.Module):
                              self.num_actions, self.fc_width, st), "azsp_fc_heads")
         return pri, v
 
+    @torch.no_grad()
+    def forward_planes(self, x, priors_out=None, values_out=None):
+        """x: observation planes [B,17,N,N] (any dtype, on the evaluator's device).  Runs the whole evaluator on the hand-written kernels
+        when this network / board has them (the planes are padded to 32 channels and converted to the tiled feature layout on the
+        device: azsp_tile_layout), otherwise `forward`.  Used where leaf rows arrive as NCHW planes: evaluation games
+        (core/evaluate.py DeviceEvaluator), drop-in eval_func wrappers."""
+        B, _, n, _ = x.shape
+        if not (x.is_cuda and self.supports_tiled_features(n, x.device)):
+            return self.forward(x, priors_out, values_out)
+        import ctypes
+
+        xb = torch.zeros((B, 32, n, n), dtype=torch.bfloat16, device=x.device).contiguous(memory_format=torch.channels_last)
+        xb[:, : x.shape[1]] = x.to(torch.bfloat16)
+        feat = torch.zeros(self.binding.dll.azsp_tiled_bytes(B, n, 32) // 2, dtype=torch.bfloat16, device=x.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        self._ck(self.binding.dll.azsp_tile_layout(xb.data_ptr(), feat.data_ptr(), B, n, 32, 1, st), "azsp_tile_layout")
+        pri, v = self.forward_tiled(feat, B, n, priors_out, values_out, slot=3)
+        return (pri, v) if priors_out is not None else (pri.clone(), v.clone())  # the slot's output buffers are reused by the next call
+
     def _fc_heads(self, pol, val, priors_out, values_out):
         """Fully connected layers of both heads (core/network.py:136-156) on the flattened head planes."""
         logits = F.linear(pol, self.pol_fc_w, self.pol_fc_b)

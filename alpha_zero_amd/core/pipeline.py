@@ -332,24 +332,34 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
     last_ckpt, t_last, played_games = None, time.time(), 0
     while stop_event is None or not stop_event.is_set():
         if ckpt_event is not None and ckpt_event.is_set():  # the learner is writing a checkpoint (pipeline.py:228-230)
+            time.sleep(0.001)
             continue
         if var_resign_threshold is not None and env.has_resign_move and var_resign_threshold.value != actor.resign_threshold:
             actor.set_resign_threshold(var_resign_threshold.value)  # pipeline.py:241-242: read before every game
         if var_ckpt is not None:
             new_ckpt = var_ckpt.value.decode("utf-8") if isinstance(var_ckpt.value, bytes) else str(var_ckpt.value)
             if new_ckpt != "" and new_ckpt != last_ckpt and os.path.exists(new_ckpt):  # pipeline.py:232-239
-                st = torch.load(new_ckpt, map_location="cpu", weights_only=False)
+                try:  # a checkpoint that holds only tensors and numbers loads without executing pickled code
+                    st = torch.load(new_ckpt, map_location="cpu", weights_only=True)
+                except Exception:  # the reference's full checkpoints also carry optimizer / scheduler objects (pipeline.py:597-606)
+                    st = torch.load(new_ckpt, map_location="cpu", weights_only=False)
                 network.load_state_dict(st["network"])
                 actor.set_network(network, st["training_steps"])
                 last_ckpt = new_ckpt
-        actor.run_rounds(harvest_every)
+        # Rounds in small chunks, polling the checkpoint event between them.  The reference actor queues every game that finished before
+        # the event, drops the one game that ends while it is set (pipeline.py:264-267) and starts no new game until it clears
+        # (pipeline.py:228-230).  Here: the moment the event is seen, whatever has finished so far is harvested and queued (those games
+        # ended before it was noticed), then the engine pauses at the top of the loop -- no game ends during the event, none is dropped;
+        # the games in progress resume under the new weights and are counted as straddling (SelfPlayActor.straddled_games).
+        done_rounds, poll = 0, max(1, min(8, harvest_every))
+        while done_rounds < harvest_every and not (ckpt_event is not None and ckpt_event.is_set()) and not (stop_event is not None and stop_event.is_set()):
+            actor.run_rounds(min(poll, harvest_every - done_rounds))
+            done_rounds += poll
         want_sgf = bool(save_sgf_dir) and save_sgf_interval > 0 and os.path.isdir(save_sgf_dir)
         finished = actor.harvest(with_moves=want_sgf)
         now = time.time()
         if stop_event is not None and stop_event.is_set():
             break
-        if ckpt_event is not None and ckpt_event.is_set():
-            continue  # pipeline.py:264-267: games that end while a checkpoint is being created are discarded
         if want_sgf:  # every save_sgf_interval-th finished game is dumped like the reference does (pipeline.py:276-281)
             from ..utils.sgf import get_time_stamp as _ts
 

@@ -447,28 +447,44 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
         }
     float ev[4];  // one epilogue quad between its phases
 
-    // epilogue of a first-convolution unit, quad q = 2 j + slot: ReLU, one bf16 rounding, 8 bytes into the intermediate image
-    auto epi_mid = [&](int set, int m0, int q) {
+    // Epilogues as MICRO-OPS: one or two instructions each, issued one per MFMA gap.  Measured with the ablation harness
+    // (tools/probes/block64_abl_probe.hip, profiles/r03_block64_ablation.txt): with the epilogue of a quad issued as one block of 8-16
+    // VALU instructions behind a k-step's four 16-cycle MFMAs the riders cost 18.6 % of the launch's cycles (matrix pipe busy 66 % ->
+    // 81 % without them) -- a 16x16x32 MFMA leaves room for about one VALU instruction in its shadow, not for a burst.
+    unsigned epa = 0, epb = 0;  // packed halves of the quad in flight
+    // first-convolution unit, quad q = 2 j + slot: ReLU, one bf16 rounding, 8 bytes into the intermediate image.  6 micro-ops.
+    auto epi_mid_op = [&](int set, int m0, int q, int op) {
         const int j = q >> 1, sl = q & 1;
-        const c6_f32x4 v = acc[set][j][sl];
-        const int ofs = (int)(lmap[m0 + j] & 0xffffu) + wconst[sl];
-        *(cv_u32x2*)(MID + ofs) = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(v[0], v[1]), 0u), cw_pk_max_i16(cw_pk_bf16(v[2], v[3]), 0u)};
+        if (op == 0) epa = cw_pk_bf16(acc[set][j][sl][0], acc[set][j][sl][1]);
+        else if (op == 1) epb = cw_pk_bf16(acc[set][j][sl][2], acc[set][j][sl][3]);
+        else if (op == 2) epa = cw_pk_max_i16(epa, 0u);
+        else if (op == 3) epb = cw_pk_max_i16(epb, 0u);
+        else if (op == 4) *(cv_u32x2*)(MID + ((int)(lmap[m0 + j] & 0xffffu) + wconst[sl])) = (cv_u32x2){epa, epb};
     };
-    // epilogue of a second-convolution unit, quad q, phase ph3: skip add (plain v_add_f32, see az_conv.h), rounding, ReLU, 8-byte store
-    auto epi_out = [&](int set, int m0, unsigned char* out, int q, int ph3, bool store_ok) {
+    constexpr int MID_OPS = 5;
+    // second-convolution unit, quad q: skip add (plain v_add_f32, see az_conv.h), rounding, ReLU, 8-byte store.  9 micro-ops.
+    auto epi_out_op = [&](int set, int m0, unsigned char* out, int q, int op, bool store_ok) {
         const int j = q >> 1, sl = q & 1;
-        const cv_u32x2 r2 = rr[set][q];
-        if (ph3 == 0) {
-            ev[0] = cw_add_f32(acc[set][j][sl][0], cv_bf16_lo(r2.x));
-            ev[1] = cw_add_f32(acc[set][j][sl][1], cv_bf16_hi(r2.x));
-        } else if (ph3 == 1) {
-            ev[2] = cw_add_f32(acc[set][j][sl][2], cv_bf16_lo(r2.y));
-            ev[3] = cw_add_f32(acc[set][j][sl][3], cv_bf16_hi(r2.y));
-        } else {
-            const unsigned gq = (lmap[m0 + j] >> 16) * 16u + gconst[sl];
-            const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(ev[0], ev[1]), 0u), cw_pk_max_i16(cw_pk_bf16(ev[2], ev[3]), 0u)};
-            if (store_ok) *(cv_u32x2*)(out + gq) = o;
+        if (op == 0) ev[0] = cw_add_f32(acc[set][j][sl][0], cv_bf16_lo(rr[set][q].x));
+        else if (op == 1) ev[1] = cw_add_f32(acc[set][j][sl][1], cv_bf16_hi(rr[set][q].x));
+        else if (op == 2) ev[2] = cw_add_f32(acc[set][j][sl][2], cv_bf16_lo(rr[set][q].y));
+        else if (op == 3) ev[3] = cw_add_f32(acc[set][j][sl][3], cv_bf16_hi(rr[set][q].y));
+        else if (op == 4) epa = cw_pk_bf16(ev[0], ev[1]);
+        else if (op == 5) epb = cw_pk_bf16(ev[2], ev[3]);
+        else if (op == 6) epa = cw_pk_max_i16(epa, 0u);
+        else if (op == 7) epb = cw_pk_max_i16(epb, 0u);
+        else if (op == 8) {
+            if (store_ok) *(cv_u32x2*)(out + ((lmap[m0 + j] >> 16) * 16u + gconst[sl])) = (cv_u32x2){epa, epb};
         }
+    };
+    constexpr int OUT_OPS = 9;
+    auto epi_mid = [&](int set, int m0, int q) {  // whole quad at once (the exposed epilogue before B2)
+#pragma unroll
+        for (int op = 0; op < MID_OPS; ++op) epi_mid_op(set, m0, q, op);
+    };
+    auto epi_out = [&](int set, int m0, unsigned char* out, int q, bool store_ok) {  // whole quad at once (after the last tile)
+#pragma unroll
+        for (int op = 0; op < OUT_OPS; ++op) epi_out_op(set, m0, out, q, op, store_ok);
     };
 
     int it = 0;
@@ -507,30 +523,38 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
                 if constexpr (i == NUNIT - 1 && t == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM_AT_M) : "memory");
                 if constexpr (t + R - 1 < KS) load_step(b0, b1p, t + R - 1, (i * KS + t + R - 1) % R);
                 else if constexpr (!cross) load_step(nb0, nb1, t + R - 1 - KS, (i * KS + t + R - 1) % R);
-#pragma unroll
-                for (int q = 0; q < nq; ++q) {
-                    const int j = q >> 1, sl = q & 1;
+                // the unit's MFMAs, each followed by ONE micro-op of the previous unit's epilogue (slot = running MFMA index of the unit)
+                cp_for_each([&](auto QC) __attribute__((always_inline)) {
+                    constexpr int q = decltype(QC)::value, j = q >> 1, sl = q & 1;
                     constexpr int fb = conv * 36 + 2 * t;
                     if constexpr (t == 0) c6_mfma_ac(acc[set][j][sl], wf[fb + sl], bb[(i * KS + t) % R][j], bv[conv][sl]);
                     else if constexpr (fb < 64) c6_mfma_a(acc[set][j][sl], wf[fb + sl], bb[(i * KS + t) % R][j]);
                     else c6_mfma_v(acc[set][j][sl], wf[fb + sl], bb[(i * KS + t) % R][j]);
-                }
-                // ---- riders of this k-step ---------------------------------------------------------------------------------
-                if constexpr (conv == 1 && t < 2) {  // this unit's skip values from the resident x tile (used by its epilogue inside the next unit)
+                    constexpr int slot = t * nq + q;            // 0 .. 18 nq - 1
+                    constexpr int S0 = 6;                       // first slot that may touch the previous unit's accumulators
+                    if constexpr (pconv == 0 && i != NU) {      // previous unit: first convolution -> intermediate image
+                        constexpr int per = (pnq * MID_OPS + (KS * nq - S0) - 1) / (KS * nq - S0);  // micro-ops per slot (1, or 2 in a short unit)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int q = 2 * t + k, j = q >> 1, sl = q & 1;
-                        if (q < nq) rr[set][q] = *(const cv_u32x2*)(Xs + ((int)(lmap[2 * u + j] & 0xffffu) + wconst[sl]));
+                        for (int k = 0; k < per; ++k) {
+                            const int o = (slot - S0) * per + k;
+                            if (slot >= S0 && o < pnq * MID_OPS) epi_mid_op(pset, 2 * pu, o / MID_OPS, o % MID_OPS);
+                        }
+                    } else if constexpr (pconv == 1) {
+                        constexpr int per = (pnq * OUT_OPS + (KS * nq - S0) - 1) / (KS * nq - S0);
+#pragma unroll
+                        for (int k = 0; k < per; ++k) {
+                            const int o = (slot - S0) * per + k;
+                            if (slot >= S0 && o < pnq * OUT_OPS) epi_out_op(pset, 2 * pu, pout, o / OUT_OPS, o % OUT_OPS, pstore);
+                        }
                     }
-                }
+                    if constexpr (conv == 1 && slot < nq) {  // this unit's skip values from the resident x tile (used by its epilogue inside the next unit)
+                        rr[set][slot] = *(const cv_u32x2*)(Xs + ((int)(lmap[2 * u + (slot >> 1)] & 0xffffu) + wconst[slot & 1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }, typename CpMakeSeq<nq>::type{});
                 if constexpr (i >= 1 && i <= 3 && (t == 2 || t == 6 || t == 11 || t == 15)) {  // the next tile's DMA pieces
                     constexpr int p = (i - 1) * 4 + (t == 2 ? 0 : t == 6 ? 1 : t == 11 ? 2 : 3);
                     if constexpr (p < NPIECE) dma_piece(nsrc, ndst, has_next, p);
-                }
-                if constexpr (pconv == 0 && i != NU) {  // previous unit belongs to the first convolution: its outputs go to the intermediate image
-                    if constexpr (t >= 4 && t <= 13 && (t - 4) % 3 == 0 && (t - 4) / 3 < pnq) epi_mid(pset, 2 * pu, (t - 4) / 3);
-                } else if constexpr (pconv == 1) {
-                    if constexpr (t >= 3 && t <= 14 && (t - 3) / 3 < pnq) epi_out(pset, 2 * pu, pout, (t - 3) / 3, (t - 3) % 3, pstore);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<KS>::type{});
@@ -552,11 +576,7 @@ k_resblock64(const unsigned char* __restrict__ x, const unsigned short* __restri
     if (it > 0) {
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[1][0][0]), "+v"(acc[1][0][1]), "+v"(acc[1][1][0]), "+v"(acc[1][1][1]));
 #pragma unroll
-        for (int q = 0; q < (SHARED ? 3 : 4); ++q) {
-            epi_out(1, 2 * (NU - 1), yprev, q, 0, true);
-            epi_out(1, 2 * (NU - 1), yprev, q, 1, true);
-            epi_out(1, 2 * (NU - 1), yprev, q, 2, true);
-        }
+        for (int q = 0; q < (SHARED ? 3 : 4); ++q) epi_out(1, 2 * (NU - 1), yprev, q, true);
     }
 }
 #endif  // __HIPCC__

@@ -121,7 +121,8 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
         const int n_cu = cu_count();
         if (n_cu < 0) return -1;
         if (x == y || res == y) return 1;  // y holds the partial sum between the launches
-        const long long nst = boards < n_cu / 4 ? boards : n_cu / 4;
+        const long long groups = n_cu / 4 > 0 ? n_cu / 4 : 1;  // stripes of 4 workgroups; a device (partition) with < 4 CUs still gets one stripe
+        const long long nst = boards < groups ? boards : groups;
         const dim3 grid((unsigned)(4 * nst)), block(CW_THREADS);
         if (res)
             hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
@@ -129,6 +130,7 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
         else
             hipLaunchKernelGGL((k_conv3x3_hb19<false, 16>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
                                (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, 0, 1, 256, 0, 32, 0);
+        if (AZ_HIP(hipGetLastError())) return -1;  // every launch is checked, not only the last one
         hipLaunchKernelGGL((k_conv3x3_hb19<true, 16>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
                            (const unsigned char*)y, (unsigned char*)y, (int)boards, relu, 0, 256, 128, 32, 16);
         return AZ_HIP(hipGetLastError());
@@ -176,7 +178,8 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
         return AZ_HIP(hipGetLastError());
     }
     if (S == C9_S && C == 256 && pad == 1) {  // 19x19 Go: 17 planes (padded to 32) -> 256 filters, one launch
-        const long long nst = boards < n_cu / 4 ? boards : n_cu / 4;
+        const long long groups = n_cu / 4 > 0 ? n_cu / 4 : 1;
+        const long long nst = boards < groups ? boards : groups;
         hipLaunchKernelGGL((k_conv3x3_hb19<false, 4>), dim3((unsigned)(4 * nst)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
                            (const unsigned short*)w, bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu, 1, 32, 0, 4, 0);
         return AZ_HIP(hipGetLastError());

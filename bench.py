@@ -184,6 +184,9 @@ def preroll(act, args, world, dev, min_rounds=None):
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if ok.item() > 0:
                 break
+    else:  # the cap was reached without the steady-state criterion: say so instead of silently timing an unsettled engine
+        print(f"bench.py: WARNING pre-roll stopped at its cap of {cap} rounds before every slot had committed {args.preroll_moves} searched moves",
+              file=sys.stderr, flush=True)
     return rounds
 
 

@@ -58,6 +58,58 @@ def check_parallel_arena(kind, golden_dir):
         assert res2[0]["moves"] == [int(m) for m in g[f"{tag}_moves_0"]]
 
 
+class SynthDeviceEvaluator:
+    """The synthetic evaluator behind the device route of play_eval_games_parallel (tensors in, tensors out)."""
+
+    def __init__(self, A, sharp):
+        import torch
+        from synth_eval import eval_batch
+
+        self.torch, self.eval_batch, self.A, self.sharp, self.calls = torch, eval_batch, A, sharp, 0
+
+    def device_eval(self, x):
+        self.calls += 1
+        p, v = self.eval_batch(x.cpu().numpy().astype(np.int8), self.A, self.sharp)
+        return self.torch.from_numpy(p).to(x.device), self.torch.from_numpy(v).to(x.device)
+
+
+def check_device_route_arena(kind, golden_dir):
+    """Evaluators with `device_eval` (leaf rows gathered / scattered by index on the engine's device, one batch per evaluator and
+    round) play exactly the games of the host route -- the reference's golden games -- also mixed with a host evaluator in one batch."""
+    import engine_util as eu
+    from alpha_zero_amd.core.evaluate import play_eval_games_parallel
+
+    binding, dev = eu.backend(kind)
+    g = np.load(os.path.join(golden_dir, "eval_arena.npz"))
+    for tag in ("p1", "p4"):
+        cfg = json.loads(str(g[f"{tag}_cfg"]))
+        strong_d, weak_d = SynthDeviceEvaluator(26, cfg["sharp_black"]), SynthDeviceEvaluator(26, cfg["sharp_white"])
+        weak_h = make_eval_func(26, cfg["sharp_white"])
+        res = play_eval_games_parallel("go", 5, [(strong_d, weak_d), (weak_d, strong_d), (strong_d, weak_h)], cfg["sims"], cfg["P"], 19652, 1.25,
+                                       komi=cfg["komi"], binding=binding, device=dev)
+        ref = play_eval_games_parallel("go", 5, [(make_eval_func(26, cfg["sharp_black"]), weak_h), (weak_h, make_eval_func(26, cfg["sharp_black"]))],
+                                       cfg["sims"], cfg["P"], 19652, 1.25, komi=cfg["komi"], binding=binding, device=dev)
+        assert res[0]["moves"] == [int(m) for m in g[f"{tag}_moves_0"]] == ref[0]["moves"]
+        assert res[1] == ref[1] and res[2] == res[0]
+        assert 0 < strong_d.calls  # one batch per evaluator and round, not one per game
+        # random openings are played before the first search and reported with the moves
+        op = [[12, 6], [12, 6]]
+        r2 = play_eval_games_parallel("go", 5, [(strong_d, weak_d), (weak_d, strong_d)], cfg["sims"], cfg["P"], 19652, 1.25, komi=cfg["komi"],
+                                      binding=binding, device=dev, openings=op)
+        assert r2[0]["moves"][:2] == [12, 6] and r2[1]["moves"][:2] == [12, 6] and r2[0]["game_length"] == len(r2[0]["moves"])
+
+    class Boom:
+        def __call__(self, *a, **k):
+            raise KeyError("evaluator failed")
+
+    try:  # an evaluator that raises must not leak the engine (try / finally around the game loop)
+        play_eval_games_parallel("go", 5, [(Boom(), Boom())], 8, 1, 19652, 1.25, binding=binding, device=dev)
+    except KeyError:
+        pass
+    else:
+        raise AssertionError("the evaluator's exception was swallowed")
+
+
 def check_elo_and_resign(golden_dir):
     from alpha_zero_amd.core.evaluate import EloRating, ResignController, get_k_factor, maybe_adjust_resign_threshold
 

@@ -121,5 +121,7 @@ def check_exact(kind, name):
     ef = module_eval_func(load_shipped(), "cpu")
     recs, total = run_golden(kind, name, ef, teacher_forced=False)
     assert len(recs) == total and all(r["same_move"] and r["pi_dtype"] for r in recs), summarize(recs, total)
-    assert max(r["dpi"] for r in recs) <= 1e-6 and max(r["dq"] for r in recs) == 0.0 and max(r["dcq"] for r in recs) == 0.0, summarize(recs, total)
+    # Q: exact where the evaluator runs on the CPU type that recorded the golden; another host CPU (the GPU box) may pick other fp32
+    # convolution kernels inside torch -- last-bit differences in the values, the same visit counts
+    assert max(r["dpi"] for r in recs) <= 1e-6 and max(r["dq"] for r in recs) <= 1e-6 and max(r["dcq"] for r in recs) <= 1e-6, summarize(recs, total)
     return summarize(recs, total)

@@ -24,3 +24,7 @@ def test_checkpoint_dictionary(tmp_path):
 
 def test_parallel_evaluation_games_match_reference(golden_dir):
     ac.check_parallel_arena("host", golden_dir)
+
+
+def test_device_route_evaluation_games_match_reference(golden_dir):
+    ac.check_device_route_arena("host", golden_dir)

@@ -12,7 +12,7 @@ from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet, widen_networ
 
 
 def load_shipped(golden_dir):
-    st = torch.load(os.path.join(golden_dir, "gomoku13_ckpt200000_network.pt"), map_location="cpu", weights_only=False)
+    st = torch.load(os.path.join(golden_dir, "gomoku13_ckpt200000_network.pt"), map_location="cpu", weights_only=True)  # tensors + an int only
     net = AlphaZeroNet((17, 13, 13), 169, 10, 40, 80, gomoku=True)
     missing = net.load_state_dict(st["network"], strict=True)  # the reference's own keys, no renaming
     assert not missing.missing_keys and not missing.unexpected_keys and st["training_steps"] == 200000

@@ -216,6 +216,7 @@ def test_gpu_parallel_evaluation_games_match_reference(golden_dir):
     import arena_checks as ac
 
     ac.check_parallel_arena("gpu", golden_dir)
+    ac.check_device_route_arena("gpu", golden_dir)
 
 
 def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, min_games):

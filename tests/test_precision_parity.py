@@ -79,8 +79,9 @@ def test_gpu_bf16_search_close_to_fp32_search_go9_bench_network():
     torch.manual_seed(1)
     net = AlphaZeroNet((17, 9, 9), 82, 10, 128, 128)  # the bench's network: random Kaiming init = nearly flat priors
     r = _compare("go9_10x128_random_init", net, "go", 9, 384, 200, 8, 40)
-    assert r["top1_agreement"] >= 0.80 and r["move_agreement"] >= 0.95, r
-    assert r["mean_kl_fp32_bf16"] <= 0.15 and r["mean_tv"] <= 0.15 and r["mean_abs_root_q_diff"] <= 0.04, r
+    # measured (profiles/r02_precision_parity_*.json, r03): 0.893 / 0.992 / 0.098 / 0.084 / 0.025 -- bounds = measured minus a small margin
+    assert r["top1_agreement"] >= 0.87 and r["move_agreement"] >= 0.975, r
+    assert r["mean_kl_fp32_bf16"] <= 0.12 and r["mean_tv"] <= 0.10 and r["mean_abs_root_q_diff"] <= 0.03, r
 
 
 def test_gpu_bf16_search_close_to_fp32_search_trained_gomoku13(golden_dir):
@@ -89,5 +90,71 @@ def test_gpu_bf16_search_close_to_fp32_search_trained_gomoku13(golden_dir):
 
     net = widen_network(test_ckpt.load_shipped(golden_dir), 64)
     r = _compare("gomoku13_shipped_ckpt_widened64", net, "gomoku", 13, 256, 200, 8, 30)
-    assert r["top1_agreement"] >= 0.95 and r["move_agreement"] >= 0.97, r
-    assert r["mean_kl_fp32_bf16"] <= 0.02 and r["mean_tv"] <= 0.03 and r["mean_abs_root_q_diff"] <= 0.02, r
+    # measured: 0.977-0.988 / 0.996 / 0.005-0.008 / 0.009-0.015 / 0.006-0.008 (the fp32 side runs library convolutions whose algorithm
+    # choice varies from box to box)
+    assert r["top1_agreement"] >= 0.96 and r["move_agreement"] >= 0.98, r
+    assert r["mean_kl_fp32_bf16"] <= 0.015 and r["mean_tv"] <= 0.025 and r["mean_abs_root_q_diff"] <= 0.015, r
+
+
+def test_gpu_bf16_vs_fp32_evaluator_match_trained_gomoku13(golden_dir):
+    """Game-level statement (VERDICT r2 "Next" #5): the bf16 hand-written evaluator against the fp32 evaluator of the SAME trained
+    network (the reference's shipped 13x13 Gomoku checkpoint), 256 evaluation games on one engine (pipeline.py:815-867 rules: no noise,
+    arg-max moves, fresh tree every move; 64 simulations, P = 8) from 128 seeded random two-ply openings, every opening played twice
+    with the colours swapped.  If the evaluators were identical every pair would split 1 : 1.  Bound: the bf16 side scores within
+    0.5 +- 0.1 (binomial sigma of 256 independent games = 0.031; colour-paired games vary less)."""
+    import test_ckpt
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.evaluate import DeviceEvaluator, play_eval_games_parallel
+    from alpha_zero_amd.core.network import InferenceNet, widen_network
+
+    net = test_ckpt.load_shipped(golden_dir)
+    ev16 = DeviceEvaluator(InferenceNet(widen_network(net, 64), dtype=torch.bfloat16, binding=_lib.load()).cuda())
+    ev32 = DeviceEvaluator(InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda())
+    assert ev16.inf.supports_tiled_features(13, "cuda")
+    rng = np.random.Generator(np.random.PCG64(99))
+    centre = [r * 13 + c for r in range(3, 10) for c in range(3, 10)]
+    openings, players = [], []
+    for _ in range(128):
+        op = [int(m) for m in rng.choice(centre, size=2, replace=False)]
+        openings += [op, op]
+        players += [(ev16, ev32), (ev32, ev16)]
+    res = play_eval_games_parallel("gomoku", 13, players, 64, 8, 19652, 1.25, openings=openings)
+    score16 = 0.0
+    for g, r in enumerate(res):
+        bf16_is_black = g % 2 == 0
+        score16 += 0.5 if r["winner"] == 0 else float((r["winner"] == 1) == bf16_is_black)
+    rate = score16 / len(res)
+    same = play_eval_games_parallel("gomoku", 13, [(ev32, ev32)] * 2 + [(ev16, ev16)] * 2, 64, 8, 19652, 1.25, openings=openings[:2] + openings[:2])
+    out = dict(games=len(res), bf16_score=rate, black_wins=sum(r["winner"] == 1 for r in res) / len(res), mean_length=float(np.mean([r["game_length"] for r in res])),
+               identical_pair_moves_equal=same[0]["moves"] == same[1]["moves"] and same[2]["moves"] == same[3]["moves"])
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "precision_parity_arena_gomoku13.json"), "w"), indent=1)
+    print(json.dumps(out))
+    assert out["identical_pair_moves_equal"]
+    assert abs(rate - 0.5) <= 0.1, out
+
+
+def test_gpu_go19_256_full_depth_forward_vs_fp32():
+    """The 19x19 x 256 kernel adds a second bf16 rounding of a partial sum per convolution (az_conv19.h: two launches, one per
+    128-channel half).  Bound it at FULL depth: the jumbo shape (20 blocks x 256, training_go_jumbo.py:46) on the hand-written kernels
+    vs the fp32 module on the same positions -- priors to 3e-2, value to 5e-2, top-1 agreement >= 0.9 (random Kaiming init with the last
+    layers shrunk so that softmax / tanh are well conditioned, as in the other network tests)."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet
+
+    torch.manual_seed(21)
+    net = AlphaZeroNet((17, 19, 19), 362, 20, 256, 256)
+    with torch.no_grad():
+        net.policy_head[4].weight.mul_(0.2)
+        net.value_head[6].weight.mul_(0.3)
+    inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
+    assert inf.supports_tiled_features(19, "cuda")
+    x = (torch.rand(48, 17, 19, 19) > 0.6).float()
+    pri, v = inf.forward_tiled(eu.tile_features(x).cuda(), 48, 19)
+    with torch.no_grad():
+        logits, vr = net.eval().cuda()(x.cuda())
+    ref_p = torch.softmax(logits, -1)
+    dp, dv = (pri - ref_p).abs().max().item(), (v - vr.squeeze(1)).abs().max().item()
+    agree = (pri.argmax(-1) == ref_p.argmax(-1)).float().mean().item()
+    json.dump(dict(max_dp=dp, max_dv=dv, top1=agree), open(os.path.join(ROOT, "gpurun_out", "precision_go19_20x256_full_depth.json"), "w"))
+    assert dp <= 3e-2 and dv <= 5e-2 and agree >= 0.9, (dp, dv, agree)

@@ -25,11 +25,63 @@ def make(mode):
     return act
 
 
+def round_engine2(act):
+    """engine kernels of the two halves on two streams, then (joined) the two half forwards one after the other on the main stream"""
+    e = act.engine
+    main = torch.cuda.current_stream()
+    for k, (g0, g1) in enumerate(act._halves):
+        act._streams[k].wait_stream(main)
+        with torch.cuda.stream(act._streams[k]):
+            e.expand_backup(g0, g1)
+            e.select(g0, g1)
+    for s in act._streams:
+        main.wait_stream(s)
+    for k in range(2):
+        act._forward_half(k)
+
+
+def round_fwd2(act):
+    """engine kernels of both halves on the main stream, then the two half forwards concurrently on two streams"""
+    e = act.engine
+    main = torch.cuda.current_stream()
+    for g0, g1 in act._halves:
+        e.expand_backup(g0, g1)
+        e.select(g0, g1)
+    for k in range(2):
+        act._streams[k].wait_stream(main)
+        with torch.cuda.stream(act._streams[k]):
+            act._forward_half(k)
+    for s in act._streams:
+        main.wait_stream(s)
+
+
+def round_eng_vs_fwd(act):
+    """half A: engine + forward on stream 0; half B strictly afterwards on the main stream -- but half B's ENGINE kernels run on stream 1
+    concurrently with half A's forward"""
+    e = act.engine
+    main = torch.cuda.current_stream()
+    (a0, a1), (b0, b1) = act._halves
+    act._streams[0].wait_stream(main)
+    act._streams[1].wait_stream(main)
+    with torch.cuda.stream(act._streams[0]):
+        e.expand_backup(a0, a1)
+        e.select(a0, a1)
+        act._forward_half(0)
+    with torch.cuda.stream(act._streams[1]):
+        e.expand_backup(b0, b1)
+        e.select(b0, b1)
+    main.wait_stream(act._streams[0])
+    main.wait_stream(act._streams[1])
+    act._forward_half(1)
+
+
 def trace(mode, rounds=60):
-    act = make(mode)
+    act = make("overlap-nograph" if mode in ("engine2", "fwd2", "eng_vs_fwd") else mode)
+    if mode in ("engine2", "fwd2", "eng_vs_fwd"):
+        act.engine.on_launch = None
     out = []
     for r in range(rounds):
-        act.run_round()
+        {"engine2": round_engine2, "fwd2": round_fwd2, "eng_vs_fwd": round_eng_vs_fwd}.get(mode, lambda a: a.run_round())(act)
         st, q = act.engine.status()
         pri = act.engine.priors.clone().cpu()
         out.append((st.copy(), q.copy(), pri))
@@ -37,7 +89,7 @@ def trace(mode, rounds=60):
 
 
 ref, _ = trace("serial")
-for mode in ("serial", "overlap1-nograph", "overlap1", "overlap-nograph", "overlap"):
+for mode in ("serial", "engine2", "fwd2", "eng_vs_fwd", "overlap-nograph"):
     tr, halves = trace(mode)
     first = None
     for r, ((s0, q0, p0), (s1, q1, p1)) in enumerate(zip(ref, tr)):
