@@ -60,13 +60,9 @@ class SelfPlayActor:
     def __init__(self, network: AlphaZeroNet, *, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8,
                  c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
                  resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.bfloat16,
-                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None,
-                 overlap_engine=None):
+                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None):
         """tiled_features: None = use the evaluator's tiled input layout whenever the network / board shape has the hand-written
-        stem / tower / head kernels (9x9, 128 filters, bf16 on the GPU); False = always NCHW planes + library stem.
-        overlap_engine: run the games as two half-batches on two streams, so that the select / backup kernels of one half execute
-        while the other half's leaf batch is in the evaluator (games never interact during a search: results are bit-identical).
-        None = on for large batches on the hand-written evaluator (>= 1024 games, <= 128 filters), off otherwise."""
+        stem / tower / head kernels (9x9, 128 filters, bf16 on the GPU); False = always NCHW planes + library stem."""
         from .. import _lib
 
         self.binding = binding or _lib.load(require_gpu=True)
@@ -99,99 +95,15 @@ class SelfPlayActor:
         self.rounds = 0
         self.straddled_games = 0  # harvested games that were in progress across a weight hot-swap (see harvest())
         self.drop_straddling_games = False
-        # ---- two half-batches on two streams (engine kernels of one half hide behind the other half's forward)
-        self._halves, self._streams, self._hgraphs, self._forked = None, None, [None, None], False
-        filters = network.conv_block[0].out_channels
-        if overlap_engine is None:
-            overlap_engine = self.device.type == "cuda" and self.tiled_features and num_games >= 1024 and filters <= 128
-        if overlap_engine:
-            if not (self.device.type == "cuda" and self.tiled_features):
-                raise ValueError("overlap_engine needs the tiled evaluator on a HIP device")
-            gA = self._plan_halves()
-            if gA is not None:
-                self._halves = [(0, gA), (gA, num_games)]
-                self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-                self.engine.on_launch = self._on_engine_launch
-        self.overlap = self._halves is not None
         self.set_network(network, training_steps)
-
-    # -- half-batch plan -----------------------------------------------------------------------------------
-    def _plan_halves(self):
-        """First game of the second half: a multiple of 32 (sub-range launches keep every game on its XCD), its first leaf row on a
-        feature-tile boundary, chosen so that the two halves' persistent convolution grids need no more tile-times per CU than the
-        undivided batch (4096 games x 8 leaves at 9x9: 5376 = 21 x 256 tiles + 5547 <= 22 x 256 tiles, against 43 x 256 undivided)."""
-        e = self.engine
-        tb = max(1, 256 // (e.N * e.N))
-        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        best = None
-        for gA in range(32, e.G, 32):
-            if (gA * e.P) % tb:
-                continue
-            tA, tB = gA * e.P // tb, -(-((e.G - gA) * e.P) // tb)
-            key = (-(-tA // n_cu) + -(-tB // n_cu), abs(2 * gA - e.G))
-            if best is None or key < best[0]:
-                best = (key, gA)
-        return None if best is None else best[1]
-
-    def _on_engine_launch(self, cur):
-        """Engine.on_launch: anything that reaches the engine from a stream other than the two half-batch streams (harvest, counters,
-        status, env_step, a serial round ...) first waits for both of them."""
-        if self._forked and all(cur.cuda_stream != s.cuda_stream for s in self._streams):
-            for s in self._streams:
-                cur.wait_stream(s)
-            self._forked = False
-
-    def _forward_half(self, k):
-        e = self.engine
-        g0, g1 = self._halves[k]
-        r0, r1 = g0 * e.P, g1 * e.P
-        tb = max(1, 256 // (e.N * e.N))
-        feat = e.features[(r0 // tb) * (32 * tb * e.N * e.N):]  # [tile][4 chunks][tb N^2 positions][8 channels]
-        self.infer.forward_tiled(feat, r1 - r0, e.N, e.priors[r0:r1], e.values[r0:r1], slot=1 + k)
-
-    def _capture_half(self, k):
-        for _ in range(2):
-            self._forward_half(k)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self._streams[k]):
-            self._forward_half(k)
-        self._hgraphs[k] = g
-
-    def _run_round_overlap(self):
-        e = self.engine
-        if not self._forked:
-            main = torch.cuda.current_stream(self.device)
-            for s in self._streams:
-                s.wait_stream(main)
-            self._forked = True
-        for k, (g0, g1) in enumerate(self._halves):
-            with torch.cuda.stream(self._streams[k]):
-                e.expand_backup(g0, g1)
-                e.select(g0, g1)
-                if self.use_graph:
-                    if self._hgraphs[k] is None:
-                        self._capture_half(k)
-                    self._hgraphs[k].replay()
-                else:
-                    self._forward_half(k)
-        self.rounds += 1
-
-    def join(self):
-        """Make the current stream wait for both half-batch streams (no-op when nothing is in flight there)."""
-        if self._streams is not None:
-            self._on_engine_launch(torch.cuda.current_stream(self.device))
 
     # -- weights ---------------------------------------------------------------------------------------
     def set_network(self, network: AlphaZeroNet, training_steps=0):
         """Checkpoint hot-swap (pipeline.py:232-239): new weights take effect at the next round."""
-        if self._streams is not None:  # nothing may still be reading the old weights
-            self.join()
-            torch.cuda.synchronize(self.device)
         self.infer = InferenceNet(network, dtype=self.net_dtype, binding=self.binding if self.device.type == "cuda" else None).to(self.device)
         self.training_steps = training_steps
         self.engine.set_actor_state(self.resign_threshold, training_steps)  # games that start from now on carry this tag
         self._graph = None
-        self._hgraphs = [None, None]
 
     def set_resign_threshold(self, resign_threshold):
         """var_resign_threshold as the reference actor reads it before EVERY game (pipeline.py:241-242): games that start after this
@@ -222,10 +134,7 @@ class SelfPlayActor:
 
     # -- rounds ----------------------------------------------------------------------------------------
     def run_round(self, evs=None):
-        """evs: optional 4 torch.cuda.Events recorded around (expand/backup + end-of-move), select, forward -- only meaningful in the
-        serial mode (self.overlap False); with the two half-batch streams the kernels of the halves interleave."""
-        if self.overlap:
-            return self._run_round_overlap()
+        """evs: optional 4 torch.cuda.Events recorded around (expand/backup + end-of-move), select, forward."""
         e = self.engine
         if evs is not None:
             evs[0].record()

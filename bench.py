@@ -78,7 +78,6 @@ def parse_args(argv=None):
     ap.add_argument("--filters", type=int, default=128)
     ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="serial rounds on one stream instead of two half-batch streams (SelfPlayActor overlap_engine)")
     ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
     ap.add_argument("--preroll-rounds", type=int, default=300, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
     ap.add_argument("--preroll-moves", type=int, default=2, help="every slot must have committed this many searched moves before timing")
@@ -200,8 +199,7 @@ def timed(act, args, world, dev, warmup, steps):
     barrier(world, dev)
     harvest_and_gather(act)
     act.counters(reset=True)
-    serial = dev.type == "cuda" and not getattr(act, "overlap", False)  # per-kernel events only mean something in the serial mode
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if serial else [None] * steps
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)] if dev.type == "cuda" else [None] * steps
     gathered = 0
     barrier(world, dev)
     del HG_MS[:]
@@ -294,8 +292,7 @@ def main(argv=None):
         """Engine + evaluator in the steady state: staggered openings, then the argument-independent pre-roll."""
         act = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
                             warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=DT[dtype_name],
-                            use_graph=not args.no_graph, engine_kw=None if reuse_tree else {"reuse_tree": False},
-                            overlap_engine=False if args.no_overlap else None)
+                            use_graph=not args.no_graph, engine_kw=None if reuse_tree else {"reuse_tree": False})
         e = act.engine
         if args.stagger > 0:  # mixed game phases from the first round (documented in DESIGN.md "Measurement")
             rng = np.random.Generator(np.random.PCG64(1234 + rank))
@@ -312,17 +309,6 @@ def main(argv=None):
     eng = actor.engine
     preroll_rounds = preroll(actor, args, world, dev)
     elapsed, cnt, evs, samples_at_root = timed(actor, args, world, dev, args.warmup, args.steps)
-    overlapped = bool(getattr(actor, "overlap", False))
-    if overlapped:
-        # two half-batch streams: the kernels of the halves interleave, so the per-kernel durations come from a short SERIAL pass
-        # (whole batch, one stream) after the timed region; `value` / `ms_per_step` are from the overlapped timed region above
-        actor.overlap = False
-        actor.run_rounds(3)
-        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(20)]
-        for ev4 in evs:
-            actor.run_round(ev4)
-        torch.cuda.synchronize(dev)
-        actor.overlap = True
     bk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # expand/backup + end-of-move kernels
     k_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))   # select kernel (the dominant hand-written kernel)
     nn_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
@@ -371,7 +357,6 @@ def main(argv=None):
                 "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2]))}
 
     if args.split_round and rank == 0:
-        actor.overlap = False
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ta = tb = 0.0
         for _ in range(20):
@@ -385,7 +370,6 @@ def main(argv=None):
             ta += ea[0].elapsed_time(ea[1]) / 20
             tb += ea[1].elapsed_time(ea[2]) / 20
         print(json.dumps({"split_round_ms": {"expand_backup_endmove": round(ta, 4), "select_features": round(tb, 4)}}), flush=True)
-        actor.overlap = overlapped
     if rank == 0:
         # ---- roofline of the dominant hand-written kernel: the fused round kernel (HBM bound) ----------
         e_bytes = {"bf16": 2, "fp16": 2, "fp32": 4}[args.net_dtype]
@@ -534,10 +518,7 @@ def main(argv=None):
             "backup_nodes_per_sim": round(cnt["backup_edges"] / max(1, cnt["sims"]), 3),
             "select_hint_prefetches_per_sim": round(cnt.get("hint_prefetches", 0) / max(1, cnt["sims"]), 3),
             "select_hint_hit_rate": round(cnt.get("hint_hits", 0) / max(1, cnt.get("hint_prefetches", 0)), 3),
-            "overlap": {"engine_behind_forward": overlapped, "halves": getattr(actor, "_halves", None),
-                        "serial_step_ms": round(bk_ms + k_ms + nn_ms, 3), "hidden_ms_per_step": round(bk_ms + k_ms + nn_ms - elapsed_max / steps * 1e3, 3),
-                        "note": "per-kernel durations (roofline, engine_roofline, nn_roofline) are measured in a serial pass after the timed region"
-                        if overlapped else "serial rounds"},
+            "serial_step_ms": round(bk_ms + k_ms + nn_ms, 3),
             "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds, "per_rank": ranks,
             "dup_leaf_rate": round(cnt["dup_leaves"] / max(1, cnt["leaves"]), 5), "terminal_hit_rate": round(cnt["terminal_hits"] / max(1, cnt["sims"]), 5),
             "fp32_moves_per_s": fp32["moves_per_s"] if fp32 else None, "fp32_companion": fp32,

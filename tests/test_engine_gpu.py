@@ -293,11 +293,11 @@ def test_gpu_sgf_text_matches_reference(golden_dir, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("game,n,filters", [("go", 9, 128), ("gomoku", 13, 64)])
-def test_gpu_two_half_batch_streams_equal_serial_rounds(game, n, filters):
-    """SelfPlayActor(overlap_engine=True) -- two half-batches on two streams, engine kernels of one half behind the other half's
-    forward (azsp_select_range / azsp_expand_backup_range) -- produces exactly the games of the serial actor: same production
-    randomness (Philox keyed by seed, slot, game, ply), same evaluations (a row's evaluation is batch independent), so every harvested
-    sample, game record and counter is bit-identical.  Games never interact inside a search (mcts_v2.py:568-625 runs per game)."""
+def test_gpu_game_range_rounds_and_half_batch_forwards_equal_whole_batch_rounds(game, n, filters):
+    """azsp_select_range / azsp_expand_backup_range + the evaluator on tile-aligned sub-batches: rounds run as two disjoint game ranges
+    one after the other (each with its own half-batch forward) produce exactly the games of whole-batch rounds: same production
+    randomness (Philox keyed by seed, slot, game, ply), same evaluations (a row's evaluation does not depend on the batch), so every
+    harvested sample, game record and counter is bit-identical.  Games never interact inside a search (mcts_v2.py:568-625 runs per game)."""
     import numpy as np
     import torch
     from alpha_zero_amd.core.network import AlphaZeroNet
@@ -306,17 +306,27 @@ def test_gpu_two_half_batch_streams_equal_serial_rounds(game, n, filters):
     A = n * n + (1 if game == "go" else 0)
     torch.manual_seed(4)
     net = AlphaZeroNet((17, n, n), A, 2, filters, 64, gomoku=(game != "go"))
+    G, P = 1184, 8
+    tb = max(1, 256 // (n * n))
+    g_split = 576  # a multiple of 32 games whose first leaf row (576 * 8) starts a feature tile (a multiple of 3 boards at 9x9)
+    assert g_split % 32 == 0 and (g_split * P) % tb == 0
     out = []
-    for overlap in (False, True):
-        act = SelfPlayActor(net, game=game, board_size=n, num_games=1184, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0,
-                            seed=7, device="cuda", overlap_engine=overlap, engine_kw={"max_steps": 24})
-        assert act.overlap == overlap
-        if overlap:
-            g0 = act._halves[0][1]
-            assert g0 % 32 == 0 and (g0 * 8) % max(1, 256 // (n * n)) == 0 and 0 < g0 < 1184
+    for split in (False, True):
+        act = SelfPlayActor(net, game=game, board_size=n, num_games=G, num_simulations=24, num_parallel=P, warm_up_steps=4, resign_threshold=-1.0,
+                            seed=7, device="cuda", use_graph=False, engine_kw={"max_steps": 24})
+        e = act.engine
         games_by_uid = {}
         for _ in range(6):
-            act.run_rounds(40)
+            for _ in range(40):
+                if not split:
+                    act.run_round()
+                    continue
+                for k, (g0, g1) in enumerate(((g_split, G), (0, g_split))):  # second half first: the order must not matter
+                    e.expand_backup(g0, g1)
+                    e.select(g0, g1)
+                    r0, r1 = g0 * P, g1 * P
+                    feat = e.features[(r0 // tb) * (32 * tb * n * n):]
+                    act.infer.forward_tiled(feat, r1 - r0, n, e.priors[r0:r1], e.values[r0:r1], slot=1 + k)
             st, pi, z, games = act.harvest_tensors(clone=True)
             st, pi, z = st.cpu(), pi.cpu(), z.cpu()
             for row in games:  # the harvest kernel hands out output rows first come first served: key the games by their uid
@@ -326,7 +336,7 @@ def test_gpu_two_half_batch_streams_equal_serial_rounds(game, n, filters):
         out.append((games_by_uid, act.counters()))
         del act
     (ga, c0), (gb, c1) = out
-    assert len(ga) > 300 and sum(v[0].shape[0] for v in ga.values()) > 5000 and ga.keys() == gb.keys()
+    assert len(ga) >= 250 and sum(v[0].shape[0] for v in ga.values()) > 5000 and ga.keys() == gb.keys()
     for uid, (s0, p0, z0, r0) in ga.items():
         s1, p1, z1, r1 = gb[uid]
         assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(r0, r1), uid

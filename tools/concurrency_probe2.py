@@ -1,0 +1,70 @@
+"""Follow-up of tools/overlap_debug.py: inside the actor flow, two half-batch forwards launched together on two streams give priors
+that differ in a few rows from the same forwards run one after the other (tools/concurrency_probe.py, which runs two forwards on
+separately allocated inputs, sees no difference).  Here: rounds of the real actor; after the engine kernels of a round the two half
+forwards run (a) concurrently and then (b) serially on the SAME features, with the stem output, the tower output, the head planes
+and the priors of both captured; reports the first stage that differs."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from alpha_zero_amd.core.network import AlphaZeroNet  # noqa: E402
+from overlap_actor import OverlapActor  # noqa: E402
+
+torch.manual_seed(4)
+net = AlphaZeroNet((17, 9, 9), 82, 2, 128, 64)
+act = OverlapActor(net, game="go", board_size=9, num_games=1184, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0, seed=7,
+                   device="cuda", overlap=True, use_graph=False, engine_kw={"max_steps": 24})
+act.engine.on_launch = None
+e, inf = act.engine, act.infer
+captured = {}
+orig_blocks = inf._blocks_tiled
+
+
+def blocks(a, m, o, B, S, C, st):
+    captured[("stem", B)] = a.clone()
+    out = orig_blocks(a, m, o, B, S, C, st)
+    captured[("tower", B)] = out.clone()
+    return out
+
+
+inf._blocks_tiled = blocks
+
+
+def snapshot(k):
+    g0, g1 = act._halves[k]
+    B = (g1 - g0) * e.P
+    pol, val, _, _ = inf._head_buffers(B, inf.fc_wp.shape[1], inf.fc_w1.shape[1], e.features.device, 1 + k)
+    return {"stem": captured[("stem", B)], "tower": captured[("tower", B)], "pol": pol.clone(), "val": val.clone(),
+            "pri": e.priors[g0 * e.P:g1 * e.P].clone(), "v": e.values[g0 * e.P:g1 * e.P].clone()}
+
+
+main = torch.cuda.current_stream()
+found = {}
+for r in range(40):
+    for g0, g1 in act._halves:
+        e.expand_backup(g0, g1)
+        e.select(g0, g1)
+    for k in range(2):
+        act._streams[k].wait_stream(main)
+        with torch.cuda.stream(act._streams[k]):
+            act._forward_half(k)
+    for s in act._streams:
+        main.wait_stream(s)
+    torch.cuda.synchronize()
+    conc = [snapshot(k) for k in range(2)]
+    ser = []
+    for k in range(2):
+        act._forward_half(k)
+        torch.cuda.synchronize()
+        ser.append(snapshot(k))
+    for k in range(2):
+        for name in ("stem", "tower", "pol", "val", "pri", "v"):
+            if not torch.equal(conc[k][name], ser[k][name]):
+                d = (conc[k][name].float() - ser[k][name].float()).abs()
+                nz = torch.nonzero(d.flatten() > 0).flatten()
+                found.setdefault((k, name), []).append((r, int(nz.numel()), nz[:8].tolist(), float(d.max())))
+                break
+print("first differing stage per (half, stage) over 40 rounds:", {k: (len(v), v[:3]) for k, v in found.items()} or "none", flush=True)

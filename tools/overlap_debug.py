@@ -7,8 +7,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from alpha_zero_amd.core.network import AlphaZeroNet  # noqa: E402
-from alpha_zero_amd.core.pipeline import SelfPlayActor  # noqa: E402
+from overlap_actor import OverlapActor  # noqa: E402  (tools/overlap_actor.py: the two-stream experiment)
 
 game, n, filters = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("go", 9, 128)
 A = n * n + (1 if game == "go" else 0)
@@ -18,11 +19,9 @@ net = AlphaZeroNet((17, n, n), A, 2, filters, 64, gomoku=(game != "go"))
 
 def make(mode):
     ov = mode.startswith("overlap")
-    act = SelfPlayActor(net, game=game, board_size=n, num_games=1184, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0,
-                        seed=7, device="cuda", overlap_engine=ov, use_graph="nograph" not in mode, engine_kw={"max_steps": 24})
-    if mode.startswith("overlap1"):
-        act._streams = [act._streams[0], act._streams[0]]
-    return act
+    return OverlapActor(net, game=game, board_size=n, num_games=1184, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0,
+                        seed=7, device="cuda", overlap=ov, one_stream=mode.startswith("overlap1"), use_graph="nograph" not in mode,
+                        engine_kw={"max_steps": 24})
 
 
 def round_engine2(act):
