@@ -14,7 +14,7 @@
 // stream run on CUs of the same XCD (one HBM read, one L2 hit).  The price is one extra bf16 rounding of the partial sum and
 // its HBM round trip (5 tensor passes per convolution instead of 3).
 //   * tile = HALF a board: output rows r0 .. r0 + 9 with r0 = 0 or 9 (row 9 is computed by both halves and stored by the first
-//     only), 190 positions = 6 column tiles of 32 = 2 units of 3; v_mfma_f32_32x32x16_bf16, 72 k-steps per column tile.
+//     only), 190 positions = 6 column tiles of 32 = 6 units; v_mfma_f32_32x32x16_bf16, 72 k-steps per column tile.
 //   * LDS image per 8-channel chunk: 242 cells of 16 B, cell(rs, x) = 1 + 20 rs + x for the 12 input rows rs (r0 - 1 .. r0 + 10)
 //     with one zero cell between rows; rows outside the board are never written (zero).  A tap (dy, dx) is the constant cell offset
 //     20 dy + dx.  Double buffered (2 x 61,952 B), filled by LDS-DMA: wave q moves cells [64 q, 64 q + 64) of every chunk strip.
@@ -22,7 +22,11 @@
 //   * (column tile, lane) -> position from a residue-class table as in az_conv.h; six of the sixteen classes have 13 members for
 //     12 lane groups, so 6 of the 190 positions sit in a group that already holds their residue (a 2-way conflict on 6 of 192
 //     lanes); unused slots repeat a cell and are never stored.
-//   * epilogue straight from the accumulators, 8-byte slots, bias as the C operand of the first MFMA.
+//   * epilogue straight from the accumulators, 8-byte slots; SOFTWARE-PIPELINED (round 3): a unit is ONE column tile (72 MFMAs that
+//     accumulate into the same 16 registers back to back), two accumulator sets, the epilogue of unit u - 1 (addend add, bf16
+//     rounding, ReLU, stores) is issued one instruction per MFMA gap inside unit u, the B-fragment ring runs on across units and
+//     tiles, one barrier per tile behind a counted vmcnt, bias from LDS.  Round 2 ran the epilogue as one serial block after every
+//     three column tiles (the two-column-tile units of az_conv.h would need three sets here or spill: 6 tiles = 3 units is odd).
 #pragma once
 #include "az_conv.h"
 
@@ -93,13 +97,46 @@ static __device__ const C9Map c9_map = c9_make_map();
 // launch: 16 (one half of the tower's 256 channels) or 4 (the stem: 17 planes padded to 32).  cin_total = row length of w_packed
 // [9 taps][256 couts][cin_total], cin_off = first input channel of this launch, x_chunks = chunks per board of x, x_chunk0 = first
 // chunk read.  The output always has 32 chunks (256 couts).
+template <bool ADD, int NCH> struct C9Sched {  // static schedule of one unit = one column tile: everything compile-time
+    static constexpr int KS = NCH / 2, NSTEP = 9 * KS, NS = NSTEP;      // k-steps = MFMA slots per unit
+    static constexpr int NU = C9_NCT;                                    // units per tile
+    static constexpr int R = 4;                                          // B-fragment ring slots
+    static constexpr int OPS = ADD ? 9 : 5, NQ = 4;                      // micro-ops per epilogue quad, quads (register quads) per unit
+    static constexpr int S0 = 5;                                         // first slot that may touch the previous unit's accumulators
+    static constexpr int PER = (NQ * OPS + (NS - S0 - 3) - 1) / (NS - S0 - 3);  // epilogue micro-ops per slot
+    static constexpr int NPIECE = NCH;                                   // DMA pieces per wave per tile: unit 0, k-step 1 + 4 p
+    static constexpr int T_BAR = NSTEP - (R - 1);                        // last unit: barrier before the ring crosses into the next tile
+    // this unit's addend of quad q is loaded right behind the store micro-op of the previous unit's quad q (which consumed the same
+    // registers a few micro-ops earlier): one addend set of 8 registers
+    static constexpr int store_slot(int q) { return S0 + (q * OPS + OPS - 1) / PER; }
+    static constexpr int dma_slot(int p) { return 1 + 4 * p; }
+    // vector-memory operations issued after the last DMA piece (unit 0) and before the barrier (last unit, slot T_BAR), in program order
+    static constexpr int vm_after_dma() {
+        int n = 0;
+        const int last = dma_slot(NPIECE - 1);
+        for (int u = 0; u < NU; ++u)
+            for (int q = 0; q < NQ; ++q) {
+                const int ss = store_slot(q);
+                if ((u > 0 || ss > last) && (u < NU - 1 || ss < T_BAR)) n += ADD ? 2 : 1;  // store of the previous unit's quad (+ this unit's addend load)
+            }
+        return n;
+    }
+    static_assert(NQ * OPS <= PER * (NS - S0 - 3), "the previous unit's epilogue must fit into the unit, before its set is re-initialised");
+    static_assert(dma_slot(NPIECE - 1) < NSTEP, "DMA pieces ride in unit 0");
+    static_assert((NU * NSTEP) % R == 0, "a tile's k-steps keep the ring phase");
+    static_assert(store_slot(NQ - 1) < T_BAR, "no vector-memory rider between the barrier and the end of the last unit (counted wait)");
+};
+
 template <bool ADD, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias, const unsigned char* add,
                unsigned char* y, int nboards, int relu, int add_bias, int cin_total, int cin_off, int x_chunks, int x_chunk0) {
-    constexpr int KS = NCH / 2, NSTEP = 9 * KS;
+    typedef C9Sched<ADD, NCH> SC;
+    constexpr int KS = SC::KS, NSTEP = SC::NSTEP, R = SC::R, NU = SC::NU;
     constexpr int LBUF = NCH * C9_LBLK;
-    constexpr int NPIECE = NCH;  // DMA pieces per wave per tile: its 64-cell quarter of every chunk strip
+    constexpr int NPIECE = SC::NPIECE;  // DMA pieces per wave per tile: its 64-cell quarter of every chunk strip
     constexpr int OTILE = 32 * C9_GBLK;  // output / addend board: 256 channels
+    constexpr int VM_AFTER_DMA = SC::vm_after_dma();
+    static_assert(VM_AFTER_DMA < 63, "vmcnt field");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,11 +163,11 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t)
         wf[t] = *(const cv_bf16x8*)(w + ((size_t)((t / KS) * 256 + cout0 + l31)) * cin_total + cin_off + ((t % KS) * 2 + hi) * 8);
-    cv_f32x16 bv;
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[rq * 4 + e] = add_bias ? bias[cout0 + 8 * rq + 4 * hi + e] : 0.0f;
+    // bias in the accumulator layout, kept in LDS ([wave][lane half][16 floats], broadcast reads): a unit's accumulators are initialised
+    // from it a few k-steps before the unit starts, which frees the 16 registers a C operand would pin (as in az_conv.h)
+    __shared__ __attribute__((aligned(64))) float bias_lds[4 * 2 * 16];
+    if (lane < 32) bias_lds[(wave * 2 + (lane >> 4)) * 16 + (lane & 15)] = add_bias ? bias[cout0 + 8 * ((lane & 15) >> 2) + 4 * (lane >> 4) + (lane & 3)] : 0.0f;
+    const cv_f32x16* bias_ptr = (const cv_f32x16*)(bias_lds + (wave * 2 + hi) * 16);
     const unsigned lo16 = relu ? 0u : 0x80008000u;
 
     // LDS-DMA: this wave's lane -> cell 64 wave + lane of a chunk strip; source = that cell's board position (rows outside the board
@@ -159,13 +196,19 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
         if (tp != 0xffffu && !(hf == 1 && tp < (unsigned)C9_S)) gp = tp + (unsigned)(r0 * C9_S);
         lmap[ct] = (unsigned)((c9_map.cell[ct * 32 + l31] - C9_CELL0) * 16 + hi * C9_LBLK) | (gp << 16);
     }
-
-    cv_bf16x8 bb[4][3];  // ring of B fragments: k-step s lives in slot s & 3
-    auto load_step = [&](const unsigned char* const (&bp)[3], int st) {
-        const int tap = st / KS, ks = st % KS;
-        const int off = ((tap / 3) * C9_PITCH + (tap % 3)) * 16 + ks * (2 * C9_LBLK);
+    unsigned long long smask[C9_NCT];  // lanes of a column tile that store their result
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bb[st & 3][j] = *(const cv_bf16x8*)(bp[j] + off);
+    for (int ct = 0; ct < C9_NCT; ++ct) smask[ct] = __builtin_amdgcn_ballot_w64((lmap[ct] >> 16) != 0xffffu);
+    // 8-byte store under a lane mask, no branch: the instruction is always issued (the counted vmcnt below relies on it)
+    auto store8 = [&](unsigned char* base, unsigned voff, unsigned a, unsigned b2, unsigned long long mask) {
+        const cv_u32x2 d = (cv_u32x2){a, b2};
+        asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" : : "s"(mask), "v"(voff), "v"(d), "s"(base) : "memory");
+    };
+
+    cv_bf16x8 bb[R];  // ring of B fragments: k-step t of unit u lives in slot (u NSTEP + t) % R
+    auto load_step = [&](const unsigned char* p0, int st, int slot) {
+        const int tap = st / KS, ks = st % KS;
+        bb[slot] = *(const cv_bf16x8*)(p0 + ((tap / 3) * C9_PITCH + (tap % 3)) * 16 + ks * (2 * C9_LBLK));
     };
 
     if (s < nboards) {  // first tile: all pieces at once
@@ -175,13 +218,46 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CV_BARRIER();
-    {
-        const unsigned char* bp0[3] = {lds + (lmap[0] & 0xffffu), lds + (lmap[1] & 0xffffu), lds + (lmap[2] & 0xffffu)};
-        load_step(bp0, 0);
-        load_step(bp0, 1);
-        load_step(bp0, 2);
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st) load_step(lds + (lmap[0] & 0xffffu), st, st);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {  // the compiler's wait for the weight loads belongs in front of the loop (see az_conv.h)
+        if (t < 64) asm volatile("" : : "a"(wf[t]));
+        else asm volatile("" : : "v"(wf[t]));
     }
+
+    cv_f32x16 acc[2];   // [accumulator set = unit parity]
+    cv_u32x2 rr[4];     // addend of the unit whose epilogue comes next: [register quad]
+    acc[0] = *bias_ptr;  // (bias_lds was published by the barrier above)
+    acc[1] = *bias_ptr;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) rr[rq] = (cv_u32x2){0u, 0u};
+    float ev[4];
+    unsigned epa = 0, epb = 0;
+    // one epilogue micro-op of register quad rq of the unit that computed column tile ct
+    auto epi_op = [&](int set, int ct, unsigned char* out, int rq, int op, bool store_ok) {
+        if (ADD) {
+            if (op == 0) ev[0] = cw_add_f32(acc[set][rq * 4 + 0], cv_bf16_lo(rr[rq].x));
+            else if (op == 1) ev[1] = cw_add_f32(acc[set][rq * 4 + 1], cv_bf16_hi(rr[rq].x));
+            else if (op == 2) ev[2] = cw_add_f32(acc[set][rq * 4 + 2], cv_bf16_lo(rr[rq].y));
+            else if (op == 3) ev[3] = cw_add_f32(acc[set][rq * 4 + 3], cv_bf16_hi(rr[rq].y));
+            else if (op == 4) epa = cw_pk_bf16(ev[0], ev[1]);
+            else if (op == 5) epb = cw_pk_bf16(ev[2], ev[3]);
+        } else {
+            if (op == 0) epa = cw_pk_bf16(acc[set][rq * 4 + 0], acc[set][rq * 4 + 1]);
+            else if (op == 1) epb = cw_pk_bf16(acc[set][rq * 4 + 2], acc[set][rq * 4 + 3]);
+        }
+        if (op == SC::OPS - 3) epa = cw_pk_max_i16(epa, lo16);
+        else if (op == SC::OPS - 2) epb = cw_pk_max_i16(epb, lo16);
+        else if (op == SC::OPS - 1) {
+            unsigned lm = lmap[ct];
+            asm volatile("" : "+v"(lm));  // recompute the offset here (two VALU in an MFMA gap) instead of hoisting 24 of them out of the loop
+            store8(out, (unsigned)(rq * C9_GBLK) + (lm >> 16) * 16u + (unsigned)(hi * 8), epa, epb, store_ok ? smask[ct] : 0ull);
+        }
+    };
+
     int it = 0;
+    unsigned char* yprev = y;  // output base of the previous tile (the epilogue of its last unit runs inside this tile's unit 0)
     for (int board = s; board < nboards; board += nst, ++it) {
         const int buf = it & 1;
         const unsigned char* Xs = lds + buf * LBUF;
@@ -192,69 +268,55 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
         const size_t obase = (size_t)board * OTILE + (size_t)(ch * 16 + wave * 4) * C9_GBLK;
         const unsigned char* abase = ADD ? add + obase : nullptr;
         unsigned char* ybase = y + obase;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const unsigned char* bp[3];
-            cv_u32x2 rr[3][4];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const unsigned mj = lmap[u * 3 + j];
-                bp[j] = Xs + (mj & 0xffffu);
-                if (ADD) {
-                    const unsigned gp = mj >> 16, gq = (gp == 0xffffu ? 0u : gp) * 16u + (unsigned)(hi * 8);
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) rr[j][rq] = *(const cv_u32x2*)(abase + rq * C9_GBLK + gq);
+        const bool have_prev = it > 0;
+        cp_for_each([&](auto UC) __attribute__((always_inline)) {
+            constexpr int u = decltype(UC)::value, set = u & 1, pset = set ^ 1;
+            constexpr int pct = (u + NU - 1) % NU;  // the previous unit's column tile
+            unsigned char* pout = u == 0 ? yprev : ybase;
+            const bool pstore = u > 0 || have_prev;
+            const unsigned char* b0 = Xs + (lmap[u] & 0xffffu);
+            const unsigned char* nb0 = (u < NU - 1 ? Xs : Xn) + (lmap[(u + 1) % NU] & 0xffffu);
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::value;
+                if constexpr (u == NU - 1 && t == SC::T_BAR) {
+                    // every read of this buffer has been issued (the ring runs R - 1 k-steps ahead); all DMA pieces of the next tile are
+                    // older than the VM_AFTER_DMA youngest vector-memory operations of this wave
+                    if (have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_AFTER_DMA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: its unit-0 epilogue stores were skipped
+                    CV_BARRIER();
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cv_f32x16 acc[3];
+                if constexpr (t + R - 1 < NSTEP) load_step(b0, t + R - 1, (u * NSTEP + t + R - 1) % R);
+                else load_step(nb0, t + R - 1 - NSTEP, (u * NSTEP + t + R - 1) % R);
+                if constexpr (t < 64) cw_mfma_a(acc[set], wf[t], bb[(u * NSTEP + t) % R]);
+                else cw_mfma_v(acc[set], wf[t], bb[(u * NSTEP + t) % R]);
+                // ---- riders of this MFMA gap -----------------------------------------------------------------------------------
 #pragma unroll
-            for (int t = 0; t < NSTEP; ++t) {  // fragments of steps 0..2 are already in flight
-                if (t + 3 < NSTEP) load_step(bp, t + 3);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    if (t == 0) cw_mfma_ac(acc[j], wf[0], bb[0][j], bv);
-                    else if (t < 64) cw_mfma_a(acc[j], wf[t], bb[t & 3][j]);
-                    else cw_mfma_v(acc[j], wf[t], bb[t & 3][j]);
+                for (int k = 0; k < SC::PER; ++k) {  // the previous unit's epilogue, PER micro-ops per gap
+                    const int o = (t - SC::S0) * SC::PER + k;
+                    if (t >= SC::S0 && o < SC::NQ * SC::OPS) epi_op(pset, pct, pout, o / SC::OPS, o % SC::OPS, pstore);
                 }
-                // the next tile's DMA pieces ride in the shadow of unit 0's MFMAs (its buffer was released by the previous barrier)
-                if (u == 0 && t % 3 == 1 && t / 3 < NPIECE) dma_piece(nsrc, ndst, has_next, t / 3);
+                if constexpr (ADD) {  // this unit's addend of quad q, right behind the store of the previous unit's quad q
+#pragma unroll
+                    for (int q = 0; q < SC::NQ; ++q)
+                        if (t == SC::store_slot(q)) {
+                            unsigned lm = lmap[u];
+                            asm volatile("" : "+v"(lm));  // (not hoisted, see epi_op)
+                            const unsigned gp = lm >> 16;
+                            rr[q] = *(const cv_u32x2*)(abase + q * C9_GBLK + ((gp == 0xffffu ? 0u : gp) * 16u + (unsigned)(hi * 8)));
+                        }
+                }
+                if constexpr (u == 0 && t % 4 == 1 && t / 4 < NPIECE) dma_piece(nsrc, ndst, has_next, t / 4);
+                if constexpr (t == NSTEP - 2) acc[pset] = *bias_ptr;  // the next unit's accumulators start from the bias (its epilogue riders are long done)
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (u == 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                CV_BARRIER();
-            }
-            {   // the next unit's first fragments fly while the epilogue below runs
-                const unsigned char* bpn[3];
+            }, typename CpMakeSeq<NSTEP>::type{});
+        }, typename CpMakeSeq<NU>::type{});
+        yprev = ybase;
+    }
+    // epilogue of the very last unit: column tile NU - 1, accumulator set (NU - 1) & 1
+    if (it > 0) {
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
 #pragma unroll
-                for (int j = 0; j < 3; ++j) bpn[j] = (u == 0 ? Xs : Xn) + (lmap[(1 - u) * 3 + j] & 0xffffu);
-                load_step(bpn, 0);
-                load_step(bpn, 1);
-                load_step(bpn, 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const unsigned gp = lmap[u * 3 + j] >> 16;
-                const unsigned gq = (gp == 0xffffu ? 0u : gp) * 16u + (unsigned)(hi * 8);
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    float v0 = acc[j][rq * 4 + 0], v1 = acc[j][rq * 4 + 1], v2 = acc[j][rq * 4 + 2], v3 = acc[j][rq * 4 + 3];
-                    if (ADD) {
-                        const cv_u32x2 r2 = rr[j][rq];
-                        v0 += cv_bf16_lo(r2.x);
-                        v1 += cv_bf16_hi(r2.x);
-                        v2 += cv_bf16_lo(r2.y);
-                        v3 += cv_bf16_hi(r2.y);
-                    }
-                    const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(v0, v1), lo16), cw_pk_max_i16(cw_pk_bf16(v2, v3), lo16)};
-                    if (gp != 0xffffu) *(cv_u32x2*)(ybase + rq * C9_GBLK + gq) = o;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int o = 0; o < SC::NQ * SC::OPS; ++o) epi_op((NU - 1) & 1, NU - 1, yprev, o / SC::OPS, o % SC::OPS, true);
     }
 }
 #endif  // __HIPCC__

@@ -97,38 +97,6 @@ template <int W> struct GameRec {
     uint8_t leaf_depth[AZ_MAXP];
 };
 
-#if !defined(AZ_HOST_TWIN_POLICIES)  // (the CPU test twin brings its own plain-C++ AzAtomic)
-struct AzAtomic {  // device-scope atomics of the harvest reservation; the host pass of hipcc only needs the symbols
-    static AZ_D void add(u64* p, u64 v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        atomicAdd((unsigned long long*)p, (unsigned long long)v);
-#else
-        (void)p, (void)v, __builtin_trap();
-#endif
-    }
-    static AZ_D int fetch_add_i32(int* p, int v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return atomicAdd(p, v);
-#else
-        return (void)p, (void)v, __builtin_trap(), 0;
-#endif
-    }
-    static AZ_D u64 cas_u64(u64* p, u64 expect, u64 desired) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)desired);
-#else
-        return (void)p, (void)expect, (void)desired, __builtin_trap(), 0;
-#endif
-    }
-    static AZ_D u64 load_u64(u64* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return __hip_atomic_load((unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        return (void)p, __builtin_trap(), 0;
-#endif
-    }
-};
-#endif
 
 // Philox4x32-10 counter-based generator (production randomness: one independent stream per
 // (seed, rank, game slot, game uid, ply, purpose, lane); replaces the actor's global np.random state).

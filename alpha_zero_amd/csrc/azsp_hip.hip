@@ -37,6 +37,38 @@ __global__ void __launch_bounds__(256) k_bias_act(const BiasActArgs a) {
         az_bias_act_vec(a, i);
 }
 
+// One workgroup: thread t owns a contiguous run of the rotated buffer order, the runs' totals are scanned in LDS.
+__global__ void __launch_bounds__(1024) k_harvest_scan(const int* __restrict__ len, int* __restrict__ ofs, int* __restrict__ counts, int n2, int rot,
+                                                        int cap, int max_games) {
+    __shared__ int ss[1024], sg[1024], best[2];
+    const int t = (int)threadIdx.x, per = (n2 + 1023) / 1024, lo = t * per < n2 ? t * per : n2, hi = lo + per < n2 ? lo + per : n2;
+    int s = 0, g = 0;
+    for (int i = lo; i < hi; ++i) {
+        const int l = len[(i + rot) % n2];
+        s += l;
+        g += l > 0;
+    }
+    ss[t] = s;
+    sg[t] = g;
+    if (t < 2) best[t] = 0;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan of the run totals
+        const int a = t >= d ? ss[t - d] : 0, b = t >= d ? sg[t - d] : 0;
+        __syncthreads();
+        ss[t] += a;
+        sg[t] += b;
+        __syncthreads();
+    }
+    int mine[2] = {0, 0};
+    az_harvest_scan_range(len, ofs, n2, rot, cap, max_games, lo, hi, ss[t] - s, sg[t] - g, mine);
+    if (mine[1] > 0) {  // the buffers that fit form a prefix of the order: the furthest fitting end is the harvest's total
+        atomicMax(&best[0], mine[0]);
+        atomicMax(&best[1], mine[1]);
+    }
+    __syncthreads();
+    if (t < 2) counts[t] = best[t];
+}
+
 namespace azb {
 void* alloc(size_t n) {
     void* p = nullptr;
@@ -79,6 +111,10 @@ int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* st) {
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)st, a, total);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_harvest_scan(const int* len, int* ofs, int* counts, int n2, int rot, int cap, int max_games, void* st) {
+    hipLaunchKernelGGL(k_harvest_scan, dim3(1), dim3(1024), 0, (hipStream_t)st, len, ofs, counts, n2, rot, cap, max_games);
     return AZ_HIP(hipGetLastError());
 }
 int launch_bias_act(const BiasActArgs& a, void* st) {

@@ -216,6 +216,40 @@ struct OpEnvStep {
         E::Wave::sync();
     }
 };
+// Harvest = three launches, deterministic: (1) OpHarvestCount publishes the length of every COMPLETE staging buffer, (2) a scan
+// (az_harvest_scan_range) hands out output rows in buffer order starting from a slot that rotates from harvest to harvest -- the
+// buffers that fit the caller's capacity form a prefix of that order, the rest stay COMPLETE for the next call -- (3) OpHarvest copies.
+// Same seed and same call sequence => the same games in the same rows (round 2 reserved rows with a CAS race: correct, but which
+// games a full harvest kept back, and the row order, depended on the order the waves arrived).
+struct OpHarvestCount {
+    int* len;  // [G][2]
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (E::Wave::first())
+            for (int b = 0; b < 2; ++b) {
+                const int* sh = e.m.stg_hdr + ((size_t)e.g * 2 + b) * SH_COUNT;
+                len[(size_t)e.g * 2 + b] = sh[SH_STATE] == AZB_COMPLETE ? sh[SH_LEN] : 0;
+            }
+    }
+};
+// element i of the rotated order (i in [lo, hi)) with the exclusive prefix (ps samples, pg games) of everything before lo
+AZ_HD void az_harvest_scan_range(const int* len, int* ofs, int n2, int rot, int cap, int max_games, int lo, int hi, int ps, int pg, int* best) {
+    for (int i = lo; i < hi; ++i) {
+        const int idx = (i + rot) % n2, l = len[idx];
+        int st = -1, gi = -1;
+        if (l > 0) {
+            if (ps + l <= cap && pg < max_games) {  // (a buffer that does not fit keeps later ones out too: the prefix sums run on)
+                st = ps;
+                gi = pg;
+                best[0] = ps + l;
+                best[1] = pg + 1;
+            }
+            ps += l;
+            pg += 1;
+        }
+        ofs[2 * idx] = st;
+        ofs[2 * idx + 1] = gi;
+    }
+}
 struct OpHarvest {
     int8_t* states;
     float* pi;
@@ -223,7 +257,7 @@ struct OpHarvest {
     int cap;
     int* games;
     int max_games;
-    int* out_counts;  // [0] samples, [1] games
+    const int* ofs;   // [G][2][2] = (first output row, game index) of a staging buffer, -1 = not this time
     int16_t* moves;   // optional: the move played from every sample's position (azsp_harvest_moves)
     int* extra;       // [max_games][4] = {training_steps at game end, resign threshold double bits lo, hi, straddled a weight swap}
     template <class E> AZ_HD void operator()(E& e) const {
@@ -236,22 +270,8 @@ struct OpHarvest {
             const int len = sh[SH_LEN];
             int start = -1, gi = 0;
             if (E::Wave::first()) {
-                // all-or-nothing reservation of (samples, games) in ONE 64-bit word: no roll-back, so the
-                // output indices stay dense whatever the interleaving of the waves
-                u64* word = (u64*)out_counts;
-                u64 old = AzAtomic::load_u64(word);
-                for (;;) {
-                    const int ns = (int)(old & 0xffffffffu), ng = (int)(old >> 32);
-                    if (ns + len > cap || ng >= max_games) break;  // no room this time: keep the buffer
-                    const u64 want = ((u64)(ng + 1) << 32) | (u64)(ns + len);
-                    const u64 seen = AzAtomic::cas_u64(word, old, want);
-                    if (seen == old) {
-                        start = ns;
-                        gi = ng;
-                        break;
-                    }
-                    old = seen;
-                }
+                start = ofs[((size_t)e.g * 2 + b) * 2];
+                gi = ofs[((size_t)e.g * 2 + b) * 2 + 1];
             }
             start = E::Wave::bcast0(start);
             gi = E::Wave::bcast0(gi);
@@ -495,6 +515,9 @@ struct AzHandle {
     int* d_moves;
     u64* d_packed;
     int* d_hcounts;
+    int* d_hlen = nullptr;   // [G][2] lengths of the COMPLETE staging buffers (azsp_harvest)
+    int* d_hofs = nullptr;   // [G][2][2] output rows / game indices handed out by the scan
+    unsigned harvest_seq = 0;  // rotates the slot a harvest starts from
     int* d_games;
     int d_games_cap;
     int16_t* harvest_moves = nullptr;  // optional per-sample move output of azsp_harvest (azsp_harvest_moves)
@@ -515,6 +538,8 @@ template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, 
 int launch_dihedral(const DihedralArgs& a, long long total, void* stream);
 int launch_bias_act(const BiasActArgs& a, void* stream);
 int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* stream);
+// exclusive scan of the staging-buffer lengths in rotated buffer order -> ofs[n2][2], counts[0..1] = samples / games handed out
+int launch_harvest_scan(const int* len, int* ofs, int* counts, int n2, int rot, int cap, int max_games, void* stream);
 // returns 0 ok, 1 unsupported shape, -1 launch error
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
                          int relu, void* stream);
@@ -684,11 +709,13 @@ int azsp_create(const AzspConfig* p, void** out) {
     h->d_moves = az_new<int>(h, G);
     h->d_packed = az_new<u64>(h, 18 * h->W + 8);
     h->d_hcounts = az_new<int>(h, 4);
+    h->d_hlen = az_new<int>(h, 2 * G);
+    h->d_hofs = az_new<int>(h, 4 * G);
     h->d_games_cap = (int)(2 * G);
     h->d_games = az_new<int>(h, (size_t)h->d_games_cap * 16);
     h->d_gextra = az_new<int>(h, (size_t)h->d_games_cap * 4);
     if (!m.nodes || !m.games || !m.rootP || !m.free_stack || !m.leaf_path || !m.stg_planes || !m.stg_pi || !m.log_pi ||
-        !h->d_games || !h->d_gextra || !m.err) {
+        !h->d_games || !h->d_gextra || !m.err || !h->d_hlen || !h->d_hofs) {
         for (void* q : h->allocs) azb::release(q);
         delete h;
         return AZSP_ENOMEM;
@@ -895,8 +922,17 @@ int azsp_harvest(void* e, int8_t* states, float* pi, float* z, int32_t cap, int3
     if (!h || !states || !pi || !z || !games || !n_samples || !n_games || cap < 1) return AZSP_EINVAL;
     if (max_games > h->d_games_cap) max_games = h->d_games_cap;
     if (azb::zero(h->d_hcounts, sizeof(int) * 4, stream)) return AZSP_EDEVICE;
-    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hcounts, h->harvest_moves, h->d_gextra};
-    int rc = az_run(h, op, stream);
+    OpHarvestCount cnt_op = {h->d_hlen};
+    int rc = az_run(h, cnt_op, stream);
+    if (rc) return rc;
+    const int n2 = 2 * h->cfg.G;
+    const int rot = (int)(((unsigned long long)h->harvest_seq++ * 2ull * 9973ull) % (unsigned long long)n2);  // a different first slot every harvest
+    if (azb::launch_harvest_scan(h->d_hlen, h->d_hofs, h->d_hcounts, n2, rot, cap, max_games, stream)) {
+        h->err = std::string("kernel launch failed: ") + azb::backend_error();
+        return AZSP_EDEVICE;
+    }
+    OpHarvest op = {states, pi, z, cap, h->d_games, max_games, h->d_hofs, h->harvest_moves, h->d_gextra};
+    rc = az_run(h, op, stream);
     if (rc) return rc;
     int cnt[4];
     if (azb::d2h(cnt, h->d_hcounts, sizeof cnt, stream)) return AZSP_EDEVICE;

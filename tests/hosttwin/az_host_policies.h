@@ -1,7 +1,6 @@
 // az_host_policies.h -- TEST INFRASTRUCTURE ONLY: the plain-C++ policies of the host twin (tests/hosttwin/azsp_host.cpp).
 // Included from alpha_zero_amd/csrc/az_wave.h when AZ_HOST_TWIN_POLICIES is defined, i.e. never in the product build.
 //   WaveHost : the wave programming model of az_wave.h as 64-iteration loops (same butterfly order in the sums)
-//   AzAtomic : the device atomics of az_engine.h as plain memory operations (one host thread)
 #pragma once
 struct WaveHost {
     static bool first() { return true; }
@@ -50,17 +49,3 @@ struct WaveHost {
     }
 };
 
-struct AzAtomic {
-    static inline u64 cas_u64(u64* p, u64 expect, u64 desired) {
-        const u64 o = *p;
-        if (o == expect) *p = desired;
-        return o;
-    }
-    static inline u64 load_u64(u64* p) { return *p; }
-    static inline void add(u64* p, u64 v) { *p += v; }
-    static inline int fetch_add_i32(int* p, int v) {
-        const int o = *p;
-        *p += v;
-        return o;
-    }
-};

@@ -37,6 +37,13 @@ int launch_replay_gather(const ReplayGatherArgs& a, long long total, void*) {
     for (long long t = 0; t < total; ++t) az_replay_gather_elem(a, t);
     return 0;
 }
+int launch_harvest_scan(const int* len, int* ofs, int* counts, int n2, int rot, int cap, int max_games, void*) {
+    int best[2] = {0, 0};
+    az_harvest_scan_range(len, ofs, n2, rot, cap, max_games, 0, n2, 0, 0, best);
+    counts[0] = best[0];
+    counts[1] = best[1];
+    return 0;
+}
 int launch_bias_act(const BiasActArgs& a, void*) {
     for (long long i = 0; i < a.nvec; ++i) az_bias_act_vec(a, i);
     return 0;

@@ -396,3 +396,36 @@ def test_game_range_rounds_equal_whole_batch_rounds():
             assert "azsp_select_range" in str(ex)
         else:
             raise AssertionError(f"range {bad} accepted")
+
+
+def test_harvest_is_deterministic_and_capacity_keeps_a_prefix():
+    """azsp_harvest hands out output rows by a scan in (rotating) slot order: two identical runs yield identical streams -- same games,
+    same rows -- and a harvest without room for everything takes a prefix of that order and leaves the rest COMPLETE for the next call
+    (nothing lost, nothing duplicated)."""
+    def stream(cap_samples):
+        a = _actor(G=40, sims=12, P=4, seed=9)
+        out = []
+        for r in range(12):
+            a.run_rounds(25)
+            st, pi, z, games = a.engine.harvest(sample_capacity=cap_samples, max_games=80)
+            out.append((st.clone(), pi.clone(), z.clone(), games.copy()))
+        return out
+
+    big1, big2, small = stream(4000), stream(4000), stream(60)
+    for (s1, p1, z1, g1), (s2, p2, z2, g2) in zip(big1, big2):
+        assert torch.equal(s1, s2) and torch.equal(p1, p2) and torch.equal(z1, z2) and np.array_equal(g1, g2)
+    assert sum(len(g) for *_, g in big1) > 40
+    for st, pi, z, g in big1 + small:  # rows tile the output without gaps, in game-record order
+        assert st.shape[0] == int(g[:, 1].sum()) and (len(g) == 0 or np.array_equal(g[:, 0], np.concatenate([[0], np.cumsum(g[:, 1])[:-1]])))
+    # a capacity of 60 samples binds (several games of ~25 samples finish per harvest): never more than 60 rows, games only delayed
+    assert all(st.shape[0] <= 60 for st, *_ in small) and any(len(g) >= 2 for *_, g in small)
+    uid_big = [int(u) for *_, g in big1 for u in g[:, 11]]
+    uid_small = [int(u) for *_, g in small for u in g[:, 11]]
+    assert len(set(uid_small)) == len(uid_small) and len(uid_small) >= 12  # every game at most once
+    first = {int(g[i, 11]): (st[int(g[i, 0]):int(g[i, 0]) + int(g[i, 1])], z[int(g[i, 0]):int(g[i, 0]) + int(g[i, 1])]) for st, _, z, g in big1 for i in range(len(g))}
+    for st, _, z, g in small:  # a game harvested late is the same game (content depends on seed, slot, uid only)
+        for i in range(len(g)):
+            u = int(g[i, 11])
+            if u in first and u < 40:  # first game of a slot: not yet affected by the slots that stalled on a full harvest
+                assert torch.equal(st[int(g[i, 0]):int(g[i, 0]) + int(g[i, 1])], first[u][0])
+    assert set(uid_small[:8]) <= set(uid_big)

@@ -327,7 +327,9 @@ def test_gpu_game_range_rounds_and_half_batch_forwards_equal_whole_batch_rounds(
                     r0, r1 = g0 * P, g1 * P
                     feat = e.features[(r0 // tb) * (32 * tb * n * n):]
                     act.infer.forward_tiled(feat, r1 - r0, n, e.priors[r0:r1], e.values[r0:r1], slot=1 + k)
-            st, pi, z, games = act.harvest_tensors(clone=True)
+            # room for EVERY finished game (all slots start in phase here and finish in bursts): a harvest that runs out of room keeps
+            # the remaining buffers for the next call, and which ones it keeps depends on the order the waves arrive
+            st, pi, z, games = e.harvest(sample_capacity=2 * G * 25, max_games=2 * G)
             st, pi, z = st.cpu(), pi.cpu(), z.cpu()
             for row in games:  # the harvest kernel hands out output rows first come first served: key the games by their uid
                 a, ln = int(row[0]), int(row[1])

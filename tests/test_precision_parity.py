@@ -96,12 +96,15 @@ def test_gpu_bf16_search_close_to_fp32_search_trained_gomoku13(golden_dir):
     assert r["mean_kl_fp32_bf16"] <= 0.015 and r["mean_tv"] <= 0.025 and r["mean_abs_root_q_diff"] <= 0.015, r
 
 
-def test_gpu_bf16_vs_fp32_evaluator_match_trained_gomoku13(golden_dir):
-    """Game-level statement (VERDICT r2 "Next" #5): the bf16 hand-written evaluator against the fp32 evaluator of the SAME trained
-    network (the reference's shipped 13x13 Gomoku checkpoint), 256 evaluation games on one engine (pipeline.py:815-867 rules: no noise,
-    arg-max moves, fresh tree every move; 64 simulations, P = 8) from 128 seeded random two-ply openings, every opening played twice
-    with the colours swapped.  If the evaluators were identical every pair would split 1 : 1.  Bound: the bf16 side scores within
-    0.5 +- 0.1 (binomial sigma of 256 independent games = 0.031; colour-paired games vary less)."""
+def test_gpu_bf16_vs_fp32_evaluator_games_trained_gomoku13(golden_dir):
+    """Game-level statement (VERDICT r2 "Next" #5) with the reference's shipped, TRAINED 13x13 Gomoku checkpoint: evaluation games on
+    one engine (pipeline.py:815-867 rules: no noise, arg-max moves, fresh tree every move; 64 simulations, P = 8) from 128 seeded random
+    four-ply openings, each opening played by four pairings: bf16 vs bf16, fp32 vs fp32, bf16 (black) vs fp32, fp32 (black) vs bf16
+    -- bf16 = the hand-written kernels (checkpoint widened to 64 filters), fp32 = library convolutions.
+      * pure bf16 games against pure fp32 games from the same opening: same winner, same length, identical move list (fractions);
+      * the mixed pairings: the bf16 side's score over both colours (0.5 if the evaluators were interchangeable).
+    Freestyle Gomoku is a first-player win and the network knows it: black wins nearly every game whoever evaluates, so the score alone
+    says little -- the move-level agreement of whole games is the informative part."""
     import test_ckpt
     from alpha_zero_amd import _lib
     from alpha_zero_amd.core.evaluate import DeviceEvaluator, play_eval_games_parallel
@@ -112,25 +115,26 @@ def test_gpu_bf16_vs_fp32_evaluator_match_trained_gomoku13(golden_dir):
     ev32 = DeviceEvaluator(InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda())
     assert ev16.inf.supports_tiled_features(13, "cuda")
     rng = np.random.Generator(np.random.PCG64(99))
-    centre = [r * 13 + c for r in range(3, 10) for c in range(3, 10)]
+    centre = [r * 13 + c for r in range(2, 11) for c in range(2, 11)]
     openings, players = [], []
     for _ in range(128):
-        op = [int(m) for m in rng.choice(centre, size=2, replace=False)]
-        openings += [op, op]
-        players += [(ev16, ev32), (ev32, ev16)]
+        op = [int(m) for m in rng.choice(centre, size=4, replace=False)]
+        openings += [op] * 4
+        players += [(ev16, ev16), (ev32, ev32), (ev16, ev32), (ev32, ev16)]
     res = play_eval_games_parallel("gomoku", 13, players, 64, 8, 19652, 1.25, openings=openings)
-    score16 = 0.0
-    for g, r in enumerate(res):
-        bf16_is_black = g % 2 == 0
-        score16 += 0.5 if r["winner"] == 0 else float((r["winner"] == 1) == bf16_is_black)
-    rate = score16 / len(res)
-    same = play_eval_games_parallel("gomoku", 13, [(ev32, ev32)] * 2 + [(ev16, ev16)] * 2, 64, 8, 19652, 1.25, openings=openings[:2] + openings[:2])
-    out = dict(games=len(res), bf16_score=rate, black_wins=sum(r["winner"] == 1 for r in res) / len(res), mean_length=float(np.mean([r["game_length"] for r in res])),
-               identical_pair_moves_equal=same[0]["moves"] == same[1]["moves"] and same[2]["moves"] == same[3]["moves"])
+    p16, p32, m16b, m32b = res[0::4], res[1::4], res[2::4], res[3::4]
+    score16 = sum(0.5 if r["winner"] == 0 else float(r["winner"] == 1) for r in m16b) + sum(0.5 if r["winner"] == 0 else float(r["winner"] != 1) for r in m32b)
+    out = dict(openings=128, games=len(res),
+               pure_same_winner=float(np.mean([a["winner"] == b["winner"] for a, b in zip(p16, p32)])),
+               pure_same_length=float(np.mean([a["game_length"] == b["game_length"] for a, b in zip(p16, p32)])),
+               pure_identical_moves=float(np.mean([a["moves"] == b["moves"] for a, b in zip(p16, p32)])),
+               mean_length_bf16=float(np.mean([r["game_length"] for r in p16])), mean_length_fp32=float(np.mean([r["game_length"] for r in p32])),
+               black_wins_bf16=float(np.mean([r["winner"] == 1 for r in p16])), black_wins_fp32=float(np.mean([r["winner"] == 1 for r in p32])),
+               mixed_bf16_score=score16 / 256.0)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "precision_parity_arena_gomoku13.json"), "w"), indent=1)
     print(json.dumps(out))
-    assert out["identical_pair_moves_equal"]
-    assert abs(rate - 0.5) <= 0.1, out
+    assert out["pure_same_winner"] >= 0.9 and out["pure_same_length"] >= 0.5 and out["pure_identical_moves"] >= 0.4, out
+    assert abs(out["mean_length_bf16"] - out["mean_length_fp32"]) <= 1.5 and abs(out["mixed_bf16_score"] - 0.5) <= 0.1, out
 
 
 def test_gpu_go19_256_full_depth_forward_vs_fp32():
@@ -145,7 +149,9 @@ def test_gpu_go19_256_full_depth_forward_vs_fp32():
     torch.manual_seed(21)
     net = AlphaZeroNet((17, 19, 19), 362, 20, 256, 256)
     with torch.no_grad():
-        net.policy_head[4].weight.mul_(0.2)
+        for blk in net.res_blocks:  # identity BatchNorm statistics + 20 unscaled residual adds would blow the activations up to a
+            blk.conv_block2[1].weight.mul_(0.25)  # one-hot softmax (and a vacuous comparison): damp the residual branch instead
+        net.policy_head[4].weight.mul_(0.5)  # top prior ~0.04 of 362 actions (uniform 0.003), logits up to +-5, values 0.2-0.6
         net.value_head[6].weight.mul_(0.3)
     inf = InferenceNet(net, dtype=torch.bfloat16, binding=_lib.load()).cuda()
     assert inf.supports_tiled_features(19, "cuda")
@@ -156,5 +162,8 @@ def test_gpu_go19_256_full_depth_forward_vs_fp32():
     ref_p = torch.softmax(logits, -1)
     dp, dv = (pri - ref_p).abs().max().item(), (v - vr.squeeze(1)).abs().max().item()
     agree = (pri.argmax(-1) == ref_p.argmax(-1)).float().mean().item()
-    json.dump(dict(max_dp=dp, max_dv=dv, top1=agree), open(os.path.join(ROOT, "gpurun_out", "precision_go19_20x256_full_depth.json"), "w"))
+    spread = float(ref_p.max(-1).values.mean())
+    json.dump(dict(max_dp=dp, max_dv=dv, top1=agree, mean_top_prior_fp32=spread, mean_abs_value_fp32=float(vr.abs().mean())),
+              open(os.path.join(ROOT, "gpurun_out", "precision_go19_20x256_full_depth.json"), "w"))
+    assert spread < 0.9 and float(vr.abs().mean()) < 0.95, "the comparison must not be between saturated outputs"
     assert dp <= 3e-2 and dv <= 5e-2 and agree >= 0.9, (dp, dv, agree)

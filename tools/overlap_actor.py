@@ -5,10 +5,12 @@ Measured on MI355X in round 3 (profiles/r03_overlap_*.json) and N
   * no gain: 9x9 Go / 10x128 17 573 vs 17 483 moves/s (+0.5 %), 13x13 Gomoku / 6x64 25 374 vs 25 307 (+0.3 %).  The weight-stationary
     convolution kernels hold one persistent workgroup per CU that owns all 512 registers of every SIMD and 160 KB of LDS, so engine
     waves only get CUs in the tails between launches, and the halved launches pay their prologue twice;
-  * not bit-exact: with two forwards in flight at once the head kernel (k_head_tiled, whose workgroups read tower tiles written on
-    OTHER XCDs) occasionally reads a stale 128-byte line of the tower output (tools/concurrency_probe2.py: stem and tower outputs
-    identical, head planes differ in a few neighbouring positions).  Kernels chained tile-by-tile keep producer and consumer on the
-    same XCD's L2 and are unaffected; one stream per engine (the product) relies on kernel-boundary coherence only, and is exact.
+  * not bit-exact: with two forwards in flight at once the head planes of the forward that was launched FIRST differ in a few
+    neighbouring positions per round (tools/concurrency_probe2.py: its stem and tower outputs are identical to a serial run, k_head_tiled's
+    output is not; the second forward, whose head kernel runs alone, is exact).  The same half-batch forwards one after the other on
+    ONE stream are bit-identical to the whole batch (tools/overlap_debug.py seq_fwd / seq_rev, 250 rounds), engine kernels of disjoint
+    ranges on two streams are exact, engine kernels beside a forward are exact.  An agent-scope acquire fence (buffer_inv sc1) at the
+    top of k_head_tiled / k_fc_heads did not change it; the cause is open.  The product runs one stream per engine.
 The range launches this experiment needs (azsp_select_range / azsp_expand_backup_range) ARE product API: they are exact
 (tests/test_actor_host.py, tests/test_engine_gpu.py run disjoint game ranges one after the other on one stream)."""
 import os

@@ -74,13 +74,28 @@ def round_eng_vs_fwd(act):
     act._forward_half(1)
 
 
-def trace(mode, rounds=60):
-    act = make("overlap-nograph" if mode in ("engine2", "fwd2", "eng_vs_fwd") else mode)
-    if mode in ("engine2", "fwd2", "eng_vs_fwd"):
+def round_seq(act, order):
+    """disjoint game ranges one after the other on the main stream, each followed by its own half-batch forward"""
+    e = act.engine
+    for k in order:
+        g0, g1 = act._halves[k]
+        e.expand_backup(g0, g1)
+        e.select(g0, g1)
+        act._forward_half(k)
+
+
+ROUNDS = int(os.environ.get("OVERLAP_DEBUG_ROUNDS", "60"))
+
+
+def trace(mode, rounds=ROUNDS):
+    special = ("engine2", "fwd2", "eng_vs_fwd", "seq_fwd", "seq_rev")
+    act = make("overlap-nograph" if mode in special else mode)
+    if mode in special:
         act.engine.on_launch = None
     out = []
     for r in range(rounds):
-        {"engine2": round_engine2, "fwd2": round_fwd2, "eng_vs_fwd": round_eng_vs_fwd}.get(mode, lambda a: a.run_round())(act)
+        {"engine2": round_engine2, "fwd2": round_fwd2, "eng_vs_fwd": round_eng_vs_fwd, "seq_fwd": lambda a: round_seq(a, (0, 1)),
+         "seq_rev": lambda a: round_seq(a, (1, 0))}.get(mode, lambda a: a.run_round())(act)
         st, q = act.engine.status()
         pri = act.engine.priors.clone().cpu()
         out.append((st.copy(), q.copy(), pri))
@@ -88,7 +103,7 @@ def trace(mode, rounds=60):
 
 
 ref, _ = trace("serial")
-for mode in ("serial", "engine2", "fwd2", "eng_vs_fwd", "overlap-nograph"):
+for mode in os.environ.get("OVERLAP_DEBUG_MODES", "serial,engine2,fwd2,eng_vs_fwd,overlap-nograph").split(","):
     tr, halves = trace(mode)
     first = None
     for r, ((s0, q0, p0), (s1, q1, p1)) in enumerate(zip(ref, tr)):
