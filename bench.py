@@ -147,12 +147,14 @@ def barrier(world, dev):
         torch.cuda.synchronize(dev)
 
 
-HG_MS = []  # wall-clock of every harvest + gather of this rank (host side, includes the harvest's own stream synchronisation)
+HG_MS = []  # wall-clock of every harvest + gather of this rank, measured from an idle stream (the rounds queued before it have drained)
 
 
 def harvest_and_gather(act):
     from alpha_zero_amd.core.gather import gather_samples
 
+    if act.device.type == "cuda":
+        torch.cuda.synchronize(act.device)  # the harvest would wait for the queued rounds anyway: keep their time out of this number
     t0 = time.perf_counter()
     st, pi, z, games = act.harvest_tensors()
     res = gather_samples(st, pi, z, games, dst=0)

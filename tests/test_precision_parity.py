@@ -133,15 +133,17 @@ def test_gpu_bf16_vs_fp32_evaluator_games_trained_gomoku13(golden_dir):
                mixed_bf16_score=score16 / 256.0)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "precision_parity_arena_gomoku13.json"), "w"), indent=1)
     print(json.dumps(out))
-    assert out["pure_same_winner"] >= 0.9 and out["pure_same_length"] >= 0.5 and out["pure_identical_moves"] >= 0.4, out
-    assert abs(out["mean_length_bf16"] - out["mean_length_fp32"]) <= 1.5 and abs(out["mixed_bf16_score"] - 0.5) <= 0.1, out
+    # measured (profiles/r03_precision_parity_arena_gomoku13.json): same winner 0.992, same length 0.961, identical move lists 0.867, mean
+    # lengths 13.43 / 13.73, black wins 85 % / 84 %, mixed score 0.496
+    assert out["pure_same_winner"] >= 0.95 and out["pure_same_length"] >= 0.85 and out["pure_identical_moves"] >= 0.7, out
+    assert abs(out["mean_length_bf16"] - out["mean_length_fp32"]) <= 1.0 and abs(out["mixed_bf16_score"] - 0.5) <= 0.06, out
 
 
 def test_gpu_go19_256_full_depth_forward_vs_fp32():
     """The 19x19 x 256 kernel adds a second bf16 rounding of a partial sum per convolution (az_conv19.h: two launches, one per
     128-channel half).  Bound it at FULL depth: the jumbo shape (20 blocks x 256, training_go_jumbo.py:46) on the hand-written kernels
-    vs the fp32 module on the same positions -- priors to 3e-2, value to 5e-2, top-1 agreement >= 0.9 (random Kaiming init with the last
-    layers shrunk so that softmax / tanh are well conditioned, as in the other network tests)."""
+    vs the fp32 module on the same positions -- priors to 1e-2, value to 4e-2, top-1 agreement >= 0.95 (random Kaiming init with the
+    residual branches damped and the last layers shrunk, so that the comparison is between unsaturated softmax / tanh outputs)."""
     import engine_util as eu
     from alpha_zero_amd import _lib
     from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet
@@ -166,4 +168,4 @@ def test_gpu_go19_256_full_depth_forward_vs_fp32():
     json.dump(dict(max_dp=dp, max_dv=dv, top1=agree, mean_top_prior_fp32=spread, mean_abs_value_fp32=float(vr.abs().mean())),
               open(os.path.join(ROOT, "gpurun_out", "precision_go19_20x256_full_depth.json"), "w"))
     assert spread < 0.9 and float(vr.abs().mean()) < 0.95, "the comparison must not be between saturated outputs"
-    assert dp <= 3e-2 and dv <= 5e-2 and agree >= 0.9, (dp, dv, agree)
+    assert dp <= 1e-2 and dv <= 4e-2 and agree >= 0.95, (dp, dv, agree)  # measured 1.6e-3 / 2.2e-2 / 1.0 (top prior 0.049 of 362 actions)

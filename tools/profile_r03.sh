@@ -1,4 +1,4 @@
-# Round 3, GPU call L: same-box A/B of the 19x19 kernel (frozen round-2 copy vs the product), whole GPU tier, final benches + rocprof.
+# Round 3 profile run on the GPU box (what profiles/r03_* come from): same-box A/B of the 19x19 kernel (frozen round-2 copy vs the product), whole GPU tier, the driver-command and C2 benches, rocprofv3 kernel stats, PMC passes over the fused block.
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out
 P=$GRAFT_REPO_ROOT/tools/probes
