@@ -13,6 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from alpha_zero_amd.core.network import AlphaZeroNet  # noqa: E402
 from overlap_actor import OverlapActor  # noqa: E402
 
+if os.environ.get("AZ_PROBE_LIB"):  # an alternative build of the library (e.g. the head kernel with 96 KB of extra dynamic LDS, so that
+    import ctypes                    # none of its workgroups can share a CU with a convolution workgroup)
+
+    from alpha_zero_amd import _abi, _lib
+
+    _lib._binding = _abi.Binding(ctypes.CDLL(os.environ["AZ_PROBE_LIB"]), "probe build")
 torch.manual_seed(4)
 net = AlphaZeroNet((17, 9, 9), 82, 2, 128, 64)
 act = OverlapActor(net, game="go", board_size=9, num_games=1184, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0, seed=7,

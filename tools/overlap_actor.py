@@ -9,8 +9,10 @@ Measured on MI355X in round 3 (profiles/r03_overlap_*.json) and N
     neighbouring positions per round (tools/concurrency_probe2.py: its stem and tower outputs are identical to a serial run, k_head_tiled's
     output is not; the second forward, whose head kernel runs alone, is exact).  The same half-batch forwards one after the other on
     ONE stream are bit-identical to the whole batch (tools/overlap_debug.py seq_fwd / seq_rev, 250 rounds), engine kernels of disjoint
-    ranges on two streams are exact, engine kernels beside a forward are exact.  An agent-scope acquire fence (buffer_inv sc1) at the
-    top of k_head_tiled / k_fc_heads did not change it; the cause is open.  The product runs one stream per engine.
+    ranges on two streams are exact, engine kernels beside a forward are exact.  The difference disappears when k_head_tiled cannot
+    share a CU with another workgroup (96 KB of extra dynamic LDS in a probe build); an agent-scope acquire fence did not change it and
+    LDS-DMA does not land in a neighbour's allocation (tools/probes/lds_dma_coresidency_probe.hip).  Mechanism open; the product runs
+    one stream per engine.
 The range launches this experiment needs (azsp_select_range / azsp_expand_backup_range) ARE product API: they are exact
 (tests/test_actor_host.py, tests/test_engine_gpu.py run disjoint game ranges one after the other on one stream)."""
 import os
