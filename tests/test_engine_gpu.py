@@ -343,3 +343,33 @@ def test_gpu_game_range_rounds_and_half_batch_forwards_equal_whole_batch_rounds(
         s1, p1, z1, r1 = gb[uid]
         assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(r0, r1), uid
     assert {k: v for k, v in c0.items() if not k.startswith("hint")} == {k: v for k, v in c1.items() if not k.startswith("hint")}
+
+
+@pytest.mark.gpu
+def test_gpu_same_seed_gives_the_same_harvest_stream():
+    """Two actors with the same seed produce the same harvest stream -- the same games in the same output rows, bit for bit: search,
+    evaluator (hand-written bf16 kernels, hipGraph replay), production randomness and the harvest's row assignment are all deterministic.
+    (Round 2 reserved harvest rows with a CAS race; a missing barrier behind the LDS zero fill of the 9x9 convolution kernel could,
+    rarely, perturb a forward -- both would show here.)"""
+    import numpy as np
+    import torch
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    torch.manual_seed(4)
+    net = AlphaZeroNet((17, 9, 9), 82, 2, 128, 64)
+    streams = []
+    for _ in range(2):
+        act = SelfPlayActor(net, game="go", board_size=9, num_games=1024, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0,
+                            seed=11, device="cuda", engine_kw={"max_steps": 30})
+        out = []
+        for _ in range(8):
+            act.run_rounds(50)
+            st, pi, z, games = act.harvest_tensors(clone=True)
+            out.append((st.cpu(), pi.cpu(), z.cpu(), games.copy()))
+        streams.append((out, act.counters()))
+        del act
+    (a, ca), (b, cb) = streams
+    assert sum(len(g) for *_, g in a) > 1000 and ca == cb
+    for (s0, p0, z0, g0), (s1, p1, z1, g1) in zip(a, b):
+        assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(g0, g1)
