@@ -483,7 +483,7 @@ def main(argv=None):
                      "note": "same engine / evaluator / workload with sub-tree reuse disabled: the upper-work variant, labelled, never `value`"}
             del af, evf
             torch.cuda.empty_cache()
-        cpu = None
+        cpu, c1 = None, None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline
 
@@ -492,6 +492,12 @@ def main(argv=None):
                                filters=args.filters, stagger=args.stagger)
             cpu["value"] = round(cpu["value"], 3)
             cpu["per_core"] = round(cpu["per_core"], 4)
+            # BASELINE configs[0] (C1): the reference's own CPU-runnable case -- 13x13 Gomoku, mcts_v2.uct_search (P = 1), ONE actor, 100
+            # sims/move, 6x64 net -- timed with the same port on one host core for a few seconds (the reference measured
+            # 2.7 moves/s in the development container)
+            c1 = baseline.run(1, seconds=min(8.0, args.cpu_seconds), game="gomoku", n=13, sims=100, P=1, blocks=6, filters=64, stagger=0)
+            c1["value"], c1["per_core"] = round(c1["value"], 3), round(c1["per_core"], 4)
+            c1["config"] = "BASELINE C1: 13x13 Gomoku, uct_search, 1 CPU self-play actor, 100 sims/move (reference path, no GPU)"
             # port vs the imported reference on identical seeded moves, measured in the development container by
             # tools/calibrate_baseline.py (the reference cannot travel to the GPU box): ratio = port moves/s / reference moves/s
             cal = os.path.join(ROOT, "tests", "golden", "cpu_baseline_calibration.json")
@@ -527,7 +533,7 @@ def main(argv=None):
             "fresh_tree_moves_per_s": fresh["moves_per_s"] if fresh else None, "fresh_tree_companion": fresh,
             "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "c1_cpu_reference_path": c1,
         }
         print(json.dumps(line), flush=True)
     if pg_active():
