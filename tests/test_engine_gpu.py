@@ -370,6 +370,6 @@ def test_gpu_same_seed_gives_the_same_harvest_stream():
         streams.append((out, act.counters()))
         del act
     (a, ca), (b, cb) = streams
-    assert sum(len(g) for *_, g in a) > 1000 and ca == cb
+    assert ca == cb and sum(len(g) for *_, g in a) > 500
     for (s0, p0, z0, g0), (s1, p1, z1, g1) in zip(a, b):
         assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(g0, g1)
