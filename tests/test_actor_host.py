@@ -367,7 +367,7 @@ def test_game_range_rounds_equal_whole_batch_rounds():
         a = _actor(G=72, sims=12, P=4, seed=5)
         e = a.engine
         by_uid = {}
-        for r in range(160):
+        for r in range(100):
             if order is None:
                 a.run_round()
             else:
@@ -385,7 +385,7 @@ def test_game_range_rounds_equal_whole_batch_rounds():
     whole, c0, _ = play(None)
     for order in ([(0, 32), (32, 72)], [(64, 72), (0, 64)]):
         part, c1, e = play(order)
-        assert len(whole) >= 30 and whole.keys() == part.keys() and c0 == c1
+        assert len(whole) >= 15 and whole.keys() == part.keys() and c0 == c1
         for uid, (s0, p0, z0, r0) in whole.items():
             s1, p1, z1, r1 = part[uid]
             assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(r0, r1)
@@ -405,8 +405,8 @@ def test_harvest_is_deterministic_and_capacity_keeps_a_prefix():
     def stream(cap_samples):
         a = _actor(G=40, sims=12, P=4, seed=9)
         out = []
-        for r in range(12):
-            a.run_rounds(25)
+        for r in range(9):
+            a.run_rounds(20)
             st, pi, z, games = a.engine.harvest(sample_capacity=cap_samples, max_games=80)
             out.append((st.clone(), pi.clone(), z.clone(), games.copy()))
         return out
@@ -414,14 +414,14 @@ def test_harvest_is_deterministic_and_capacity_keeps_a_prefix():
     big1, big2, small = stream(4000), stream(4000), stream(60)
     for (s1, p1, z1, g1), (s2, p2, z2, g2) in zip(big1, big2):
         assert torch.equal(s1, s2) and torch.equal(p1, p2) and torch.equal(z1, z2) and np.array_equal(g1, g2)
-    assert sum(len(g) for *_, g in big1) > 40
+    assert sum(len(g) for *_, g in big1) > 20
     for st, pi, z, g in big1 + small:  # rows tile the output without gaps, in game-record order
         assert st.shape[0] == int(g[:, 1].sum()) and (len(g) == 0 or np.array_equal(g[:, 0], np.concatenate([[0], np.cumsum(g[:, 1])[:-1]])))
     # a capacity of 60 samples binds (several games of ~25 samples finish per harvest): never more than 60 rows, games only delayed
     assert all(st.shape[0] <= 60 for st, *_ in small) and any(len(g) >= 2 for *_, g in small)
     uid_big = [int(u) for *_, g in big1 for u in g[:, 11]]
     uid_small = [int(u) for *_, g in small for u in g[:, 11]]
-    assert len(set(uid_small)) == len(uid_small) and len(uid_small) >= 12  # every game at most once
+    assert len(set(uid_small)) == len(uid_small) and len(uid_small) >= 8  # every game at most once
     first = {int(g[i, 11]): (st[int(g[i, 0]):int(g[i, 0]) + int(g[i, 1])], z[int(g[i, 0]):int(g[i, 0]) + int(g[i, 1])]) for st, _, z, g in big1 for i in range(len(g))}
     for st, _, z, g in small:  # a game harvested late is the same game (content depends on seed, slot, uid only)
         for i in range(len(g)):
