@@ -113,6 +113,7 @@ class InferenceNet(nn.Module):
         self.use_fused_conv = True
         self.use_tiled_tower = True
         self.use_fused_block = True  # 64-filter towers: azsp_resblock_tiled instead of two azsp_conv3x3_tiled launches per block
+        self.use_split_tower = True  # fp32 networks: azsp_conv3x3_split (hi + lo f16 pairs, three MFMA products) instead of the library
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.stem_pad = net.conv_block[0].padding[0]
         with torch.no_grad():
@@ -126,6 +127,16 @@ class InferenceNet(nn.Module):
             self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
                                                      requires_grad=False) for w, _ in convs[1:]])
             self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
+            if dtype == torch.float32:
+                # split-precision tower (azsp_conv3x3_split): every fp32 weight as hi = f16(w) and lo = f16((w - hi) * 2048),
+                # packed [plane][tap = ky*3+kx][cout][cin]
+                def _split_w(w):
+                    w9 = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).float()
+                    hi = w9.to(torch.float16)
+                    lo = ((w9 - hi.float()) * 2048.0).to(torch.float16)
+                    return nn.Parameter(torch.stack([hi, lo]).contiguous(), requires_grad=False)
+
+                self.wsp = nn.ParameterList([_split_w(w) for w, _ in convs[1:]])
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
@@ -173,6 +184,13 @@ class InferenceNet(nn.Module):
         run) and 19x19 planes x 256 filters (the jumbo Go network)."""
         return (self.binding is not None and self.use_fused_conv and self.use_tiled_tower and x.is_cuda and x.dtype == torch.bfloat16
                 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17), (64, 9), (256, 19))
+                and x.is_contiguous(memory_format=torch.channels_last))
+
+    def _split_tower_ok(self, x):
+        """fp32 networks on 9x9 planes with 128 or 64 filters: the tower runs on azsp_conv3x3_split (include/azsp.h) -- the reference's
+        precision class (pipeline.py:91-123 evaluates in fp32) at the f16 MFMA rate."""
+        return (self.binding is not None and self.use_fused_conv and self.use_split_tower and x.is_cuda and x.dtype == torch.float32
+                and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 9))
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     def _conv(self, x, i, res=None):
@@ -253,6 +271,10 @@ class InferenceNet(nn.Module):
             s = board_size + 2 * (self.stem_pad - 1)
             if (self.filters, s) in ((128, 9), (64, 17), (64, 9), (256, 19)):
                 return "hand-written tower (azsp_conv3x3_tiled) behind a library stem and heads"
+        if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower:
+            if (self.filters, board_size + 2 * (self.stem_pad - 1)) in ((128, 9), (64, 9)):
+                return ("fp32 class: hand-written split-precision tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 "
+                        "accumulation) behind a library fp32 stem and heads")
         return f"library convolutions + azsp_bias_act epilogue (no hand-written kernel for {self.filters} filters on {board_size}x{board_size}, {self.dtype})"
 
     def supports_tiled_features(self, board_size, device):
@@ -337,6 +359,32 @@ class InferenceNet(nn.Module):
         ck(dll.azsp_tile_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_tile_layout")
         return x
 
+    def _tower_split(self, x):
+        """The whole residual tower of an fp32 network on the split layout (azsp_split_layout / azsp_conv3x3_split): activations are
+        converted once on entry and once on exit; x is channels-last fp32 [B,C,S,S] and is overwritten with the tower's output."""
+        import ctypes
+
+        dll, ck = self.binding.dll, self._ck
+        st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        B, C, S = x.shape[0], x.shape[1], x.shape[2]
+        n = dll.azsp_split_bytes(B, S, C) // 2
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (n, str(x.device))
+        if key not in cache:
+            cache.clear()
+            cache[key] = [torch.zeros(n, dtype=torch.float16, device=x.device) for _ in range(3)]
+        a, m, o = cache[key]
+        self._split = (a, m, o, B)  # (bench.py replays the tower on the activations of the last forward)
+        ck(dll.azsp_split_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_split_layout")
+        for i in range(self.n_blocks):
+            ck(dll.azsp_conv3x3_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
+               "azsp_conv3x3_split")
+            ck(dll.azsp_conv3x3_split(m.data_ptr(), self.wsp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
+                                      B, S, C, 1, st), "azsp_conv3x3_split")
+            a, o = o, a
+        ck(dll.azsp_split_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_split_layout")
+        return x
+
     @torch.no_grad()
     def forward(self, x, priors_out=None, values_out=None):
         """x: [B,17,N,N] any dtype -> (priors fp32 [B,A], values fp32 [B])."""
@@ -344,6 +392,8 @@ class InferenceNet(nn.Module):
         x = self._epilogue(F.conv2d(x, self.w[0], None, padding=self.stem_pad), self.b[0])
         if self._tiled_tower_ok(x):
             x = self._tower_tiled(x)
+        elif self._split_tower_ok(x):
+            x = self._tower_split(x)
         else:
             for i in range(self.n_blocks):
                 y = self._conv(x, 2 * i)

@@ -8,6 +8,7 @@
 #include "azsp_impl.h"
 #include "az_conv64.h"
 #include "az_conv19.h"
+#include "az_conv_sp.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -256,6 +257,35 @@ int launch_tile_layout(const void* src, void* dst, long long boards, int S, int 
     const long long nchunks = boards * S * S * nch;
     hipLaunchKernelGGL(k_tile_layout, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)src,
                        (unsigned char*)dst, nchunks, to_tiled, nch, tile_rows);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* st) {
+    if (C % 8 || S < 1) return 1;
+    const long long nchunks = boards * S * S * (C / 8);
+    hipLaunchKernelGGL(k_split_layout, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)src,
+                       (unsigned char*)dst, nchunks, to_split, C / 8, S * S);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
+                         void* st) {
+    if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const int ncg = C / 64;
+    long long nslot = n_cu / ncg > 0 ? n_cu / ncg : 1;  // one persistent workgroup per CU; the cout groups of a board run side by side
+    if (boards < nslot) nslot = boards;
+    const dim3 grid((unsigned)(nslot * ncg)), block(CW_THREADS);
+#define AZ_SP(RES, NCH, NCG)                                                                                                             \
+    hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias, \
+                       (const unsigned char*)res, (unsigned char*)y, (int)boards, relu)
+    if (C == 128) {
+        if (res) AZ_SP(true, 16, 2);
+        else AZ_SP(false, 16, 2);
+    } else {
+        if (res) AZ_SP(true, 8, 1);
+        else AZ_SP(false, 8, 1);
+    }
+#undef AZ_SP
     return AZ_HIP(hipGetLastError());
 }
 }  // namespace azb

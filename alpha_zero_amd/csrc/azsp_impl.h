@@ -546,6 +546,9 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
 int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
                           void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
+int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* stream);
+int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
+                         void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
                       int pol_stride, int val_stride, void* stream);
@@ -1014,6 +1017,26 @@ int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const vo
     if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int64_t azsp_split_bytes(int64_t boards, int32_t S, int32_t C) {
+    if (boards < 0 || S <= 0 || C <= 0 || C % 8) return -1;
+    return boards * 2 * (int64_t)S * S * C * 2;
+}
+
+int azsp_split_layout(const void* src, void* dst, int64_t boards, int32_t S, int32_t C, int32_t to_split, void* stream) {
+    if (!src || !dst || boards < 0 || boards > 0x7fffffff || S <= 0 || C <= 0 || C % 8) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_split_layout(src, dst, (long long)boards, S, C, to_split, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
+                       int32_t relu, void* stream) {
+    if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_conv3x3_split(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -32,6 +32,9 @@
  *   azsp_conv3x3_tiled                a whole conv3x3 + BatchNorm (+ skip) + ReLU of a ResNetBlock (core/network.py:42-82)
  *   azsp_resblock_tiled               a whole ResNetBlock of a 64-filter tower in one launch (intermediate activation in LDS)
  *   azsp_tile_layout / azsp_tiled_bytes the tower's resident activation layout
+ *   azsp_conv3x3_split                the same layer at the reference's fp32 precision class (core/pipeline.py:91-123 evaluates
+ *                                     in fp32): values as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulation
+ *   azsp_split_layout / azsp_split_bytes the split-precision tower's activation layout
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
  * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
@@ -254,6 +257,22 @@ int azsp_conv3x3_tiled(const void* x_dev, const void* w_packed_dev, const float*
  * tower, (9, 64) the 9x9 Go tower with 64 filters (logs/go/9x9_12b64); AZSP_EINVAL for other shapes. */
 int azsp_resblock_tiled(const void* x_dev, const void* w1_packed_dev, const float* bias1_dev, const void* w2_packed_dev, const float* bias2_dev,
                         void* y_dev, int64_t boards, int32_t board_size, int32_t channels, void* stream);
+
+/* The residual tower at the reference's precision class (core/network.py:42-82 evaluated in fp32 by core/pipeline.py:91-123).
+ * gfx950 multiplies fp32 matrices at 1/16 of its f16 rate and has no TF32, so here an fp32 value v travels as two f16 numbers,
+ * hi = f16(v) and lo = f16((v - hi) * 2048), and a product is three f16 MFMAs (w_hi x_hi; w_hi x_lo + w_lo x_hi scaled by 1/2048)
+ * accumulated in fp32: 22-bit significands, per-product error <= 3 * 2^-22, i.e. fp32 round-off class (bounded against fp64 next to
+ * the library's fp32 convolution in tests/test_network.py).  Values are clamped to +-65504 when split.
+ * "Split layout": [board][plane: hi, lo][C/8 channel chunks][S*S positions][8 ch] f16 = azsp_split_bytes(boards, S, C) bytes;
+ * azsp_split_layout converts fp32 channels-last rows [boards][S][S][C] to (to_split = 1) / from (0) it.
+ * azsp_conv3x3_split: y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y in the split layout (x must not alias y; residual
+ * may), w_split [2 planes: hi, lo][9 taps (ky*3+kx)][C out][C in] f16 with lo = (w - hi) * 2048, bias float[C].  On the device:
+ * (S, C) = (9, 128) and (9, 64); AZSP_EINVAL for other shapes. */
+int64_t azsp_split_bytes(int64_t boards, int32_t board_size, int32_t channels);
+int azsp_split_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t to_split,
+                      void* stream);
+int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
+                       int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch
  * tensors and apply_random_transformation): out_states[b] = T_op(ring_states[idx[b]]) cast to state_dtype (AZSP_FEAT_I8 / F32 /

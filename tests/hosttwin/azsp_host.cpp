@@ -86,6 +86,87 @@ int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const 
     host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
     return 0;
 }
+// ---- split-precision tower (azsp_split_layout / azsp_conv3x3_split): plain loops on the same hi / lo f16 arithmetic ----
+static inline unsigned short sp_h_from_f32(float f) {  // fp32 -> f16, round to nearest even, subnormals kept
+    union { unsigned u; float f; } v;
+    v.f = f;
+    const unsigned sign = (v.u >> 16) & 0x8000u, x = v.u & 0x7fffffffu;
+    if (x >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);  // >= 65520 rounds to infinity
+    if (x < 0x38800000u) {                                           // below 2^-14: a multiple of 2^-24
+        v.u = x;
+        return (unsigned short)(sign | (unsigned)nearbyintf(v.f * 16777216.0f));
+    }
+    unsigned h = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+    const unsigned rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (unsigned short)(sign | h);
+}
+static inline float sp_h_to_f32(unsigned short h) {
+    const int e = (h >> 10) & 31, m = h & 0x3ff;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400), e - 25);
+    return (h & 0x8000) ? -v : v;
+}
+static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    h = sp_h_from_f32(v);
+    l = sp_h_from_f32((v - sp_h_to_f32(h)) * 2048.0f);
+}
+static inline float sp_h_join(unsigned short h, unsigned short l) { return fmaf(sp_h_to_f32(l), 1.0f / 2048.0f, sp_h_to_f32(h)); }
+// split layout [board][plane][C/8][P2][8] f16 <-> channels-last fp32 rows
+int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void*) {
+    const int P2 = S * S, nch = C / 8;
+    const size_t plane = (size_t)nch * P2 * 8;
+    for (long long b = 0; b < boards; ++b)
+        for (int c = 0; c < nch; ++c)
+            for (int p = 0; p < P2; ++p)
+                for (int e = 0; e < 8; ++e) {
+                    const size_t so = (size_t)b * 2 * plane + ((size_t)c * P2 + p) * 8 + e, fo = ((size_t)b * P2 + p) * C + c * 8 + e;
+                    if (to_split) sp_h_split(((const float*)src)[fo], ((unsigned short*)dst)[so], ((unsigned short*)dst)[so + plane]);
+                    else ((float*)dst)[fo] = sp_h_join(((const unsigned short*)src)[so], ((const unsigned short*)src)[so + plane]);
+                }
+    return 0;
+}
+int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
+                         void*) {
+    if (S != 9 || (C != 128 && C != 64)) return 1;
+    const int P2 = S * S, nch = C / 8;
+    const size_t plane = (size_t)nch * P2 * 8, wplane = (size_t)9 * C * C;
+    const unsigned short *xs = (const unsigned short*)x, *ws = (const unsigned short*)w, *rs = (const unsigned short*)res;
+    unsigned short* ys = (unsigned short*)y;
+    auto at = [&](int ch, int p) { return ((size_t)(ch / 8) * P2 + p) * 8 + ch % 8; };
+    std::vector<float> wh(wplane), wl(wplane);
+    for (size_t i = 0; i < wplane; ++i) wh[i] = sp_h_to_f32(ws[i]), wl[i] = sp_h_to_f32(ws[wplane + i]);
+    std::vector<float> xh((size_t)P2 * C), xl((size_t)P2 * C);
+    for (long long b = 0; b < boards; ++b) {
+        const size_t bo = (size_t)b * 2 * plane;
+        for (int p = 0; p < P2; ++p)
+            for (int ci = 0; ci < C; ++ci) xh[(size_t)p * C + ci] = sp_h_to_f32(xs[bo + at(ci, p)]), xl[(size_t)p * C + ci] = sp_h_to_f32(xs[bo + plane + at(ci, p)]);
+        for (int p = 0; p < P2; ++p)
+            for (int co = 0; co < C; ++co) {
+                float main = bias[co], corr = 0.0f;
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int sy = p / S + tap / 3 - 1, sx = p % S + tap % 3 - 1;
+                    if (sy < 0 || sx < 0 || sy >= S || sx >= S) continue;
+                    const float *h = &xh[(size_t)(sy * S + sx) * C], *l = &xl[(size_t)(sy * S + sx) * C];
+                    const float *a = &wh[((size_t)tap * C + co) * C], *d = &wl[((size_t)tap * C + co) * C];
+                    for (int ci = 0; ci < C; ++ci) {
+                        main += a[ci] * h[ci];
+                        corr += a[ci] * l[ci];
+                        corr += d[ci] * h[ci];
+                    }
+                }
+                float v = fmaf(corr, 1.0f / 2048.0f, main);
+                if (rs) v += sp_h_join(rs[bo + at(co, p)], rs[bo + plane + at(co, p)]);
+                if (relu && v < 0.0f) v = 0.0f;
+                sp_h_split(v, ys[bo + at(co, p)], ys[bo + plane + at(co, p)]);
+            }
+    }
+    return 0;
+}
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*) {
     // un-tile the 32-channel features, embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1), pad-1 convolution
     const int So = S + 2 * (pad - 1), off = pad - 1;

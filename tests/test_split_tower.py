@@ -1,0 +1,187 @@
+"""The residual tower at the reference's precision class (core/pipeline.py:91-123 evaluates the network in fp32) on the f16-rate
+matrix cores: azsp_split_layout / azsp_conv3x3_split (include/azsp.h, alpha_zero_amd/csrc/az_conv_sp.h).
+
+Checker = torch in fp64 on the CPU (the same convolution, exact to ~1e-16), with the library's own fp32 convolution measured beside
+the kernel: the statement is "the kernel's error against fp64 is of the size of fp32 round-off", tolerance written in each test."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def split_weights(w):
+    """[Cout,Cin,3,3] fp32 -> [2 planes][9 taps][Cout][Cin] f16 (the packing InferenceNet does)."""
+    w9 = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).float()
+    hi = w9.to(torch.float16)
+    return torch.stack([hi, ((w9 - hi.float()) * 2048.0).to(torch.float16)]).contiguous()
+
+
+def _inputs(boards, C, S, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(boards, C, S, S, generator=g) * scale
+    x = torch.where(torch.rand(boards, C, S, S, generator=g) < 0.5, torch.zeros(()), x.abs())  # post-ReLU-like: half zeros
+    x[:, : C // 8] *= 37.0    # a few loud channels ...
+    x[:, -C // 8 :] *= 3e-3   # ... and a few quiet ones
+    r = torch.randn(boards, C, S, S, generator=g).abs() * scale
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    return x, r, w, b
+
+
+def _run_split_conv(bnd, x, r, w, b, relu, device):
+    """x, r: [B,C,S,S] fp32 -> y [B,C,S,S] fp32 through split_layout -> conv3x3_split -> split_layout."""
+    B, C, S, _ = x.shape
+    dll = bnd.dll
+    xc = x.to(device).contiguous(memory_format=torch.channels_last)
+    n = dll.azsp_split_bytes(B, S, C) // 2
+    assert n == B * 2 * S * S * C
+    xs, ys = torch.zeros(n, dtype=torch.float16, device=device), torch.zeros(n, dtype=torch.float16, device=device)
+    assert dll.azsp_split_layout(xc.data_ptr(), xs.data_ptr(), B, S, C, 1, None) == 0
+    rs = None
+    if r is not None:
+        rc = r.to(device).contiguous(memory_format=torch.channels_last)
+        rs = torch.zeros(n, dtype=torch.float16, device=device)
+        assert dll.azsp_split_layout(rc.data_ptr(), rs.data_ptr(), B, S, C, 1, None) == 0
+    wsp, bb = split_weights(w).to(device), b.float().to(device)
+    assert dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bb.data_ptr(), rs.data_ptr() if rs is not None else None, ys.data_ptr(),
+                                  B, S, C, relu, None) == 0
+    y = torch.empty_like(xc)
+    assert dll.azsp_split_layout(ys.data_ptr(), y.data_ptr(), B, S, C, 0, None) == 0
+    # the layout round trip of the input itself: 22-bit significands
+    back = torch.empty_like(xc)
+    assert dll.azsp_split_layout(xs.data_ptr(), back.data_ptr(), B, S, C, 0, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    # |v - hi - lo / 2048| <= 2^-22 |v| (+ the fp32 rounding of the join); below f16's normal range the lo half is a multiple of
+    # 2^-24 / 2048 = 2^-35: the excess over that absolute floor, relative to |v|
+    rt = (((back.cpu() - x).abs() - 2.0 ** -35).clamp_min(0) / x.abs().clamp_min(1e-30)).max().item()
+    return y.cpu().contiguous(), rt
+
+
+def _ref64(x, r, w, b, relu):
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if r is not None:
+        y = y + r.double()
+    return torch.relu(y) if relu else y
+
+
+def test_split_abi_host_twin():
+    """azsp_split_layout / azsp_conv3x3_split through the ABI on the host twin (plain loops on the same hi / lo f16 arithmetic)."""
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    for boards, res, relu in ((1, False, 1), (2, True, 1), (1, True, 0)):
+        x, r, w, b = _inputs(boards, 64, 9, 10 + boards)
+        if not relu:
+            x = x - 0.3
+        y, rt = _run_split_conv(bnd, x, r if res else None, w, b, relu, "cpu")
+        ref = _ref64(x, r if res else None, w, b, relu)
+        err = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert rt <= 2.0 ** -21, rt
+        assert err <= 2e-6, (boards, res, relu, err)
+    assert bnd.dll.azsp_split_bytes(3, 9, 128) == 3 * 2 * 81 * 128 * 2 and bnd.dll.azsp_split_bytes(1, 9, 12) == -1
+    assert bnd.dll.azsp_conv3x3_split(None, None, None, None, None, 1, 9, 128, 1, None) != 0
+    z = torch.zeros(2 * 2 * 121 * 64, dtype=torch.float16)
+    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.clone().data_ptr(), 1, 11, 64, 1, None) != 0  # unsupported plane size
+
+
+def test_split_tower_clamps_at_f16_range_host_twin():
+    """Values beyond f16's largest finite number are clamped when they are split (documented in include/azsp.h), never inf / NaN."""
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    x = torch.tensor([1e5, -1e5, 65504.0, 1e-7, 0.0, 3.0, -2.5e-5, 70000.0]).reshape(1, 8, 1, 1).contiguous(memory_format=torch.channels_last)
+    s = torch.zeros(2 * 8, dtype=torch.float16)
+    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None) == 0
+    back = torch.empty_like(x)
+    assert bnd.dll.azsp_split_layout(s.data_ptr(), back.data_ptr(), 1, 1, 8, 0, None) == 0
+    want = x.clamp(-65504.0, 65504.0)
+    assert torch.isfinite(back).all() and ((back - want).abs() <= want.abs() * 2.0 ** -21 + 1e-11).all(), back.flatten()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [128, 64])
+@pytest.mark.parametrize("boards", [1, 2, 127, 128, 129, 300, 1000])
+def test_gpu_split_conv_error_vs_fp64(boards, C):
+    """k_conv3x3_sp vs fp64, next to the library's fp32 convolution on the same inputs.  Board counts around one / two boards per
+    workgroup slot (128 slots at 128 filters, 256 at 64) exercise the first-board, has-next and last-board paths of the persistent loop.
+    Bound: max |y - y64| <= 4e-6 max|y64| and at most 8x the library's own fp32 error + 1e-6 (measured: see profiles/r03_split_*)."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    out = []
+    for res, relu in ((False, 1), (True, 1), (True, 0)):
+        x, r, w, b = _inputs(boards, C, 9, 100 + boards)
+        if not relu:
+            x = x - 0.3
+        y, rt = _run_split_conv(bnd, x, r if res else None, w, b, relu, "cuda")
+        ref = _ref64(x, r if res else None, w, b, relu)
+        lib = F.conv2d(x.cuda(), w.cuda(), b.cuda(), padding=1)
+        if res:
+            lib = lib + r.cuda()
+        lib = (torch.relu(lib) if relu else lib).cpu()
+        scale = ref.abs().max().item()
+        err, lib_err = (y.double() - ref).abs().max().item() / scale, (lib.double() - ref).abs().max().item() / scale
+        out.append(dict(boards=boards, C=C, residual=res, relu=relu, err=err, library_fp32_err=lib_err, layout_roundtrip_rel=rt))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "split_conv_error.jsonl"), "a") as f:
+        for o in out:
+            f.write(json.dumps(o) + "\n")
+    for o in out:
+        assert o["layout_roundtrip_rel"] <= 2.0 ** -21, o
+        assert o["err"] <= 4e-6 and o["err"] <= 8 * o["library_fp32_err"] + 1e-6, o
+
+
+@pytest.mark.gpu
+def test_gpu_split_conv_small_and_large_magnitudes():
+    """The lo halves are scaled by 2^11, so precision must hold for activations far from 1: tiny (below f16's normal range the hi half
+    turns subnormal and the scaled lo half carries the value) and large (up to the clamp)."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    res = {}
+    for name, scale in (("1e-4", 1e-4), ("1e-2", 1e-2), ("1e2", 1e2)):
+        x, r, w, b = _inputs(40, 128, 9, 7, scale=scale)
+        b = b * scale
+        y, _ = _run_split_conv(bnd, x, r, w, b, 1, "cuda")
+        ref = _ref64(x, r, w, b, 1)
+        res[name] = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    print(json.dumps(res))
+    assert res["1e-2"] <= 4e-6 and res["1e2"] <= 4e-6, res
+    assert res["1e-4"] <= 1e-4, res  # inputs of 1e-4 x 3e-3 are below every f16 normal: graceful, not exact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filters", [128, 64])
+def test_gpu_fp32_network_on_the_split_tower(filters):
+    """The whole fp32 evaluator with the tower on azsp_conv3x3_split vs the same InferenceNet on library convolutions vs the fp64
+    module: priors / values within 2e-5 of fp64 (the library path's own distance to fp64 is reported beside it)."""
+    from alpha_zero_amd import _lib
+
+    torch.manual_seed(3)
+    net = AlphaZeroNet((17, 9, 9), 82, 10, filters, 128).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):  # non-trivial running statistics, as after training
+                m.running_mean.normal_(0, 0.2), m.running_var.uniform_(0.5, 1.5), m.weight.uniform_(0.7, 1.3), m.bias.normal_(0, 0.2)
+    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    assert "azsp_conv3x3_split" in inf.evaluator_path(9, "cuda")
+    x = (torch.rand(200, 17, 9, 9, generator=torch.Generator().manual_seed(1)) > 0.6).float()
+    ps, vs = [t.cpu().clone() for t in inf(x.cuda())]
+    assert getattr(inf, "_split", None) is not None, "the split tower did not run"
+    inf.use_split_tower = False
+    pl, vl = [t.cpu().clone() for t in inf(x.cuda())]
+    with torch.no_grad():
+        lg, v64 = net.double()(x.double())
+    p64 = torch.softmax(lg, -1)
+    d = dict(filters=filters, split_vs_fp64=((ps.double() - p64).abs().max().item(), (vs.double() - v64.squeeze(1)).abs().max().item()),
+             library_vs_fp64=((pl.double() - p64).abs().max().item(), (vl.double() - v64.squeeze(1)).abs().max().item()))
+    print(json.dumps(d))
+    assert d["split_vs_fp64"][0] <= 2e-5 and d["split_vs_fp64"][1] <= 2e-5, d
+
+
+from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet  # noqa: E402
