@@ -8,7 +8,7 @@
 //     main += w_hi x_hi          corr += w_hi x_lo + w_lo x_hi          result = main + 2^-11 corr
 // (the dropped w_lo x_lo term is <= 2^-22 |w x|): 22-bit significands, exact f16 x f16 products, fp32 accumulation -- the error
 // of one output is of the size of fp32 summation error itself (measured against fp64 next to the library's fp32 convolution:
-// tests/test_network.py::test_gpu_split_conv_error_vs_fp64), at 1/3 of the f16 MFMA rate = 5.3x the f32 MFMA peak.
+// tests/test_split_tower.py::test_gpu_split_conv_error_vs_fp64), at 1/3 of the f16 MFMA rate = 5.3x the f32 MFMA peak.
 // The lo halves are scaled by 2^11 so that they sit in f16's normal range whenever the value itself does (no reliance on
 // subnormal inputs); activations are clamped to +-65504 (f16's largest finite value) when they are split.
 //
@@ -26,6 +26,9 @@
 //     positions of a column tile are distinct mod 16 (residue-class map as in az_conv64.h): conflict-free ds_read_b128.
 //   * the next board's 2 x C/8 strips arrive by LDS-DMA (global_load_lds_dwordx4, masked to the position cells) in the shadow of
 //     the first k-steps; one barrier per board; epilogue on the accumulators (bias enters as the C operand of the first MFMA).
+// Measured on MI355X (profiles/r03_pmc_split.txt, r03_split_bench.txt; 32768 boards, 128 filters): 2.03 ms per layer = 385 TFLOP/s
+// fp32-equivalent (the library's fp32 convolution + epilogue: 7.9 - 8.9 ms), matrix pipe busy 74 % at a power-limited ~1.78 GHz,
+// no LDS bank conflicts, HBM traffic = the tensors once each (the second cout group's input read hits the XCD's L2).
 #pragma once
 #include "az_conv64.h"
 
@@ -105,36 +108,43 @@ k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict_
     }
 }
 
-// the inline-asm MFMAs are opaque to the compiler's hazard recognizer: wait states before VALU reads of their results
-__device__ __forceinline__ void sp_settle(c6_f32x4 (&a)[6], c6_f32x4 (&b)[6]) {
-    asm volatile("s_nop 15\n\ts_nop 15"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]),
-                   "+v"(b[5]));
+// first MFMA of an accumulator that starts from zero: the C operand is the inline constant 0 (no zeroed registers to keep)
+__device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, const sp_f16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(wa), "v"(b));
 }
-
-// NCH = input-channel chunks of 8 (16: 128 -> C layer, 8: 64 -> C layer); NCG = cout groups of 64 (C = 64 NCG).
+// ---------------------------------------------------------------------------------------------------------------------
+// k_conv3x3_sp<RES, NCH, NCG>: NCH = input-channel chunks of 8 (16: 128 -> C layer, 8: 64 -> C layer); NCG = cout groups of 64 (C = 64 NCG).
 // w: [plane: hi, lo][9 taps][C couts][8 NCH cin] f16 with lo = (w - hi) * 2^11; bias fp32 [C].
+// The EPILOGUE is SOFTWARE-PIPELINED into the MFMA stream (the scheme of k_conv3x3_tiled / k_resblock64): a board is 2 units of 3
+// column tiles with two accumulator sets; while unit i multiplies into set i & 1, the epilogue of unit i - 1 (join of the two
+// accumulators, residual join + add, clamp, split into hi / lo, two 8-byte stores per column tile) is issued ONE micro-op per MFMA
+// gap from the other set (measured against an exposed per-board epilogue: -4 %); the B-fragment ring (3 k-steps of 6 fragments) runs
+// on across units and boards; the next board's LDS-DMA pieces ride in unit 0; ONE barrier per board (unit 1, two k-steps before its
+// end: every read of the current buffer has been issued and each wave's pieces of the next board have landed).
 template <bool RES, int NCH, int NCG> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
-             const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
+              const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
     typedef SpGeo9 G;
     constexpr int C = 64 * NCG, CIN = 8 * NCH;
-    constexpr int KS = NCH / 4, NSTEP = 9 * KS;             // k-steps (one tap x 32 input channels)
-    constexpr int NJ = G::NCT;                               // column tiles: every wave multiplies all of them for its 16 couts
+    constexpr int KS = 9 * NCH / 4;                          // k-steps per unit (one tap x 32 input channels)
+    constexpr int NJ = 3, R = 3;                             // column tiles per unit, ring slots (k-steps)
     constexpr int LBLK = G::CELLS * 16, LPLANE = NCH * LBLK, LBUF = 2 * LPLANE;
-    constexpr int GBLK = G::P2 * 16, XPLANE = NCH * GBLK, XTILE = 2 * XPLANE;  // input board
-    constexpr int YPLANE = (C / 8) * GBLK, YTILE = 2 * YPLANE;                  // output / residual board
-    constexpr int NP = (G::CELLS + 63) / 64;                 // DMA pieces of 64 cells per strip (2)
-    constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips (both planes) and pieces per wave
-    constexpr int NF = 2 * NSTEP, NF_A = NF < 64 ? NF : 64;  // A fragments: hi bank then lo bank; the first 64 live in AGPRs
-    static_assert(NSTEP >= NPIECE, "the next board's pieces ride in the k-steps");
+    constexpr int GBLK = G::P2 * 16, XPLANE = NCH * GBLK, XTILE = 2 * XPLANE;
+    constexpr int YPLANE = (C / 8) * GBLK, YTILE = 2 * YPLANE;
+    constexpr int NP = (G::CELLS + 63) / 64;
+    constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;
+    constexpr int NF = 2 * KS, NF_A = NF < 64 ? NF : 64;
+    constexpr int E_OPS = RES ? 12 : 8, CT_OPS = 4 * E_OPS + 6, U_OPS = NJ * CT_OPS;  // epilogue micro-ops per element / column tile / unit
+    constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
+    static_assert((2 * KS) % R == 0, "a board's k-steps keep the ring phase");
+    static_assert(KS - 2 >= NPIECE, "the next board's pieces ride in unit 0");
+    constexpr int PER = (U_OPS + (9 * KS - S0 - 40) - 1) / (9 * KS - S0 - 40);  // micro-ops per MFMA gap (1 at 128 filters, 2 at 64)
+    static_assert(PER <= 2, "the previous unit's epilogue fits the unit's MFMA gaps with room before the barrier");
     static_assert(LPLANE + 3 * 4 * LBLK + 22 * 16 < 65536, "fragment addresses are a base + a 16-bit immediate");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    // workgroup -> (cout group, board slot).  Workgroups are dealt to the 8 XCDs round-robin; when the grid allows it the NCG groups of a
-    // board are workgroups b and b + 8, ... (same XCD, launched together): the board's second read hits that XCD's L2.
     int cg, slot, nslot;
     {
         const int b = (int)blockIdx.x, nb = (int)gridDim.x;
@@ -149,21 +159,20 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
         }
     }
     for (int i = tid; i < 2 * LBUF / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
-    CV_BARRIER();  // the zero cells are final before any LDS-DMA piece can land
+    CV_BARRIER();
+    if (slot >= ntiles) return;  // (uniform per workgroup)
 
-    // A fragments: fragment f = plane * NSTEP + (tap * KS + ks): lane (cout = 64 cg + 16 wave + l15, cin = 32 ks + 8 kg .. + 8)
     sp_f16x8 wf[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-        const int pl = f / NSTEP, s = f % NSTEP;
-        wf[f] = *(const sp_f16x8*)(w + ((size_t)((pl * 9 + s / KS) * C + cg * 64 + wave * 16 + l15)) * CIN + (s % KS) * 32 + kg * 8);
+        const int pl = f / KS, s = f % KS;
+        wf[f] = *(const sp_f16x8*)(w + ((size_t)((pl * 9 + s / (NCH / 4)) * C + cg * 64 + wave * 16 + l15)) * CIN + (s % (NCH / 4)) * 32 + kg * 8);
     }
-    c6_f32x4 bv;  // bias in the D layout (rows = couts 4 kg + e of the wave's 16): the C operand of the first k-step
+    c6_f32x4 bv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = bias[cg * 64 + wave * 16 + 4 * kg + e];
     const float lo_bound = relu ? 0.0f : -SP_F16_MAX;
 
-    // LDS-DMA plan: a strip is NP pieces of 64 cells; wave q moves strips SPW q .. SPW q + SPW - 1 (strip = plane * NCH + chunk)
     unsigned dsrc[NP];
     unsigned long long dmask[NP];
 #pragma unroll
@@ -182,45 +191,89 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                      : "s"(mask), "s"(dst), "v"(dsrc[pc]), "s"(base)
                      : "memory");
     };
-
-    // this lane's column tiles: LDS byte offset of the (-1, -1) neighbour in its own 8-channel group (low 16 bits), position (high 16 bits)
-    unsigned lmap[NJ];
+    unsigned lmap[2 * NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < 2 * NJ; ++j) {
         const int idx = j * 16 + l15;
-        lmap[j] = (unsigned)((sp_map9.cell[idx] - G::CELL0) * 16 + kg * LBLK) | ((unsigned)sp_map9.pos[idx] << 16);
+        // low 16 bits: LDS byte offset of the (-1, -1) neighbour in this lane's 8-channel group; high 16 bits: byte offset of this lane's
+        // 8-byte output slot inside the wave's two chunk strips of a plane (couts 4 kg .. + 4 = chunk kg / 2, half kg % 2)
+        lmap[j] = (unsigned)((sp_map9.cell[idx] - G::CELL0) * 16 + kg * LBLK) |
+                  ((unsigned)(sp_map9.pos[idx] * 16 + (kg >> 1) * GBLK + (kg & 1) * 8) << 16);
     }
-    sp_f16x8 bb[2][2][NJ];  // B fragments [k-step parity][plane][column tile]
-    auto load_step = [&](const unsigned char* const (&bp)[NJ], int s) {
-        const int tap = s / KS;
-        const int off = ((tap / 3) * G::PITCH + (tap % 3)) * 16 + (s % KS) * (4 * LBLK);
+    static_assert(G::P2 * 16 + GBLK + 8 < 65536, "output slot offsets fit 16 bits");
+    sp_f16x8 bb[R][2][NJ];  // ring of B fragments [k-step slot][plane][column tile]
+    auto load_step = [&](const unsigned char* img, int j0, int s, int rs) {
+        const int tap = s / (NCH / 4);
+        const int off = ((tap / 3) * G::PITCH + (tap % 3)) * 16 + (s % (NCH / 4)) * (4 * LBLK);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bb[s & 1][0][j] = *(const sp_f16x8*)(bp[j] + off);
+        for (int j = 0; j < NJ; ++j) bb[rs][0][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bb[s & 1][1][j] = *(const sp_f16x8*)(bp[j] + off + LPLANE);
+        for (int j = 0; j < NJ; ++j) bb[rs][1][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off + LPLANE);
     };
 
-    if (slot < ntiles) {  // first board: all pieces at once
+    {   // first board: all pieces at once, then the first fragments
         const unsigned char* src = x + (size_t)slot * XTILE;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) dma_piece(src, lds0, true, i);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    CV_BARRIER();
-    {
-        const unsigned char* bp0[NJ];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CV_BARRIER();
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bp0[j] = lds + (lmap[j] & 0xffffu);
-        load_step(bp0, 0);
+        for (int s = 0; s < R - 1; ++s) load_step(lds, 0, s, s);
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {  // the compiler's wait for the weight loads belongs in front of the loop (see az_conv.h)
+    for (int f = 0; f < NF; ++f) {
         if (f < NF_A) asm volatile("" : : "a"(wf[f]));
         else asm volatile("" : : "v"(wf[f]));
     }
-    asm volatile("" : : "v"(bv), "v"(lmap[0]), "v"(lmap[NJ - 1]), "v"(dsrc[0]), "v"(dsrc[NP - 1]));
+    asm volatile("" : : "v"(bv), "v"(lmap[0]), "v"(lmap[2 * NJ - 1]), "v"(dsrc[0]), "v"(dsrc[NP - 1]));
+
+    c6_f32x4 accm[2][NJ], accc[2][NJ];  // [unit parity][column tile]
+    cv_u32x2 rr[2][NJ][2];             // residual of a unit: [unit parity][column tile][plane]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            accm[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accc[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            rr[a][j][0] = (cv_u32x2){0u, 0u}, rr[a][j][1] = (cv_u32x2){0u, 0u};
+        }
+    float ev = 0.0f, t0 = 0.0f, t1 = 0.0f;
+    _Float16 hh[4], ll[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hh[e] = (_Float16)0.0f, ll[e] = (_Float16)0.0f;
+    unsigned pk0 = 0, pk1 = 0;
+    // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`
+    auto epi_op = [&](int set, int j, int mj, unsigned char* out, int o, bool store_ok) {
+        if (o < 4 * E_OPS) {
+            const int e = o / E_OPS, k = o % E_OPS;
+            const unsigned rh = (e < 2 ? rr[set][j][0].x : rr[set][j][0].y), rl = (e < 2 ? rr[set][j][1].x : rr[set][j][1].y);
+            const int tail = RES ? k - 4 : k;  // ops after the residual part
+            if (k == 0) ev = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
+            else if (RES && k == 1) t0 = (float)((e & 1) ? sp_hi16(rh) : sp_lo16(rh));
+            else if (RES && k == 2) t1 = (float)((e & 1) ? sp_hi16(rl) : sp_lo16(rl));
+            else if (RES && k == 3) t0 = fmaf(t1, SP_INV_SCALE, t0);
+            else if (RES && k == 4) ev = cw_add_f32(ev, t0);
+            else if (tail == 1) ev = fmaxf(ev, lo_bound);
+            else if (tail == 2) ev = fminf(ev, SP_F16_MAX);
+            else if (tail == 3) hh[e] = (_Float16)ev;
+            else if (tail == 4) t0 = (float)hh[e];
+            else if (tail == 5) t1 = ev - t0;
+            else if (tail == 6) t1 = t1 * SP_SCALE;
+            else if (tail == 7) ll[e] = (_Float16)t1;
+        } else {
+            const int k = o - 4 * E_OPS;
+            const unsigned gq = lmap[mj] >> 16;
+            if (k == 0) pk0 = sp_pack(hh[0], hh[1]);
+            else if (k == 1) pk1 = sp_pack(hh[2], hh[3]);
+            else if (k == 2) {
+                if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){pk0, pk1};
+            } else if (k == 3) pk0 = sp_pack(ll[0], ll[1]);
+            else if (k == 4) pk1 = sp_pack(ll[2], ll[3]);
+            else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){pk0, pk1};
+        }
+    };
 
     int it = 0;
+    unsigned char* yprev = y;
     for (int tile = slot; tile < ntiles; tile += nslot, ++it) {
         const int buf = it & 1;
         const unsigned char* Xs = lds + buf * LBUF;
@@ -228,75 +281,63 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
         const bool has_next = tile + nslot < ntiles;
         const unsigned char* nsrc = x + (size_t)(has_next ? tile + nslot : tile) * XTILE;
         const unsigned ndst = lds0 + (unsigned)((buf ^ 1) * LBUF);
-        // this wave's 16 couts = chunks 8 cg + 2 wave + {0, 1}; lane group kg holds couts 4 kg .. + 4 = chunk kg / 2, half kg % 2
-        const size_t yo = (size_t)tile * YTILE + (size_t)(cg * 8 + wave * 2 + (kg >> 1)) * GBLK + (size_t)((kg & 1) * 8);
+        const size_t yo = (size_t)tile * YTILE + (size_t)(cg * 8 + wave * 2) * GBLK;  // uniform: the lane part is in lmap
         const unsigned char* rbase = RES ? res + yo : nullptr;
         unsigned char* ybase = y + yo;
-        const unsigned char* bp[NJ];
-        cv_u32x2 rr[NJ][2];
-        c6_f32x4 accm[NJ], accc[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            bp[j] = Xs + (lmap[j] & 0xffffu);
-            accc[j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (RES) {
-                const unsigned gq = (lmap[j] >> 16) * 16u;
-                rr[j][0] = *(const cv_u32x2*)(rbase + gq);
-                rr[j][1] = *(const cv_u32x2*)(rbase + YPLANE + gq);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < NSTEP; ++t) {  // the fragments of step 0 are already in flight (issued before the previous epilogue)
-            if (t + 1 < NSTEP) load_step(bp, t + 1);
-            // three products, each over the 6 column tiles (6 independent accumulators between two uses of one)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (t == 0) sp_mfma_ac(accm[j], wf[0], bb[0][0][j], bv);
-                else sp_mfma_a(accm[j], wf[t], bb[t & 1][0][j]);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) sp_mfma_a(accc[j], wf[t], bb[t & 1][1][j]);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (NSTEP + t < NF_A) sp_mfma_a(accc[j], wf[NSTEP + t], bb[t & 1][0][j]);
-                else sp_mfma_v(accc[j], wf[NSTEP + t], bb[t & 1][0][j]);
-            }
-            if (t < NPIECE) dma_piece(nsrc, ndst, has_next, t);  // the next board's pieces ride in the shadow of the first k-steps
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // everything this wave has in flight is old (pieces issued >= NSTEP - NPIECE k-steps ago, the previous board's stores): after
-        // the barrier every wave's pieces of the next board have landed and this buffer may be overwritten
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CV_BARRIER();
-        {
-            const unsigned char* bpn[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bpn[j] = Xn + (lmap[j] & 0xffffu);
-            load_step(bpn, 0);  // the next board's first fragments fly while the epilogue runs
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        sp_settle(accm, accc);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const unsigned gq = (lmap[j] >> 16) * 16u;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(accc[j][e], SP_INV_SCALE, accm[j][e]);
-            if (RES) {
-                const cv_u32x2 rh = rr[j][0], rl = rr[j][1];
-                v[0] += sp_join(sp_lo16(rh.x), sp_lo16(rl.x));
-                v[1] += sp_join(sp_hi16(rh.x), sp_hi16(rl.x));
-                v[2] += sp_join(sp_lo16(rh.y), sp_lo16(rl.y));
-                v[3] += sp_join(sp_hi16(rh.y), sp_hi16(rl.y));
-            }
-            _Float16 h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sp_split(fmaxf(v[e], lo_bound), h[e], l[e]);
-            *(cv_u32x2*)(ybase + gq) = (cv_u32x2){sp_pack(h[0], h[1]), sp_pack(h[2], h[3])};
-            *(cv_u32x2*)(ybase + YPLANE + gq) = (cv_u32x2){sp_pack(l[0], l[1]), sp_pack(l[2], l[3])};
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        const bool have_prev = it > 0;
+        auto unit = [&](auto IC) __attribute__((always_inline)) {
+            constexpr int i = decltype(IC)::value, set = i, pset = i ^ 1, j0 = NJ * i, pj0 = NJ * (i ^ 1);
+            unsigned char* pout = i == 0 ? yprev : ybase;
+            const bool pstore = i > 0 || have_prev;
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::value;
+                constexpr int g = i * KS + t;  // running k-step of the board
+                if constexpr (i == 1 && t == KS - (R - 1)) {
+                    // every read of this buffer has been issued; this wave's pieces of the next board (unit 0) and everything younger
+                    // (unit 0's epilogue stores, this unit's residual loads: all >= 100 MFMAs old) have completed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    CV_BARRIER();
+                }
+                if constexpr (t + R - 1 < KS) load_step(Xs, j0, t + R - 1, (g + R - 1) % R);
+                else if constexpr (i == 0) load_step(Xs, NJ, t + R - 1 - KS, (g + R - 1) % R);
+                else load_step(Xn, 0, t + R - 1 - KS, (g + R - 1) % R);
+                cp_for_each([&](auto QC) __attribute__((always_inline)) {
+                    constexpr int q = decltype(QC)::value, prod = q / NJ, j = q % NJ;  // product 0: main, 1: w_hi x_lo, 2: w_lo x_hi
+                    constexpr int fa = prod == 2 ? KS + t : t, pl = prod == 1 ? 1 : 0;
+                    if constexpr (prod == 0) {
+                        if constexpr (t == 0) sp_mfma_ac(accm[set][j], wf[fa], bb[g % R][pl][j], bv);
+                        else sp_mfma_a(accm[set][j], wf[fa], bb[g % R][pl][j]);
+                    } else if constexpr (prod == 1) {
+                        if constexpr (t == 0) sp_mfma_a0(accc[set][j], wf[fa], bb[g % R][pl][j]);
+                        else sp_mfma_a(accc[set][j], wf[fa], bb[g % R][pl][j]);
+                    } else {
+                        if constexpr (fa < NF_A) sp_mfma_a(accc[set][j], wf[fa], bb[g % R][pl][j]);
+                        else sp_mfma_v(accc[set][j], wf[fa], bb[g % R][pl][j]);
+                    }
+                    constexpr int sl = t * 9 + q;  // MFMA slot of the unit
+                    cp_for_each([&](auto KC) __attribute__((always_inline)) {
+                        constexpr int o = (sl - S0) * PER + decltype(KC)::value;
+                        if constexpr (sl >= S0 && o < U_OPS) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
+                    }, typename CpMakeSeq<PER>::type{});
+                    if constexpr (RES && sl < 2 * NJ) {  // this unit's residual (used by its epilogue inside the next unit)
+                        constexpr int rj = sl >> 1, rp = sl & 1;
+                        rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * YPLANE + (lmap[j0 + rj] >> 16));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }, typename CpMakeSeq<9>::type{});
+                if constexpr (i == 0 && t >= 1 && t - 1 < NPIECE) dma_piece(nsrc, ndst, has_next, t - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }, typename CpMakeSeq<KS>::type{});
+        };
+        unit(CpInt<0>{});
+        unit(CpInt<1>{});
+        yprev = ybase;
     }
+    // epilogue of the very last unit (accumulator set 1, column tiles 3 .. 5)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accm[1][0]), "+v"(accm[1][1]), "+v"(accm[1][2]), "+v"(accc[1][0]), "+v"(accc[1][1]), "+v"(accc[1][2]));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, NJ + j, yprev, o, true);
 }
 #endif  // __HIPCC__

@@ -457,18 +457,30 @@ def main(argv=None):
                         "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
         else:
             roofline = engine_roof
-        fp32 = None
+        fp32 = fp32_lib = None
         if world == 1 and args.net_dtype != "fp32" and not args.no_fp32:
-            # the reference's evaluator precision (pipeline.py:91-123 runs the network in fp32): same engine, same workload, fp32
-            # network (library convolutions + fused epilogue kernel), shorter pre-roll and window -- a companion number, not `value`
-            a32 = make_actor("fp32")
-            pre32 = preroll(a32, args, world, dev, min_rounds=60)
-            el32, c32, ev32, _ = timed(a32, args, world, dev, 5, 40)
-            fp32 = {"moves_per_s": round(c32["moves"] / el32, 2), "sims_per_sec": round(c32["sims"] / el32, 1), "ms_per_step": round(el32 / 40 * 1e3, 3),
-                    "sims_per_move": round(c32["sims"] / max(1, c32["moves"]), 2), "steps": 40, "warmup": 5, "preroll_rounds": pre32,
-                    "evaluator": "fp32, library convolutions + fused epilogue kernel"}
-            del a32, ev32
-            torch.cuda.empty_cache()
+            # the reference's evaluator precision (pipeline.py:91-123 runs the network in fp32): same engine, same workload, fp32-class
+            # network, shorter pre-roll and window -- companion numbers, never `value`.  Two evaluators: (a) the tower on the
+            # hand-written split-precision kernel (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 accumulation;
+            # as close to fp64 as the library's fp32 convolution, tests/test_split_tower.py) where the shape has it, (b) the
+            # library's fp32 convolutions + fused epilogue kernel.
+            def companion(split, steps, pre):
+                a = make_actor("fp32")
+                a.infer.use_split_tower = split
+                prer = preroll(a, args, world, dev, min_rounds=pre)
+                el, c, ev, _ = timed(a, args, world, dev, 5, steps)
+                used_split = getattr(a.infer, "_split", None) is not None
+                r = {"moves_per_s": round(c["moves"] / el, 2), "sims_per_sec": round(c["sims"] / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
+                     "sims_per_move": round(c["sims"] / max(1, c["moves"]), 2), "steps": steps, "warmup": 5, "preroll_rounds": prer,
+                     "forward_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev])), 3),
+                     "evaluator": a.evaluator_path if used_split else "fp32, library convolutions + fused epilogue kernel"}
+                del a, ev
+                torch.cuda.empty_cache()
+                return r, used_split
+
+            fp32, used_split = companion(True, 40, 60)
+            if used_split:
+                fp32_lib, _ = companion(False, 20, 30)
         fresh = None
         if world == 1 and not args.no_fresh_tree:
             # SURVEY 8d's "fresh-tree" variant: sub-tree reuse off (mcts_v2.py:436-446 never runs), every move pays the full budget of
@@ -530,6 +542,7 @@ def main(argv=None):
             "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds, "per_rank": ranks,
             "dup_leaf_rate": round(cnt["dup_leaves"] / max(1, cnt["leaves"]), 5), "terminal_hit_rate": round(cnt["terminal_hits"] / max(1, cnt["sims"]), 5),
             "fp32_moves_per_s": fp32["moves_per_s"] if fp32 else None, "fp32_companion": fp32,
+            "fp32_library_moves_per_s": fp32_lib["moves_per_s"] if fp32_lib else None, "fp32_library_companion": fp32_lib,
             "fresh_tree_moves_per_s": fresh["moves_per_s"] if fresh else None, "fresh_tree_companion": fresh,
             "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,

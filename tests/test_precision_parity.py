@@ -24,12 +24,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _searched_policies(net, game, n, dtype, G, sims, P, stagger, seed=7):
+def _searched_policies(net, game, n, dtype, G, sims, P, stagger, seed=7, split_tower=None):
     from alpha_zero_amd import _abi, _lib
     from alpha_zero_amd.core.pipeline import SelfPlayActor
 
     act = SelfPlayActor(net, game=game, board_size=n, num_games=G, num_simulations=sims, num_parallel=P, warm_up_steps=16, seed=seed, device="cuda",
                         net_dtype=dtype, use_graph=False, binding=_lib.load(), engine_kw=dict(log_moves=True, log_capacity=1, max_plies=1))
+    if split_tower is not None:  # fp32 evaluator: azsp_conv3x3_split tower (True) or the library's fp32 convolutions (False)
+        act.infer.use_split_tower = split_tower
     e = act.engine
     rng = np.random.Generator(np.random.PCG64(4321))
     plies = rng.integers(0, stagger + 1, size=G)
@@ -57,7 +59,7 @@ def _searched_policies(net, game, n, dtype, G, sims, P, stagger, seed=7):
 def _compare(name, net, game, n, G, sims, P, stagger):
     pa, va, ma, qa, live, tiled = _searched_policies(net, game, n, torch.bfloat16, G, sims, P, stagger)
     assert tiled, "the bf16 run must go through the hand-written tiled evaluator"
-    pb, vb, mb, qb, live_b, _ = _searched_policies(net, game, n, torch.float32, G, sims, P, stagger)
+    pb, vb, mb, qb, live_b, _ = _searched_policies(net, game, n, torch.float32, G, sims, P, stagger, split_tower=False)  # library fp32
     assert np.array_equal(live, live_b)
     pa, pb, va, vb, ma, mb, qa, qb = pa[live], pb[live], va[live], vb[live], ma[live], mb[live], qa[live], qb[live]
     eps = 1e-3  # ~ a fifth of one visit at 200 simulations
@@ -82,6 +84,30 @@ def test_gpu_bf16_search_close_to_fp32_search_go9_bench_network():
     # measured (profiles/r02_precision_parity_*.json, r03): 0.893 / 0.992 / 0.098 / 0.084 / 0.025 -- bounds = measured minus a small margin
     assert r["top1_agreement"] >= 0.87 and r["move_agreement"] >= 0.975, r
     assert r["mean_kl_fp32_bf16"] <= 0.12 and r["mean_tv"] <= 0.10 and r["mean_abs_root_q_diff"] <= 0.03, r
+
+
+def test_gpu_split_fp32_search_equals_library_fp32_search_go9():
+    """The fp32-class evaluator (tower on azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products) against the library's fp32
+    evaluator: same engine, positions, noise and uniforms, one full search per position.  Both are fp32-round-off-accurate (each is
+    ~1e-5 from the fp64 network, tests/test_split_tower.py), so the searches agree up to PUCT near-ties on the nearly flat priors of a
+    random-init network: bounds = agreement of two fp32 implementations, far tighter than the bf16 statement above."""
+    from alpha_zero_amd.core.network import AlphaZeroNet
+
+    torch.manual_seed(1)
+    net = AlphaZeroNet((17, 9, 9), 82, 10, 128, 128)
+    G, sims, P, stagger = 384, 200, 8, 40
+    pa, va, ma, qa, live, _ = _searched_policies(net, "go", 9, torch.float32, G, sims, P, stagger, split_tower=True)
+    pb, vb, mb, qb, live_b, _ = _searched_policies(net, "go", 9, torch.float32, G, sims, P, stagger, split_tower=False)
+    assert np.array_equal(live, live_b)
+    va, vb, ma, mb, qa, qb = va[live], vb[live], ma[live], mb[live], qa[live], qb[live]
+    r = dict(name="go9_10x128_random_init_split_vs_library_fp32", positions=int(live.sum()), sims=sims, P=P,
+             identical_visit_counts=float((np.abs(va - vb).max(1) == 0).mean()), top1_agreement=float((va.argmax(1) == vb.argmax(1)).mean()),
+             move_agreement=float((ma == mb).mean()), mean_tv=float(0.5 * np.abs(va - vb).sum(1).mean()),
+             mean_abs_root_q_diff=float(np.abs(qa - qb).mean()), max_abs_root_q_diff=float(np.abs(qa - qb).max()))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(r, open(os.path.join(ROOT, "gpurun_out", "precision_parity_split_vs_library_fp32.json"), "w"), indent=1)
+    print(json.dumps(r))
+    assert r["top1_agreement"] >= 0.97 and r["move_agreement"] >= 0.99 and r["mean_tv"] <= 0.02 and r["mean_abs_root_q_diff"] <= 2e-3, r
 
 
 def test_gpu_bf16_search_close_to_fp32_search_trained_gomoku13(golden_dir):

@@ -109,7 +109,8 @@ def test_split_tower_clamps_at_f16_range_host_twin():
 def test_gpu_split_conv_error_vs_fp64(boards, C):
     """k_conv3x3_sp vs fp64, next to the library's fp32 convolution on the same inputs.  Board counts around one / two boards per
     workgroup slot (128 slots at 128 filters, 256 at 64) exercise the first-board, has-next and last-board paths of the persistent loop.
-    Bound: max |y - y64| <= 4e-6 max|y64| and at most 8x the library's own fp32 error + 1e-6 (measured: see profiles/r03_split_*)."""
+    Bound: max |y - y64| <= 2e-6 max|y64| and at most 2x the library's own fp32 error + 2e-7 (measured on MI355X over the 42 cases,
+    profiles/r03_split_conv_error.jsonl: kernel max 6.5e-7 / mean 4.5e-7, library fp32 max 7.9e-7 / mean 5.6e-7)."""
     from alpha_zero_amd import _lib
 
     bnd = _lib.load()
@@ -133,7 +134,7 @@ def test_gpu_split_conv_error_vs_fp64(boards, C):
             f.write(json.dumps(o) + "\n")
     for o in out:
         assert o["layout_roundtrip_rel"] <= 2.0 ** -21, o
-        assert o["err"] <= 4e-6 and o["err"] <= 8 * o["library_fp32_err"] + 1e-6, o
+        assert o["err"] <= 2e-6 and o["err"] <= 2 * o["library_fp32_err"] + 2e-7, o
 
 
 @pytest.mark.gpu
@@ -151,15 +152,17 @@ def test_gpu_split_conv_small_and_large_magnitudes():
         ref = _ref64(x, r, w, b, 1)
         res[name] = (y.double() - ref).abs().max().item() / ref.abs().max().item()
     print(json.dumps(res))
-    assert res["1e-2"] <= 4e-6 and res["1e2"] <= 4e-6, res
-    assert res["1e-4"] <= 1e-4, res  # inputs of 1e-4 x 3e-3 are below every f16 normal: graceful, not exact
+    # measured: 6.7e-7 / 5.7e-7 / 5.1e-7 -- the f16 MFMA takes subnormal hi halves as they are, the scaled lo halves carry the rest
+    assert max(res.values()) <= 2e-6, res
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("filters", [128, 64])
 def test_gpu_fp32_network_on_the_split_tower(filters):
     """The whole fp32 evaluator with the tower on azsp_conv3x3_split vs the same InferenceNet on library convolutions vs the fp64
-    module: priors / values within 2e-5 of fp64 (the library path's own distance to fp64 is reported beside it)."""
+    module (10 blocks, non-trivial BatchNorm statistics: round-off is amplified through the depth for both fp32 paths).  Bound: the
+    split tower is at most 1.5x + 1e-5 as far from fp64 as the library path, and within 2e-4 absolutely (measured on MI355X, r03:
+    priors 4.5e-5 vs 9.3e-5 (library) at 128 filters, 1.5e-5 vs 2.6e-5 at 64; values 2.9e-5 vs 4.0e-5 and 3.8e-5 vs 8.4e-5)."""
     from alpha_zero_amd import _lib
 
     torch.manual_seed(3)
@@ -181,7 +184,10 @@ def test_gpu_fp32_network_on_the_split_tower(filters):
     d = dict(filters=filters, split_vs_fp64=((ps.double() - p64).abs().max().item(), (vs.double() - v64.squeeze(1)).abs().max().item()),
              library_vs_fp64=((pl.double() - p64).abs().max().item(), (vl.double() - v64.squeeze(1)).abs().max().item()))
     print(json.dumps(d))
-    assert d["split_vs_fp64"][0] <= 2e-5 and d["split_vs_fp64"][1] <= 2e-5, d
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(d, open(os.path.join(ROOT, "gpurun_out", f"split_network_error_{filters}.json"), "w"))
+    for k in (0, 1):
+        assert d["split_vs_fp64"][k] <= 2e-4 and d["split_vs_fp64"][k] <= 1.5 * d["library_vs_fp64"][k] + 1e-5, d
 
 
 from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet  # noqa: E402
