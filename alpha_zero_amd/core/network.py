@@ -114,6 +114,7 @@ class InferenceNet(nn.Module):
         self.use_tiled_tower = True
         self.use_fused_block = True  # 64-filter towers: azsp_resblock_tiled instead of two azsp_conv3x3_tiled launches per block
         self.use_split_tower = True  # fp32 networks: azsp_conv3x3_split (hi + lo f16 pairs, three MFMA products) instead of the library
+        self.use_split_heads = True  # ... and azsp_split_features / azsp_stem_split / azsp_head_split around it (whole evaluator hand-written)
         self.mf = torch.channels_last if channels_last else torch.contiguous_format
         self.stem_pad = net.conv_block[0].padding[0]
         with torch.no_grad():
@@ -137,6 +138,7 @@ class InferenceNet(nn.Module):
                     return nn.Parameter(torch.stack([hi, lo]).contiguous(), requires_grad=False)
 
                 self.wsp = nn.ParameterList([_split_w(w) for w, _ in convs[1:]])
+                self._split_w = _split_w
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
@@ -147,6 +149,10 @@ class InferenceNet(nn.Module):
                 swp[:, :, : sw.shape[1]] = sw.permute(2, 3, 0, 1).reshape(9, sw.shape[0], sw.shape[1])
                 self.stem_wp = nn.Parameter(swp.to(torch.bfloat16).contiguous(), requires_grad=False)
                 self.stem_b32 = nn.Parameter(convs[0][1].float().contiguous(), requires_grad=False)
+                if dtype == torch.float32:  # azsp_stem_split: [plane][tap][cout][32 in] f16, input channels 17.. zero
+                    sw32 = torch.zeros(sw.shape[0], 32, 3, 3)
+                    sw32[:, : sw.shape[1]] = sw
+                    self.stem_wsp = self._split_w(sw32)
             pw, pb = _fold(net.policy_head[0], net.policy_head[1])
             vw, vb = _fold(net.value_head[0], net.value_head[1])
             self.npol, self.nval = pw.shape[0], vw.shape[0]
@@ -176,6 +182,12 @@ class InferenceNet(nn.Module):
             self.fc_w1, self.fc_b1 = _pad_w(net.value_head[4].weight), _pad_v(net.value_head[4].bias)
             self.fc_w2, self.fc_b2 = _pad_v(net.value_head[6].weight), float(net.value_head[6].bias.item())
             self.num_actions, self.fc_width = net.policy_head[4].weight.shape[0], net.value_head[4].weight.shape[0]
+            if dtype == torch.float32:  # azsp_head_split: fp32 Linear weights transposed [inputs][outputs]
+                self.pol_fc_wt = nn.Parameter(net.policy_head[4].weight.float().t().contiguous(), requires_grad=False)
+                self.val_fc1_wt = nn.Parameter(net.value_head[4].weight.float().t().contiguous(), requires_grad=False)
+                self.pol_fc_b32 = nn.Parameter(net.policy_head[4].bias.float().contiguous(), requires_grad=False)
+                self.val_fc1_b32 = nn.Parameter(net.value_head[4].bias.float().contiguous(), requires_grad=False)
+                self.val_fc2_w32 = nn.Parameter(net.value_head[6].weight.float().reshape(-1).contiguous(), requires_grad=False)
             self.use_fused_fc = True
 
     def _tiled_tower_ok(self, x):
@@ -192,6 +204,60 @@ class InferenceNet(nn.Module):
         return (self.binding is not None and self.use_fused_conv and self.use_split_tower and x.is_cuda and x.dtype == torch.float32
                 and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 9))
                 and x.is_contiguous(memory_format=torch.channels_last))
+
+    def supports_split_features(self, board_size, device):
+        """True when the WHOLE fp32 evaluator runs on the split-precision kernels (azsp_split_features -> azsp_stem_split ->
+        azsp_conv3x3_split tower -> azsp_head_split): fp32 networks, 9x9 Go with 128 or 64 filters (pad-1 stem)."""
+        return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.use_fused_conv
+                and self.use_split_tower and self.use_split_heads and self.stem_ok and self.npol + self.nval == 3
+                and (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 9, 1)))
+
+    @torch.no_grad()
+    def forward_split(self, planes, priors_out=None, values_out=None):
+        """planes: observation planes [B,17,N,N] fp32, contiguous NCHW (the engine's AZSP_FEAT_F32 features).  The whole evaluator at
+        the reference's precision class (pipeline.py:91-123 evaluates in fp32) on hand-written kernels."""
+        import ctypes
+
+        dll, ck = self.binding.dll, self._ck
+        st = ctypes.c_void_p(torch.cuda.current_stream(planes.device).cuda_stream) if planes.is_cuda else None  # (host twin: CPU tensors)
+        B, cin, n, _ = planes.shape
+        C, S = self.filters, n
+        nb, nf = dll.azsp_split_bytes(B, S, C) // 2, dll.azsp_split_bytes(B, S, 32) // 2
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (nb, str(planes.device))
+        if key not in cache:
+            cache.clear()
+            cache[key] = [torch.zeros(nb, dtype=torch.float16, device=planes.device) for _ in range(3)]
+        fkey = ("feat", nf, B, str(planes.device))
+        if fkey not in cache:
+            for k in [k for k in cache if k[0] == "feat"]:
+                del cache[k]
+            cache[fkey] = (torch.zeros(nf, dtype=torch.float16, device=planes.device),
+                           torch.empty((B, self.num_actions), dtype=torch.float32, device=planes.device),
+                           torch.empty((B,), dtype=torch.float32, device=planes.device))
+        a, m, o = cache[key]
+        feat, pri_buf, v_buf = cache[fkey]
+        self._split = (a, m, o, B)
+        ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, st), "azsp_split_features")
+        ck(dll.azsp_stem_split(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_stem_split")
+        a = self._blocks_split(a, m, o, B, S, C, st)
+        pri = priors_out if priors_out is not None else pri_buf
+        v = values_out if values_out is not None else v_buf
+        ck(dll.azsp_head_split(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), self.pol_fc_wt.data_ptr(), self.pol_fc_b32.data_ptr(),
+                               self.val_fc1_wt.data_ptr(), self.val_fc1_b32.data_ptr(), self.val_fc2_w32.data_ptr(), ctypes.c_float(self.fc_b2),
+                               pri.data_ptr(), v.data_ptr(), B, S, C, self.num_actions, self.fc_width, self.npol, st), "azsp_head_split")
+        return (pri, v) if priors_out is not None else (pri.clone(), v.clone())  # the cached output buffers are reused by the next call
+
+    def _blocks_split(self, a, m, o, B, S, C, st):
+        """All residual blocks on split-layout buffers; returns the buffer holding the tower output."""
+        dll, ck = self.binding.dll, self._ck
+        for i in range(self.n_blocks):
+            ck(dll.azsp_conv3x3_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
+               "azsp_conv3x3_split")
+            ck(dll.azsp_conv3x3_split(m.data_ptr(), self.wsp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
+                                      B, S, C, 1, st), "azsp_conv3x3_split")
+            a, o = o, a
+        return a
 
     def _conv(self, x, i, res=None):
         """relu(conv3x3(x) + bias [+ res]) of tower convolution i (0-based) for shapes WITHOUT a hand-written tower kernel: the library
@@ -271,6 +337,9 @@ class InferenceNet(nn.Module):
             s = board_size + 2 * (self.stem_pad - 1)
             if (self.filters, s) in ((128, 9), (64, 17), (64, 9), (256, 19)):
                 return "hand-written tower (azsp_conv3x3_tiled) behind a library stem and heads"
+        if self.supports_split_features(board_size, device):
+            return ("fp32 class, hand-written: split-precision stem / tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, "
+                    "fp32 accumulation) / fp32 heads (libazsp)")
         if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower:
             if (self.filters, board_size + 2 * (self.stem_pad - 1)) in ((128, 9), (64, 9)):
                 return ("fp32 class: hand-written split-precision tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 "
@@ -376,18 +445,15 @@ class InferenceNet(nn.Module):
         a, m, o = cache[key]
         self._split = (a, m, o, B)  # (bench.py replays the tower on the activations of the last forward)
         ck(dll.azsp_split_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_split_layout")
-        for i in range(self.n_blocks):
-            ck(dll.azsp_conv3x3_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
-               "azsp_conv3x3_split")
-            ck(dll.azsp_conv3x3_split(m.data_ptr(), self.wsp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
-                                      B, S, C, 1, st), "azsp_conv3x3_split")
-            a, o = o, a
+        a = self._blocks_split(a, m, o, B, S, C, st)
         ck(dll.azsp_split_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_split_layout")
         return x
 
     @torch.no_grad()
     def forward(self, x, priors_out=None, values_out=None):
         """x: [B,17,N,N] any dtype -> (priors fp32 [B,A], values fp32 [B])."""
+        if x.is_cuda and self.supports_split_features(x.shape[2], x.device):
+            return self.forward_split(x.float().contiguous(), priors_out, values_out)
         x = x.to(self.dtype).contiguous(memory_format=self.mf)
         x = self._epilogue(F.conv2d(x, self.w[0], None, padding=self.stem_pad), self.b[0])
         if self._tiled_tower_ok(x):

@@ -108,12 +108,114 @@ k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict_
     }
 }
 
+// Observation planes [boards][Cin][P2] fp32 (NCHW, what the engine's AZSP_FEAT_F32 features are) -> split layout with 32 channels
+// (4 chunks; channels >= Cin zero) = the stem's input.  One thread per (board, chunk, position), positions fastest.
+__global__ void __launch_bounds__(256)
+k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst, long long nitems, int cin, int p2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nitems) return;
+    const long long b = i / (4 * p2);
+    const int r = (int)(i - b * 4 * p2), c = r / p2, p = r - c * p2;
+    _Float16 h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = 8 * c + e;
+        sp_split(ch < cin ? src[((size_t)b * cin + ch) * p2 + p] : 0.0f, h[e], l[e]);
+    }
+    const size_t plane = (size_t)4 * p2 * 16, so = (size_t)b * 2 * plane + ((size_t)c * p2 + p) * 16;
+    *(cv_u32x4*)(dst + so) = (cv_u32x4){sp_pack(h[0], h[1]), sp_pack(h[2], h[3]), sp_pack(h[4], h[5]), sp_pack(h[6], h[7])};
+    *(cv_u32x4*)(dst + so + plane) = (cv_u32x4){sp_pack(l[0], l[1]), sp_pack(l[2], l[3]), sp_pack(l[4], l[5]), sp_pack(l[6], l[7])};
+}
+
+// Both heads of the network (core/network.py:118-156) in fp32 on the split layout, one pass over the tower output:
+//   head planes  hp[pl][pos] = relu(sum_c hw[pl][c] x[c][pos] + hb[pl])      (the two 1x1 convolutions, BatchNorm folded; pl < 3)
+//   priors = softmax(Wp flatten(hp[0 .. npol)) + bp)       value = tanh(w2 . relu(W1 flatten(hp[npol .. 3)) + b1) + b2)
+// BPB boards per 256-thread workgroup (the fully connected weights, stored TRANSPOSED [inputs][outputs] so that neighbouring threads
+// read neighbouring outputs, are streamed from L2 once per BPB boards); plain fp32 FMAs -- HBM-bound (2 x C x P2 x 2 bytes per board).
+// dynamic LDS: 3 C + BPB (3 P2 + A + F) floats.
+#define SP_HEAD_BPB 4
+__global__ void __launch_bounds__(256)
+k_head_split(const unsigned char* __restrict__ x, const float* __restrict__ hw, const float* __restrict__ hb, const float* __restrict__ wp_t,
+             const float* __restrict__ bp, const float* __restrict__ w1_t, const float* __restrict__ b1, const float* __restrict__ w2, float b2,
+             float* __restrict__ priors, float* __restrict__ values, long long boards, int C, int P2, int A, int F, int npol) {
+    extern __shared__ float sm[];
+    float* ws = sm;                                  // [3][C]
+    float* hp = ws + 3 * C;                          // [BPB][3 P2]
+    float* out = hp + SP_HEAD_BPB * 3 * P2;          // [BPB][A + F]
+    const int tid = threadIdx.x, nch = C / 8;
+    const long long b0 = (long long)blockIdx.x * SP_HEAD_BPB;
+    for (int i = tid; i < 3 * C; i += 256) ws[i] = hw[i];
+    __syncthreads();
+    const size_t plane = (size_t)nch * P2 * 16;
+    for (int it = tid; it < SP_HEAD_BPB * 3 * P2; it += 256) {
+        const int b = it / (3 * P2), r = it - b * 3 * P2, pl = r / P2, pos = r - pl * P2;
+        float acc = 0.0f;
+        if (b0 + b < boards) {
+            acc = hb[pl];
+            const unsigned char* src = x + (size_t)(b0 + b) * 2 * plane + (size_t)pos * 16;
+            const float* wr = ws + pl * C;
+#pragma unroll 4
+            for (int c = 0; c < nch; ++c) {
+                const cv_u32x4 h = *(const cv_u32x4*)(src + (size_t)c * P2 * 16), l = *(const cv_u32x4*)(src + (size_t)c * P2 * 16 + plane);
+                const unsigned hv[4] = {h.x, h.y, h.z, h.w}, lv[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = fmaf(sp_join(sp_lo16(hv[e]), sp_lo16(lv[e])), wr[c * 8 + 2 * e], acc);
+                    acc = fmaf(sp_join(sp_hi16(hv[e]), sp_hi16(lv[e])), wr[c * 8 + 2 * e + 1], acc);
+                }
+            }
+            acc = fmaxf(acc, 0.0f);
+        }
+        hp[it] = acc;
+    }
+    __syncthreads();
+    const int kp = npol * P2, kv = (3 - npol) * P2;
+    for (int o = tid; o < A + F; o += 256) {
+        float acc[SP_HEAD_BPB];
+        const bool pol = o < A;
+        const float* wcol = pol ? wp_t + o : w1_t + (o - A);
+        const int ld = pol ? A : F, kn = pol ? kp : kv, k0 = pol ? 0 : kp;
+        const float bias0 = pol ? bp[o] : b1[o - A];
+#pragma unroll
+        for (int b = 0; b < SP_HEAD_BPB; ++b) acc[b] = bias0;
+        for (int k = 0; k < kn; ++k) {
+            const float wv = wcol[(size_t)k * ld];
+#pragma unroll
+            for (int b = 0; b < SP_HEAD_BPB; ++b) acc[b] = fmaf(hp[b * 3 * P2 + k0 + k], wv, acc[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < SP_HEAD_BPB; ++b) out[b * (A + F) + o] = pol ? acc[b] : fmaxf(acc[b], 0.0f);
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;  // wave w finishes board b0 + w (4 waves = SP_HEAD_BPB boards)
+    if (b0 + wave >= boards) return;
+    const float* o = out + wave * (A + F);
+    float mx = -__builtin_inff();
+    for (int a = lane; a < A; a += 64) mx = fmaxf(mx, o[a]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+    float sum = 0.0f;
+    for (int a = lane; a < A; a += 64) sum += expf(o[a] - mx);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    const float inv = 1.0f / sum;
+    float* prow = priors + (size_t)(b0 + wave) * A;
+    for (int a = lane; a < A; a += 64) prow[a] = expf(o[a] - mx) * inv;
+    float v = 0.0f;
+    for (int f = lane; f < F; f += 64) v = fmaf(o[A + f], w2[f], v);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) values[b0 + wave] = tanhf(v + b2);
+}
+static_assert(SP_HEAD_BPB == 4, "one wave per board in the last phase of k_head_split");
+
 // first MFMA of an accumulator that starts from zero: the C operand is the inline constant 0 (no zeroed registers to keep)
 __device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, const sp_f16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(wa), "v"(b));
 }
 // ---------------------------------------------------------------------------------------------------------------------
-// k_conv3x3_sp<RES, NCH, NCG>: NCH = input-channel chunks of 8 (16: 128 -> C layer, 8: 64 -> C layer); NCG = cout groups of 64 (C = 64 NCG).
+// k_conv3x3_sp<RES, NCH, NCG>: NCH = input-channel chunks of 8 (16: 128 -> C layer, 8: 64 -> C layer, 4: the stem, 17 planes padded to 32
+// -> C); NCG = cout groups of 64 (C = 64 NCG).
 // w: [plane: hi, lo][9 taps][C couts][8 NCH cin] f16 with lo = (w - hi) * 2^11; bias fp32 [C].
 // The EPILOGUE is SOFTWARE-PIPELINED into the MFMA stream (the scheme of k_conv3x3_tiled / k_resblock64): a board is 2 units of 3
 // column tiles with two accumulator sets; while unit i multiplies into set i & 1, the epilogue of unit i - 1 (join of the two
@@ -139,7 +241,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     static_assert((2 * KS) % R == 0, "a board's k-steps keep the ring phase");
     static_assert(KS - 2 >= NPIECE, "the next board's pieces ride in unit 0");
     constexpr int PER = (U_OPS + (9 * KS - S0 - 40) - 1) / (9 * KS - S0 - 40);  // micro-ops per MFMA gap (1 at 128 filters, 2 at 64)
-    static_assert(PER <= 2, "the previous unit's epilogue fits the unit's MFMA gaps with room before the barrier");
+    static_assert(PER <= (NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits the unit's MFMA gaps with room before the barrier");
     static_assert(LPLANE + 3 * 4 * LBLK + 22 * 16 < 65536, "fragment addresses are a base + a 16-bit immediate");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;

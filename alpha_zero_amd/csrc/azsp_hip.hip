@@ -288,4 +288,36 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
 #undef AZ_SP
     return AZ_HIP(hipGetLastError());
 }
+int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st) {
+    if (cin < 1 || cin > 32 || S < 1) return 1;
+    const long long nitems = boards * 4 * S * S;
+    hipLaunchKernelGGL(k_split_features, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, (hipStream_t)st, src, (unsigned char*)dst, nitems, cin,
+                       S * S);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* st) {
+    if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const int ncg = C / 64;
+    long long nslot = n_cu / ncg > 0 ? n_cu / ncg : 1;
+    if (boards < nslot) nslot = boards;
+    const dim3 grid((unsigned)(nslot * ncg)), block(CW_THREADS);
+    if (C == 128)
+        hipLaunchKernelGGL((k_conv3x3_sp<false, 4, 2>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
+                           (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+    else
+        hipLaunchKernelGGL((k_conv3x3_sp<false, 4, 1>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
+                           (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+    return AZ_HIP(hipGetLastError());
+}
+int launch_head_split(const HeadSplitArgs& a, void* st) {
+    const int P2 = a.S * a.S;
+    const size_t lds = (size_t)(3 * a.C + SP_HEAD_BPB * (3 * P2 + a.A + a.F)) * sizeof(float);
+    if (a.C % 8 || a.npol < 1 || a.npol > 2 || lds > 64 * 1024) return 1;
+    hipLaunchKernelGGL(k_head_split, dim3((unsigned)((a.boards + SP_HEAD_BPB - 1) / SP_HEAD_BPB)), dim3(256), lds, (hipStream_t)st,
+                       (const unsigned char*)a.x, a.hw, a.hb, a.wp_t, a.bp, a.w1_t, a.b1, a.w2, a.b2, a.priors, a.values, a.boards, a.C, P2, a.A, a.F,
+                       a.npol);
+    return AZ_HIP(hipGetLastError());
+}
 }  // namespace azb

@@ -549,6 +549,17 @@ int launch_tile_layout(const void* src, void* dst, long long boards, int S, int 
 int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* stream);
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void* stream);
+struct HeadSplitArgs {
+    const void* x;
+    const float *hw, *hb, *wp_t, *bp, *w1_t, *b1, *w2;
+    float b2;
+    float *priors, *values;
+    long long boards;
+    int S, C, A, F, npol;
+};
+int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* stream);
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* stream);
+int launch_head_split(const HeadSplitArgs& a, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
                       int pol_stride, int val_stride, void* stream);
@@ -1037,6 +1048,33 @@ int azsp_conv3x3_split(const void* x, const void* w, const float* bias, const vo
     if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3_split(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_split_features(const float* planes, void* dst, int64_t boards, int32_t S, int32_t cin, void* stream) {
+    if (!planes || !dst || boards < 0 || boards > 0x7fffffff || S <= 0 || cin < 1 || cin > 32) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_split_features(planes, dst, (long long)boards, S, cin, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_stem_split(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t relu, void* stream) {
+    if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_head_split(const void* x, const float* head_w, const float* head_b, const float* pol_fc_wt, const float* pol_fc_b, const float* val_fc1_wt,
+                    const float* val_fc1_b, const float* val_fc2_w, float val_fc2_b, float* priors, float* values, int64_t boards, int32_t S,
+                    int32_t C, int32_t A, int32_t F, int32_t npol, void* stream) {
+    if (!x || !head_w || !head_b || !pol_fc_wt || !pol_fc_b || !val_fc1_wt || !val_fc1_b || !val_fc2_w || !priors || !values || boards < 0 ||
+        boards > 0x7fffffff || S <= 0 || C <= 0 || A <= 0 || F <= 0)
+        return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const azb::HeadSplitArgs a = {x, head_w, head_b, pol_fc_wt, pol_fc_b, val_fc1_wt, val_fc1_b, val_fc2_w, val_fc2_b, priors, values, (long long)boards,
+                             S, C, A, F, npol};
+    const int rc = azb::launch_head_split(a, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -35,6 +35,8 @@
  *   azsp_conv3x3_split                the same layer at the reference's fp32 precision class (core/pipeline.py:91-123 evaluates
  *                                     in fp32): values as hi + lo f16 pairs, three f16 MFMA products, fp32 accumulation
  *   azsp_split_layout / azsp_split_bytes the split-precision tower's activation layout
+ *   azsp_split_features / azsp_stem_split / azsp_head_split   the stem and both heads of the same fp32-class evaluator
+ *                                     (core/network.py:101-156)
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
  * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
@@ -273,6 +275,24 @@ int azsp_split_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_
                       void* stream);
 int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                        int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+
+/* The rest of the fp32-class evaluator on the split layout (core/network.py:101-156):
+ * azsp_split_features: observation planes [boards][in_channels <= 32][S][S] fp32 (the engine's AZSP_FEAT_F32 features) -> split
+ *   layout with 32 channels (the missing ones zero), azsp_split_bytes(boards, S, 32) bytes.
+ * azsp_stem_split: the stem convolution + BatchNorm + ReLU (network.py:101-110, padding 1): x from azsp_split_features, w_split
+ *   [2 planes][9 taps][C out][32 in] f16 (input channels >= the network's zero), y in the tower's split layout.  (S, C) as
+ *   azsp_conv3x3_split.
+ * azsp_head_split: both heads in fp32 in one pass over the tower output (network.py:118-156): the two 1x1 convolutions + BatchNorm +
+ *   ReLU (head_w [3][C], head_b [3]: npol policy planes first), policy Linear + softmax over all A actions (pol_fc_wt = the Linear's
+ *   weight TRANSPOSED, [npol*S*S][A], inputs in nn.Flatten order), value Linear + ReLU + Linear + tanh (val_fc1_wt transposed
+ *   [(3-npol)*S*S][F], val_fc2_w [F], val_fc2_b); priors float [boards][A], values float [boards].  Any (S, C) with C % 8 == 0. */
+int azsp_split_features(const float* planes_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t in_channels, void* stream);
+int azsp_stem_split(const void* x_split32_dev, const void* w_split_dev, const float* bias_dev, void* y_dev, int64_t boards, int32_t board_size,
+                    int32_t channels, int32_t relu, void* stream);
+int azsp_head_split(const void* x_dev, const float* head_w_dev, const float* head_b_dev, const float* pol_fc_wt_dev, const float* pol_fc_b_dev,
+                    const float* val_fc1_wt_dev, const float* val_fc1_b_dev, const float* val_fc2_w_dev, float val_fc2_b, float* priors_dev,
+                    float* values_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t num_actions, int32_t fc_units, int32_t npol,
+                    void* stream);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch
  * tensors and apply_random_transformation): out_states[b] = T_op(ring_states[idx[b]]) cast to state_dtype (AZSP_FEAT_I8 / F32 /

@@ -130,40 +130,98 @@ int launch_split_layout(const void* src, void* dst, long long boards, int S, int
                 }
     return 0;
 }
-int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
-                         void*) {
-    if (S != 9 || (C != 128 && C != 64)) return 1;
-    const int P2 = S * S, nch = C / 8;
-    const size_t plane = (size_t)nch * P2 * 8, wplane = (size_t)9 * C * C;
+// x: split layout with Cin channels, w: [2][9][C][Cin] f16, y / res: split layout with C channels
+static int host_conv_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int Cin, int C,
+                           int relu) {
+    const int P2 = S * S;
+    const size_t xplane = (size_t)(Cin / 8) * P2 * 8, yplane = (size_t)(C / 8) * P2 * 8, wplane = (size_t)9 * C * Cin;
     const unsigned short *xs = (const unsigned short*)x, *ws = (const unsigned short*)w, *rs = (const unsigned short*)res;
     unsigned short* ys = (unsigned short*)y;
     auto at = [&](int ch, int p) { return ((size_t)(ch / 8) * P2 + p) * 8 + ch % 8; };
     std::vector<float> wh(wplane), wl(wplane);
     for (size_t i = 0; i < wplane; ++i) wh[i] = sp_h_to_f32(ws[i]), wl[i] = sp_h_to_f32(ws[wplane + i]);
-    std::vector<float> xh((size_t)P2 * C), xl((size_t)P2 * C);
+    std::vector<float> xh((size_t)P2 * Cin), xl((size_t)P2 * Cin);
     for (long long b = 0; b < boards; ++b) {
-        const size_t bo = (size_t)b * 2 * plane;
+        const size_t xo = (size_t)b * 2 * xplane, yo = (size_t)b * 2 * yplane;
         for (int p = 0; p < P2; ++p)
-            for (int ci = 0; ci < C; ++ci) xh[(size_t)p * C + ci] = sp_h_to_f32(xs[bo + at(ci, p)]), xl[(size_t)p * C + ci] = sp_h_to_f32(xs[bo + plane + at(ci, p)]);
+            for (int ci = 0; ci < Cin; ++ci)
+                xh[(size_t)p * Cin + ci] = sp_h_to_f32(xs[xo + at(ci, p)]), xl[(size_t)p * Cin + ci] = sp_h_to_f32(xs[xo + xplane + at(ci, p)]);
         for (int p = 0; p < P2; ++p)
             for (int co = 0; co < C; ++co) {
                 float main = bias[co], corr = 0.0f;
                 for (int tap = 0; tap < 9; ++tap) {
                     const int sy = p / S + tap / 3 - 1, sx = p % S + tap % 3 - 1;
                     if (sy < 0 || sx < 0 || sy >= S || sx >= S) continue;
-                    const float *h = &xh[(size_t)(sy * S + sx) * C], *l = &xl[(size_t)(sy * S + sx) * C];
-                    const float *a = &wh[((size_t)tap * C + co) * C], *d = &wl[((size_t)tap * C + co) * C];
-                    for (int ci = 0; ci < C; ++ci) {
+                    const float *h = &xh[(size_t)(sy * S + sx) * Cin], *l = &xl[(size_t)(sy * S + sx) * Cin];
+                    const float *a = &wh[((size_t)tap * C + co) * Cin], *d = &wl[((size_t)tap * C + co) * Cin];
+                    for (int ci = 0; ci < Cin; ++ci) {
                         main += a[ci] * h[ci];
                         corr += a[ci] * l[ci];
                         corr += d[ci] * h[ci];
                     }
                 }
                 float v = fmaf(corr, 1.0f / 2048.0f, main);
-                if (rs) v += sp_h_join(rs[bo + at(co, p)], rs[bo + plane + at(co, p)]);
+                if (rs) v += sp_h_join(rs[yo + at(co, p)], rs[yo + yplane + at(co, p)]);
                 if (relu && v < 0.0f) v = 0.0f;
-                sp_h_split(v, ys[bo + at(co, p)], ys[bo + plane + at(co, p)]);
+                sp_h_split(v, ys[yo + at(co, p)], ys[yo + yplane + at(co, p)]);
             }
+    }
+    return 0;
+}
+int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
+                         void*) {
+    if (S != 9 || (C != 128 && C != 64)) return 1;
+    return host_conv_split(x, w, bias, res, y, boards, S, C, C, relu);
+}
+int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void*) {
+    if (cin < 1 || cin > 32) return 1;
+    const int P2 = S * S;
+    const size_t plane = (size_t)4 * P2 * 8;
+    unsigned short* d = (unsigned short*)dst;
+    for (long long b = 0; b < boards; ++b)
+        for (int ch = 0; ch < 32; ++ch)
+            for (int p = 0; p < P2; ++p) {
+                const size_t so = (size_t)b * 2 * plane + ((size_t)(ch / 8) * P2 + p) * 8 + ch % 8;
+                sp_h_split(ch < cin ? src[((size_t)b * cin + ch) * P2 + p] : 0.0f, d[so], d[so + plane]);
+            }
+    return 0;
+}
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void*) {
+    if (S != 9 || (C != 128 && C != 64)) return 1;
+    return host_conv_split(x, w, bias, nullptr, y, boards, S, 32, C, relu);
+}
+int launch_head_split(const HeadSplitArgs& a, void*) {
+    const int P2 = a.S * a.S, nch = a.C / 8, kp = a.npol * P2, kv = (3 - a.npol) * P2;
+    if (a.C % 8 || a.npol < 1 || a.npol > 2) return 1;
+    const size_t plane = (size_t)nch * P2 * 8;
+    const unsigned short* xs = (const unsigned short*)a.x;
+    std::vector<float> hp((size_t)3 * P2), out((size_t)a.A + a.F);
+    for (long long b = 0; b < a.boards; ++b) {
+        for (int pl = 0; pl < 3; ++pl)
+            for (int p = 0; p < P2; ++p) {
+                float acc = a.hb[pl];
+                for (int ch = 0; ch < a.C; ++ch) {
+                    const size_t so = (size_t)b * 2 * plane + ((size_t)(ch / 8) * P2 + p) * 8 + ch % 8;
+                    acc = fmaf(sp_h_join(xs[so], xs[so + plane]), a.hw[pl * a.C + ch], acc);
+                }
+                hp[(size_t)pl * P2 + p] = acc > 0.0f ? acc : 0.0f;
+            }
+        for (int o = 0; o < a.A; ++o) {
+            float acc = a.bp[o];
+            for (int k = 0; k < kp; ++k) acc = fmaf(hp[k], a.wp_t[(size_t)k * a.A + o], acc);
+            out[o] = acc;
+        }
+        for (int f = 0; f < a.F; ++f) {
+            float acc = a.b1[f];
+            for (int k = 0; k < kv; ++k) acc = fmaf(hp[kp + k], a.w1_t[(size_t)k * a.F + f], acc);
+            out[a.A + f] = acc > 0.0f ? acc : 0.0f;
+        }
+        float mx = -INFINITY, sum = 0.0f, v = 0.0f;
+        for (int o = 0; o < a.A; ++o) mx = fmaxf(mx, out[o]);
+        for (int o = 0; o < a.A; ++o) sum += expf(out[o] - mx);
+        for (int o = 0; o < a.A; ++o) a.priors[(size_t)b * a.A + o] = expf(out[o] - mx) / sum;
+        for (int f = 0; f < a.F; ++f) v = fmaf(out[a.A + f], a.w2[f], v);
+        a.values[b] = tanhf(v + a.b2);
     }
     return 0;
 }

@@ -156,38 +156,87 @@ def test_gpu_split_conv_small_and_large_magnitudes():
     assert max(res.values()) <= 2e-6, res
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("filters", [128, 64])
-def test_gpu_fp32_network_on_the_split_tower(filters):
-    """The whole fp32 evaluator with the tower on azsp_conv3x3_split vs the same InferenceNet on library convolutions vs the fp64
-    module (10 blocks, non-trivial BatchNorm statistics: round-off is amplified through the depth for both fp32 paths).  Bound: the
-    split tower is at most 1.5x + 1e-5 as far from fp64 as the library path, and within 2e-4 absolutely (measured on MI355X, r03:
-    priors 4.5e-5 vs 9.3e-5 (library) at 128 filters, 1.5e-5 vs 2.6e-5 at 64; values 2.9e-5 vs 4.0e-5 and 3.8e-5 vs 8.4e-5)."""
-    from alpha_zero_amd import _lib
-
-    torch.manual_seed(3)
-    net = AlphaZeroNet((17, 9, 9), 82, 10, filters, 128).eval()
+def _trained_like_net(filters, blocks, seed=3):
+    torch.manual_seed(seed)
+    net = AlphaZeroNet((17, 9, 9), 82, blocks, filters, 128).eval()
     with torch.no_grad():
         for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm2d):  # non-trivial running statistics, as after training
                 m.running_mean.normal_(0, 0.2), m.running_var.uniform_(0.5, 1.5), m.weight.uniform_(0.7, 1.3), m.bias.normal_(0, 0.2)
-    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
-    assert "azsp_conv3x3_split" in inf.evaluator_path(9, "cuda")
-    x = (torch.rand(200, 17, 9, 9, generator=torch.Generator().manual_seed(1)) > 0.6).float()
-    ps, vs = [t.cpu().clone() for t in inf(x.cuda())]
-    assert getattr(inf, "_split", None) is not None, "the split tower did not run"
-    inf.use_split_tower = False
-    pl, vl = [t.cpu().clone() for t in inf(x.cuda())]
+    return net
+
+
+def test_split_evaluator_host_twin():
+    """azsp_split_features -> azsp_stem_split -> azsp_conv3x3_split x 2 -> azsp_head_split through InferenceNet.forward_split on the host
+    twin (plain loops on the same arithmetic): a 1-block 64-filter network on 3 positions vs the fp64 module."""
+    import engine_util as eu
+
+    net = _trained_like_net(64, 1)
+    inf = InferenceNet(net, dtype=torch.float32, binding=eu.hosttwin_binding())
+    x = (torch.rand(3, 17, 9, 9, generator=torch.Generator().manual_seed(2)) > 0.6).float()
+    pri, v = inf.forward_split(x)
     with torch.no_grad():
         lg, v64 = net.double()(x.double())
-    p64 = torch.softmax(lg, -1)
-    d = dict(filters=filters, split_vs_fp64=((ps.double() - p64).abs().max().item(), (vs.double() - v64.squeeze(1)).abs().max().item()),
-             library_vs_fp64=((pl.double() - p64).abs().max().item(), (vl.double() - v64.squeeze(1)).abs().max().item()))
+    dp, dv = (pri.double() - torch.softmax(lg, -1)).abs().max().item(), (v.double() - v64.squeeze(1)).abs().max().item()
+    assert dp <= 2e-6 and dv <= 2e-6, (dp, dv)
+    assert abs(pri.sum(1) - 1).max().item() <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filters", [128, 64])
+def test_gpu_fp32_network_on_the_split_kernels(filters):
+    """The whole fp32-class evaluator (azsp_split_features / azsp_stem_split / azsp_conv3x3_split / azsp_head_split), the same tower
+    behind a library stem and heads, and the all-library fp32 InferenceNet, each against the fp64 module (10 blocks, non-trivial
+    BatchNorm statistics: round-off is amplified through the depth for every fp32 path).  Bound: the hand-written paths are at most
+    1.5x + 1e-5 as far from fp64 as the library path, and within 2e-4 absolutely (measured on MI355X, r03, tower on the split kernel:
+    priors 4.5e-5 vs 9.3e-5 (library) at 128 filters, 1.5e-5 vs 2.6e-5 at 64; values 2.9e-5 vs 4.0e-5 and 3.8e-5 vs 8.4e-5)."""
+    from alpha_zero_amd import _lib
+
+    net = _trained_like_net(filters, 10)
+    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    assert inf.supports_split_features(9, "cuda") and "hand-written" in inf.evaluator_path(9, "cuda")
+    x = (torch.rand(203, 17, 9, 9, generator=torch.Generator().manual_seed(1)) > 0.6).float()
+    with torch.no_grad():
+        lg, v64 = net.double()(x.double())
+    p64, v64 = torch.softmax(lg, -1), v64.squeeze(1)
+
+    def dist(pv):
+        return (pv[0].cpu().double() - p64).abs().max().item(), (pv[1].cpu().double() - v64).abs().max().item()
+
+    d = dict(filters=filters)
+    inf._split = None
+    d["split_evaluator_vs_fp64"] = dist(inf(x.cuda()))
+    assert inf._split is not None, "the split kernels did not run"
+    inf.use_split_heads, inf._split = False, None
+    d["split_tower_library_heads_vs_fp64"] = dist(inf(x.cuda()))
+    assert inf._split is not None and "azsp_conv3x3_split" in inf.evaluator_path(9, "cuda")
+    inf.use_split_tower = False
+    d["library_vs_fp64"] = dist(inf(x.cuda()))
     print(json.dumps(d))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(d, open(os.path.join(ROOT, "gpurun_out", f"split_network_error_{filters}.json"), "w"))
-    for k in (0, 1):
-        assert d["split_vs_fp64"][k] <= 2e-4 and d["split_vs_fp64"][k] <= 1.5 * d["library_vs_fp64"][k] + 1e-5, d
+    for name in ("split_evaluator_vs_fp64", "split_tower_library_heads_vs_fp64"):
+        for k in (0, 1):
+            assert d[name][k] <= 2e-4 and d[name][k] <= 1.5 * d["library_vs_fp64"][k] + 1e-5, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 3, 4, 5, 203])
+def test_gpu_split_stem_and_heads_vs_fp64(boards):
+    """azsp_split_features + azsp_stem_split and azsp_head_split on their own (a 0-block network = stem -> heads) vs the fp64 module,
+    board counts around the head kernel's 4 boards per workgroup."""
+    from alpha_zero_amd import _lib
+
+    for filters in (128, 64):
+        net = _trained_like_net(filters, 0, seed=boards)
+        inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+        x = (torch.rand(boards, 17, 9, 9, generator=torch.Generator().manual_seed(boards)) > 0.6).float()
+        pri, v = inf(x.cuda())
+        assert inf._split is not None
+        with torch.no_grad():
+            lg, v64 = net.double()(x.double())
+        dp, dv = (pri.cpu().double() - torch.softmax(lg, -1)).abs().max().item(), (v.cpu().double() - v64.squeeze(1)).abs().max().item()
+        assert dp <= 2e-6 and dv <= 4e-6, (filters, boards, dp, dv)
 
 
 from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet  # noqa: E402
