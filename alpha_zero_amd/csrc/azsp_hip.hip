@@ -266,27 +266,26 @@ int launch_split_layout(const void* src, void* dst, long long boards, int S, int
                        (unsigned char*)dst, nchunks, to_split, C / 8, S * S);
     return AZ_HIP(hipGetLastError());
 }
+// main kernel (80 positions per board) + the corner position (k_corner_sp), on the same stream
+template <bool RES, int NCH, int NCG>
+static int launch_sp(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    long long nslot = n_cu / NCG > 0 ? n_cu / NCG : 1;  // one persistent workgroup per CU; the cout groups of a board run side by side
+    if (boards < nslot) nslot = boards;
+    hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG>), dim3((unsigned)(nslot * NCG)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+    if (AZ_HIP(hipGetLastError())) return -1;
+    const long long tasks = (boards + 15) / 16 * (64 * NCG / 16);
+    hipLaunchKernelGGL((k_corner_sp<RES, NCH>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x,
+                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, 64 * NCG, relu);
+    return AZ_HIP(hipGetLastError());
+}
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void* st) {
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
-    const int n_cu = cu_count();
-    if (n_cu < 0) return -1;
-    const int ncg = C / 64;
-    long long nslot = n_cu / ncg > 0 ? n_cu / ncg : 1;  // one persistent workgroup per CU; the cout groups of a board run side by side
-    if (boards < nslot) nslot = boards;
-    const dim3 grid((unsigned)(nslot * ncg)), block(CW_THREADS);
-#define AZ_SP(RES, NCH, NCG)                                                                                                             \
-    hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias, \
-                       (const unsigned char*)res, (unsigned char*)y, (int)boards, relu)
-    if (C == 128) {
-        if (res) AZ_SP(true, 16, 2);
-        else AZ_SP(false, 16, 2);
-    } else {
-        if (res) AZ_SP(true, 8, 1);
-        else AZ_SP(false, 8, 1);
-    }
-#undef AZ_SP
-    return AZ_HIP(hipGetLastError());
+    if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st);
+    return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st);
 }
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st) {
     if (cin < 1 || cin > 32 || S < 1) return 1;
@@ -297,19 +296,7 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
 }
 int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* st) {
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
-    const int n_cu = cu_count();
-    if (n_cu < 0) return -1;
-    const int ncg = C / 64;
-    long long nslot = n_cu / ncg > 0 ? n_cu / ncg : 1;
-    if (boards < nslot) nslot = boards;
-    const dim3 grid((unsigned)(nslot * ncg)), block(CW_THREADS);
-    if (C == 128)
-        hipLaunchKernelGGL((k_conv3x3_sp<false, 4, 2>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
-                           (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
-    else
-        hipLaunchKernelGGL((k_conv3x3_sp<false, 4, 1>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
-                           (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
-    return AZ_HIP(hipGetLastError());
+    return C == 128 ? launch_sp<false, 4, 2>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp<false, 4, 1>(x, w, bias, nullptr, y, boards, relu, st);
 }
 int launch_head_split(const HeadSplitArgs& a, void* st) {
     const int P2 = a.S * a.S;

@@ -470,10 +470,36 @@ def main(argv=None):
                 prer = preroll(a, args, world, dev, min_rounds=pre)
                 el, c, ev, _ = timed(a, args, world, dev, 5, steps)
                 used_split = getattr(a.infer, "_split", None) is not None
+                tower = None
+                if used_split:  # the split-precision tower convolution, replayed on the activations of the last forward (HIP events)
+                    import ctypes
+
+                    inf, dll = a.infer, a.binding.dll
+                    xa, xm, xo, rows_s = inf._split
+                    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                    S_s, C_s = args.board, args.filters
+                    ms = {}
+                    for nm, rp in (("plain", None), ("residual", xa)):
+                        for rep in range(2):  # first pass: warm-up
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(10):
+                                dll.azsp_conv3x3_split(xm.data_ptr(), inf.wsp[1].data_ptr(), inf.b32[1].data_ptr(), rp.data_ptr() if rp is not None else None,
+                                                       xo.data_ptr(), rows_s, S_s, C_s, 1, st)
+                            e1.record()
+                            torch.cuda.synchronize(dev)
+                            ms[nm] = e0.elapsed_time(e1) / 10
+                    avg = 0.5 * (ms["plain"] + ms["residual"])
+                    fl = 2.0 * rows_s * S_s * S_s * C_s * C_s * 9
+                    tower = {"kernel": "k_conv3x3_sp + k_corner_sp (split-precision 3x3 convolution: hi + lo f16 pairs, three f16 MFMA products, fp32 accumulation)",
+                             "avg_launch_ms": round(avg, 4), "avg_launch_ms_plain": round(ms["plain"], 4), "avg_launch_ms_residual": round(ms["residual"], 4),
+                             "fp32_equivalent_tflops": round(fl / avg / 1e9, 1), "fp32_mfma_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
+                             "f16_mfma_flops_tflops": round(3 * fl / avg / 1e9, 1), "frac_of_f16_mfma_peak": round(3 * fl / avg / 1e9 / MFMA_PEAK_TFLOPS["fp16"], 4),
+                             "launches_per_step": 2 * args.blocks}
                 r = {"moves_per_s": round(c["moves"] / el, 2), "sims_per_sec": round(c["sims"] / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
                      "sims_per_move": round(c["sims"] / max(1, c["moves"]), 2), "steps": steps, "warmup": 5, "preroll_rounds": prer,
                      "forward_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev])), 3),
-                     "evaluator": a.evaluator_path if used_split else "fp32, library convolutions + fused epilogue kernel"}
+                     "evaluator": a.evaluator_path if used_split else "fp32, library convolutions + fused epilogue kernel", "tower_kernel": tower}
                 del a, ev
                 torch.cuda.empty_cache()
                 return r, used_split
