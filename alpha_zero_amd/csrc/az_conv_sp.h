@@ -20,9 +20,11 @@
 //     the hi AND lo filter banks of its 16 couts in registers: 2 x 9 taps x C/32 k-steps x 4 registers = 288 at C = 128 (256 in
 //     AGPRs, read by the MFMA in place).
 //   * v_mfma_f32_16x16x32_f16, tile = ONE board: 80 of its 81 positions = exactly 5 column tiles of 16, per k-step (one tap x 32 input
-//     channels) 10 B fragments from LDS (5 hi + 5 lo) feed 15 MFMAs; the 81st position, the corner (8, 0) with only 4 taps on the
-//     board, is a tiny second launch (k_corner_sp: [couts] x [boards] x [4 taps x cin]).  (With all 81 positions in 6 column tiles a
-//     sixth of the matrix work multiplied repeated positions.)
+//     channels) 10 B fragments from LDS (5 hi + 5 lo) feed 15 MFMAs.  The 81st position, the corner (8, 0), has only 4 taps on the
+//     board: its 4 input cells are copied to a small LDS side buffer while the board is resident, and every 16 boards each wave
+//     multiplies one extra [16 couts] x [16 boards] x [4 taps x cin] tile on its resident filter banks (48 MFMAs per 16 boards).
+//     (With all 81 positions in 6 column tiles a sixth of the matrix work multiplied repeated positions; a separate launch for the
+//     corner cost 0.14 - 0.24 ms per layer: its scattered 16-byte cells are HBM sector over-fetch.)
 //   * LDS image per (plane, chunk): a strip of 120 16-byte cells, cell(y, x) = 12 + 11 y + x with zero cells around the rows, so a
 //     tap is a constant cell offset and every fragment address is a per-lane base + an immediate; strips are 7.5 x 256 B and the
 //     lane -> position table (tools/gen_sp_map.py) makes every ds_read_b128 lane group hit all 64 banks once: conflict-free.
@@ -40,8 +42,8 @@
 #define SP_F16_MAX 65504.0f
 
 struct SpGeo9 {
-    // cell(y, x) = 12 + 11 y + x: two zero cells between board rows.  Position (8, 0) is NOT a column of the main kernel (k_corner_sp
-    // computes it: a corner has only 4 taps on the board): the other 80 positions are exactly 5 column tiles of 16.
+    // cell(y, x) = 12 + 11 y + x: two zero cells between board rows.  Position (8, 0) is NOT a column of the per-board tiles (it is
+    // computed for 16 boards at a time: a corner has only 4 taps on the board): the other 80 positions are exactly 5 column tiles of 16.
     static constexpr int S = 9, P2 = 81, PITCH = 11, CELL0 = 12, CORNER = 72;
     static constexpr int CELLS = 120;  // 12 + 8 * 11 + 8 + 12; a strip is 1920 B = 7.5 x 256 B: neighbouring strips are shifted by 8 cells in bank space
     static constexpr int NCT = 5;
@@ -248,7 +250,7 @@ __device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, co
 }
 // ---------------------------------------------------------------------------------------------------------------------
 // k_conv3x3_sp<RES, NCH, NCG>: NCH = input-channel chunks of 8 (16: 128 -> C layer, 8: 64 -> C layer, 4: the stem, 17 planes padded to 32
-// -> C); NCG = cout groups of 64 (C = 64 NCG).  Computes every position of a board except the corner (8, 0) (k_corner_sp).
+// -> C); NCG = cout groups of 64 (C = 64 NCG).
 // w: [plane: hi, lo][9 taps][C couts][8 NCH cin] f16 with lo = (w - hi) * 2^11; bias fp32 [C].
 // The EPILOGUE is SOFTWARE-PIPELINED into the MFMA stream (the scheme of k_conv3x3_tiled / k_resblock64): a board is 2 units (column
 // tiles 0-2 and 3-4) with two accumulator sets; while unit i multiplies into set i, the epilogue of the previous unit (join of the two
@@ -274,7 +276,12 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     static_assert((2 * KS) % R == 0, "a board's k-steps keep the ring phase");
     static_assert(KS - 1 >= NPIECE, "the next board's pieces ride in unit 0");
     static_assert(LPLANE + 3 * 4 * LBLK + (2 * G::PITCH + 2) * 16 < 65536, "fragment addresses are a base + a 16-bit immediate");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * LBUF + 16];  // + one zero cell: the (+1, +1) tap of (8, 8) in the last strip
+    // x double buffer, + one zero cell (the (+1, +1) tap of (8, 8) in the last strip), + the corner side buffer: for each of the last
+    // <= 16 boards of this workgroup the 4 cells the corner (8, 0) multiplies ((7, 0), (7, 1), (8, 0), (8, 1); both planes, all chunks)
+    constexpr int SIDE_BOARD = 8 * NCH * 16 + 16;  // bytes per board; + 16: neighbouring boards (= MFMA columns) fall on different banks
+    constexpr int SIDE0 = 2 * LBUF + 16;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[SIDE0 + 16 * SIDE_BOARD];
+    static_assert(SIDE0 + 16 * SIDE_BOARD <= 160 * 1024, "LDS budget");
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
@@ -293,7 +300,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             slot = b / NCG;
         }
     }
-    for (int i = tid; i < (2 * LBUF + 16) / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    for (int i = tid; i < (SIDE0 + 16 * SIDE_BOARD) / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
     CV_BARRIER();  // the zero cells are final before any LDS-DMA piece can land
     if (slot >= ntiles) return;  // (uniform per workgroup)
 
@@ -411,6 +418,19 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
         }
     };
 
+    // Corner side buffer.  Thread tid < 8 NCH copies one 16-byte cell per board: cell index c = tid = ((kg * 4 + tap) * 2 + plane) * KSUB + ks
+    // (tap = 2 dy' + dx': board cells (7 + dy', dx')), i.e. a column's four 8-channel groups are 512 B apart = on the same banks, and the
+    // corner phase reads B fragment (tap, plane, ks) of lane (board n = l15, group kg) at  n SIDE_BOARD + 16 c : conflict-free.
+    const bool copier = tid < 8 * NCH;
+    int csrc, cdst;
+    {
+        const int c = copier ? tid : 0, ks = c % KSUB, pl = (c / KSUB) & 1, tp = (c / (2 * KSUB)) & 3, g4 = c / (8 * KSUB);
+        csrc = (pl * NCH + 4 * ks + g4) * LBLK + (G::CELL0 + G::PITCH * (G::S - 2 + (tp >> 1)) + (tp & 1)) * 16;
+        cdst = SIDE0 + c * 16;
+    }
+    cv_u32x4 ctmp = (cv_u32x4){0u, 0u, 0u, 0u};
+    static_assert(KS >= 6, "the side-buffer copy rides in unit 0");
+
     int it = 0;
     unsigned char* yprev = y;
     for (int tile = slot; tile < ntiles; tile += nslot, ++it) {
@@ -470,12 +490,62 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
                 if constexpr (i == 0 && t >= 1 && t - 1 < NPIECE) dma_piece(nsrc, ndst, has_next, t - 1);
+                if constexpr (i == 0 && t == 2) {  // this board's corner cells -> side buffer column it & 15 (read now, written three k-steps on)
+                    if (copier) ctmp = *(const cv_u32x4*)(Xs + csrc);
+                }
+                if constexpr (i == 0 && t == 5) {
+                    if (copier) *(cv_u32x4*)(lds + cdst + (it & 15) * SIDE_BOARD) = ctmp;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<KS>::type{});
         };
         unit(CpInt<0>{});
         unit(CpInt<1>{});
         yprev = ybase;
+        if ((it & 15) == 15 || !has_next) {
+            // ---- the corner (8, 0) of the last (it & 15) + 1 boards: a [16 couts] x [<= 16 boards] x [4 taps x cin] tile per wave on the resident
+            // filter banks.  The side buffer is complete: every wave passed this board's barrier after the copy of its column.
+            const int n_ok = (it & 15) + 1, it0 = it - (it & 15);
+            c6_f32x4 cm, cc;
+            const unsigned char* sb = lds + SIDE0 + l15 * SIDE_BOARD + kg * (8 * KSUB * 16);
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int u = decltype(TC)::value, tp = u / KSUB, ks = u % KSUB;         // tap = (7 + tp / 2, tp % 2) relative to (8, 0)
+                constexpr int fa = ((tp >> 1) * 3 + 1 + (tp & 1)) * KSUB + ks;              // weight k-step of tap (dy, dx) = (tp / 2 - 1, tp % 2)
+                const sp_f16x8 bh = *(const sp_f16x8*)(sb + ((tp * 2 + 0) * KSUB + ks) * 16);
+                const sp_f16x8 bl = *(const sp_f16x8*)(sb + ((tp * 2 + 1) * KSUB + ks) * 16);
+                if constexpr (u == 0) {
+                    sp_mfma_ac(cm, wf[fa], bh, bv);
+                    sp_mfma_a0(cc, wf[fa], bl);
+                } else {
+                    sp_mfma_a(cm, wf[fa], bh);
+                    sp_mfma_a(cc, wf[fa], bl);
+                }
+                if constexpr (KS + fa < NF_A) sp_mfma_a(cc, wf[KS + fa], bh);
+                else sp_mfma_v(cc, wf[KS + fa], bh);
+            }, typename CpMakeSeq<4 * KSUB>::type{});
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(cm), "+v"(cc));
+            // D layout: column = board l15 of the group, rows = couts 4 kg + e of the wave's 16
+            const int nb = l15 < n_ok ? l15 : 0;
+            const size_t co = (size_t)(slot + (size_t)(it0 + nb) * nslot) * YTILE + (size_t)(cg * 8 + wave * 2 + (kg >> 1)) * GBLK + G::CORNER * 16 + (kg & 1) * 8;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(cc[e], SP_INV_SCALE, cm[e]);
+            if (RES) {
+                const cv_u32x2 rh = *(const cv_u32x2*)(res + co), rl = *(const cv_u32x2*)(res + co + YPLANE);
+                v[0] += sp_join(sp_lo16(rh.x), sp_lo16(rl.x));
+                v[1] += sp_join(sp_hi16(rh.x), sp_hi16(rl.x));
+                v[2] += sp_join(sp_lo16(rh.y), sp_lo16(rl.y));
+                v[3] += sp_join(sp_hi16(rh.y), sp_hi16(rl.y));
+            }
+            _Float16 h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sp_split(fmaxf(v[e], lo_bound), h[e], l[e]);
+            if (l15 < n_ok) {
+                *(cv_u32x2*)(y + co) = (cv_u32x2){sp_pack(h[0], h[1]), sp_pack(h[2], h[3])};
+                *(cv_u32x2*)(y + co + YPLANE) = (cv_u32x2){sp_pack(l[0], l[1]), sp_pack(l[2], l[3])};
+            }
+            CV_BARRIER();  // the next group's copies may overwrite the side buffer
+        }
     }
     // epilogue of the very last unit (accumulator set 1, column tiles 3 and 4)
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accm[1][0]), "+v"(accm[1][1]), "+v"(accc[1][0]), "+v"(accc[1][1]));
@@ -485,60 +555,4 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
         for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, NJ0 + j, yprev, o, true);
 }
 
-// The corner (8, 0) of every board: 4 taps on the board -- a [C couts] x [boards] x [4 taps x cin] product on the same three f16 MFMA
-// products.  One wave per (16 boards, 16 couts) tile, cout tiles fastest (the 16 boards' 4 neighbour cells are re-read from L2 by
-// the C / 16 waves that share them); B fragments straight from global memory (16 bytes per lane), A fragments from the weights in L2.
-template <bool RES, int NCH> __global__ void __launch_bounds__(256)
-k_corner_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
-            const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int boards, int C, int relu) {
-    typedef SpGeo9 G;
-    constexpr int CIN = 8 * NCH, KSUB = NCH / 4, GBLK = G::P2 * 16, XPLANE = NCH * GBLK, XTILE = 2 * XPLANE;
-    const int lane = threadIdx.x & 63, l15 = lane & 15, kg = lane >> 4;
-    const int nct = C / 16;
-    const long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int bt = (int)(task / nct), ct = (int)(task % nct);
-    if (bt * 16 >= boards) return;
-    const int board = bt * 16 + l15 < boards ? bt * 16 + l15 : boards - 1;  // tail lanes recompute the last board, never store
-    const size_t YPLANE = (size_t)(C / 8) * GBLK, YTILE = 2 * YPLANE;
-    c6_f32x4 accm, accc = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) accm[e] = bias[ct * 16 + 4 * kg + e];
-    const unsigned char* xb = x + (size_t)board * XTILE + (size_t)kg * GBLK;
-    const _Float16* wb = w + (size_t)(ct * 16 + l15) * CIN + kg * 8;
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const int ty = tt >> 1, tx = 1 + (tt & 1), tap = ty * 3 + tx;          // taps (dy, dx) in {-1, 0} x {0, +1}
-        const int pos = (G::S - 1 + ty - 1) * G::S + (tx - 1);                  // (7, 0), (7, 1), (8, 0), (8, 1)
-#pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks) {
-            const sp_f16x8 xh = *(const sp_f16x8*)(xb + (size_t)(4 * ks) * GBLK + pos * 16);
-            const sp_f16x8 xl = *(const sp_f16x8*)(xb + XPLANE + (size_t)(4 * ks) * GBLK + pos * 16);
-            const sp_f16x8 wh = *(const sp_f16x8*)(wb + (size_t)tap * C * CIN + ks * 32);
-            const sp_f16x8 wl = *(const sp_f16x8*)(wb + (size_t)(9 + tap) * C * CIN + ks * 32);
-            accm = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, accm, 0, 0, 0);
-            accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, accc, 0, 0, 0);
-            accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, accc, 0, 0, 0);
-        }
-    }
-    // D layout: column = board (l15), rows = couts 16 ct + 4 kg + e: chunk 2 ct + kg / 2, half kg % 2 of position (8, 0)
-    const size_t yo = (size_t)board * YTILE + (size_t)(2 * ct + (kg >> 1)) * GBLK + G::CORNER * 16 + (kg & 1) * 8;
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaf(accc[e], SP_INV_SCALE, accm[e]);
-    if (RES) {
-        const cv_u32x2 rh = *(const cv_u32x2*)(res + yo), rl = *(const cv_u32x2*)(res + yo + YPLANE);
-        v[0] += sp_join(sp_lo16(rh.x), sp_lo16(rl.x));
-        v[1] += sp_join(sp_hi16(rh.x), sp_hi16(rl.x));
-        v[2] += sp_join(sp_lo16(rh.y), sp_lo16(rl.y));
-        v[3] += sp_join(sp_hi16(rh.y), sp_hi16(rl.y));
-    }
-    const float lo_bound = relu ? 0.0f : -SP_F16_MAX;
-    _Float16 h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sp_split(fmaxf(v[e], lo_bound), h[e], l[e]);
-    if (bt * 16 + l15 < boards) {
-        *(cv_u32x2*)(y + yo) = (cv_u32x2){sp_pack(h[0], h[1]), sp_pack(h[2], h[3])};
-        *(cv_u32x2*)(y + yo + YPLANE) = (cv_u32x2){sp_pack(l[0], l[1]), sp_pack(l[2], l[3])};
-    }
-}
 #endif  // __HIPCC__

@@ -266,7 +266,6 @@ int launch_split_layout(const void* src, void* dst, long long boards, int S, int
                        (unsigned char*)dst, nchunks, to_split, C / 8, S * S);
     return AZ_HIP(hipGetLastError());
 }
-// main kernel (80 positions per board) + the corner position (k_corner_sp), on the same stream
 template <bool RES, int NCH, int NCG>
 static int launch_sp(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
     const int n_cu = cu_count();
@@ -275,10 +274,6 @@ static int launch_sp(const void* x, const void* w, const float* bias, const void
     if (boards < nslot) nslot = boards;
     hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG>), dim3((unsigned)(nslot * NCG)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
                        (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
-    if (AZ_HIP(hipGetLastError())) return -1;
-    const long long tasks = (boards + 15) / 16 * (64 * NCG / 16);
-    hipLaunchKernelGGL((k_corner_sp<RES, NCH>), dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x,
-                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, 64 * NCG, relu);
     return AZ_HIP(hipGetLastError());
 }
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
