@@ -491,7 +491,7 @@ def main(argv=None):
                             ms[nm] = e0.elapsed_time(e1) / 10
                     avg = 0.5 * (ms["plain"] + ms["residual"])
                     fl = 2.0 * rows_s * S_s * S_s * C_s * C_s * 9
-                    tower = {"kernel": "k_conv3x3_sp + k_corner_sp (split-precision 3x3 convolution: hi + lo f16 pairs, three f16 MFMA products, fp32 accumulation)",
+                    tower = {"kernel": "k_conv3x3_sp (split-precision 3x3 convolution: hi + lo f16 pairs, three f16 MFMA products, fp32 accumulation)",
                              "avg_launch_ms": round(avg, 4), "avg_launch_ms_plain": round(ms["plain"], 4), "avg_launch_ms_residual": round(ms["residual"], 4),
                              "fp32_equivalent_tflops": round(fl / avg / 1e9, 1), "fp32_mfma_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
                              "f16_mfma_flops_tflops": round(3 * fl / avg / 1e9, 1), "frac_of_f16_mfma_peak": round(3 * fl / avg / 1e9 / MFMA_PEAK_TFLOPS["fp16"], 4),
