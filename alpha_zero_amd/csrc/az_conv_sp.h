@@ -30,9 +30,9 @@
 //     lane -> position table (tools/gen_sp_map.py) makes every ds_read_b128 lane group hit all 64 banks once: conflict-free.
 //   * the next board's 2 x C/8 strips arrive by LDS-DMA (global_load_lds_dwordx4, masked to the position cells) in the shadow of
 //     the first k-steps; one barrier per board; epilogue on the accumulators (bias enters as the C operand of the first MFMA).
-// Measured on MI355X (profiles/r03_pmc_split.txt, r03_split_bench.txt; 32768 boards, 128 filters): 2.03 ms per layer = 385 TFLOP/s
-// fp32-equivalent (the library's fp32 convolution + epilogue: 7.9 - 8.9 ms), matrix pipe busy 74 % at a power-limited ~1.78 GHz,
-// no LDS bank conflicts, HBM traffic = the tensors once each (the second cout group's input read hits the XCD's L2).
+// Measured on MI355X (profiles/r03_pmc_split.txt, r03_split_bench.txt, r03_bench_driver_cmd_e.json; 32768 boards, 128 filters): 1.71 - 1.90 ms
+// per layer depending on the box = 412 - 458 TFLOP/s fp32-equivalent (the library's fp32 convolution + epilogue: 7.9 - 9.1 ms), matrix
+// pipe busy 72 % at a power-limited ~1.8 GHz, HBM traffic = the tensors once each (the second cout group's input read hits the XCD's L2).
 #pragma once
 #include "az_conv64.h"
 
