@@ -93,6 +93,15 @@ def widen_network(net: "AlphaZeroNet", num_filters: int) -> "AlphaZeroNet":
     return out
 
 
+def split_weights_f16(w):
+    """Convolution weights [Cout,Cin,3,3] fp32 -> the packing of the split-precision kernels (include/azsp.h, azsp_conv3x3_split):
+    [plane: hi, lo][tap = ky*3+kx][Cout][Cin] f16 with hi = f16(w) and lo = f16((w - hi) * 2048)."""
+    w9 = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).float()
+    hi = w9.to(torch.float16)
+    lo = ((w9 - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo]).contiguous()
+
+
 def _fold(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     """Eval-mode BN(conv(x)) == conv'(x) + b'."""
     s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
@@ -128,17 +137,8 @@ class InferenceNet(nn.Module):
             self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
                                                      requires_grad=False) for w, _ in convs[1:]])
             self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
-            if dtype == torch.float32:
-                # split-precision tower (azsp_conv3x3_split): every fp32 weight as hi = f16(w) and lo = f16((w - hi) * 2048),
-                # packed [plane][tap = ky*3+kx][cout][cin]
-                def _split_w(w):
-                    w9 = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).float()
-                    hi = w9.to(torch.float16)
-                    lo = ((w9 - hi.float()) * 2048.0).to(torch.float16)
-                    return nn.Parameter(torch.stack([hi, lo]).contiguous(), requires_grad=False)
-
-                self.wsp = nn.ParameterList([_split_w(w) for w, _ in convs[1:]])
-                self._split_w = _split_w
+            if dtype == torch.float32:  # split-precision tower (azsp_conv3x3_split)
+                self.wsp = nn.ParameterList([nn.Parameter(split_weights_f16(w), requires_grad=False) for w, _ in convs[1:]])
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
@@ -152,7 +152,7 @@ class InferenceNet(nn.Module):
                 if dtype == torch.float32:  # azsp_stem_split: [plane][tap][cout][32 in] f16, input channels 17.. zero
                     sw32 = torch.zeros(sw.shape[0], 32, 3, 3)
                     sw32[:, : sw.shape[1]] = sw
-                    self.stem_wsp = self._split_w(sw32)
+                    self.stem_wsp = nn.Parameter(split_weights_f16(sw32), requires_grad=False)
             pw, pb = _fold(net.policy_head[0], net.policy_head[1])
             vw, vb = _fold(net.value_head[0], net.value_head[1])
             self.npol, self.nval = pw.shape[0], vw.shape[0]

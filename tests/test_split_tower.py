@@ -13,13 +13,6 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def split_weights(w):
-    """[Cout,Cin,3,3] fp32 -> [2 planes][9 taps][Cout][Cin] f16 (the packing InferenceNet does)."""
-    w9 = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).float()
-    hi = w9.to(torch.float16)
-    return torch.stack([hi, ((w9 - hi.float()) * 2048.0).to(torch.float16)]).contiguous()
-
-
 def _inputs(boards, C, S, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(boards, C, S, S, generator=g) * scale
@@ -46,7 +39,7 @@ def _run_split_conv(bnd, x, r, w, b, relu, device):
         rc = r.to(device).contiguous(memory_format=torch.channels_last)
         rs = torch.zeros(n, dtype=torch.float16, device=device)
         assert dll.azsp_split_layout(rc.data_ptr(), rs.data_ptr(), B, S, C, 1, None) == 0
-    wsp, bb = split_weights(w).to(device), b.float().to(device)
+    wsp, bb = split_weights_f16(w).to(device), b.float().to(device)
     assert dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bb.data_ptr(), rs.data_ptr() if rs is not None else None, ys.data_ptr(),
                                   B, S, C, relu, None) == 0
     y = torch.empty_like(xc)
@@ -240,4 +233,4 @@ def test_gpu_split_stem_and_heads_vs_fp64(boards):
         assert dp <= 2e-6 and dv <= 4e-6, (filters, boards, dp, dv)
 
 
-from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet  # noqa: E402
+from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet, split_weights_f16  # noqa: E402

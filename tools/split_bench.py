@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alpha_zero_amd import _lib
+from alpha_zero_amd.core.network import split_weights_f16
 
 b = _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
@@ -24,9 +25,7 @@ def act():
 x, res = act(), act()
 w = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5)
 bias = (torch.randn(C, generator=g) * 0.1).cuda()
-w9 = w.permute(2, 3, 0, 1).reshape(9, C, C)
-hi = w9.to(torch.float16)
-wsp = torch.stack([hi, ((w9 - hi.float()) * 2048.0).to(torch.float16)]).contiguous().cuda()
+wsp = split_weights_f16(w).cuda()
 wl = w.cuda().contiguous(memory_format=torch.channels_last)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 torch.backends.cudnn.benchmark = True

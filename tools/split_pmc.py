@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alpha_zero_amd import _lib
+from alpha_zero_amd.core.network import split_weights_f16
 
 b = _lib.load()
 B, S, C = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 9, 128
@@ -18,9 +19,7 @@ for dst in (xs, rs):
     t = torch.where(torch.rand(B, C, S, S, generator=g) < 0.5, torch.zeros(()), t.abs()).cuda().contiguous(memory_format=torch.channels_last)
     assert b.dll.azsp_split_layout(t.data_ptr(), dst.data_ptr(), B, S, C, 1, None) == 0
     del t
-w9 = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).permute(2, 3, 0, 1).reshape(9, C, C)
-hi = w9.to(torch.float16)
-wsp = torch.stack([hi, ((w9 - hi.float()) * 2048.0).to(torch.float16)]).contiguous().cuda()
+wsp = split_weights_f16(torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
 bias = (torch.randn(C, generator=g) * 0.1).cuda()
 for i in range(6):
     assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bias.data_ptr(), rs.data_ptr() if i % 2 else None, ys.data_ptr(), B, S, C, 1, None) == 0
