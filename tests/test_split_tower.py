@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet, split_weights_f16
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -231,6 +233,3 @@ def test_gpu_split_stem_and_heads_vs_fp64(boards):
             lg, v64 = net.double()(x.double())
         dp, dv = (pri.cpu().double() - torch.softmax(lg, -1)).abs().max().item(), (v.cpu().double() - v64.squeeze(1)).abs().max().item()
         assert dp <= 2e-6 and dv <= 4e-6, (filters, boards, dp, dv)
-
-
-from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet, split_weights_f16  # noqa: E402
