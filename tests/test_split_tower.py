@@ -151,6 +151,22 @@ def test_gpu_split_conv_small_and_large_magnitudes():
     assert max(res.values()) <= 2e-6, res
 
 
+def test_column_tile_map_in_the_header_is_the_generated_one():
+    """az_conv_sp.h carries the lane -> position table of tools/gen_sp_map.py (conflict-free ds_read_b128 lane groups; the header
+    static_asserts the property, this test keeps the table and its generator in step)."""
+    import re
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_sp_map.py")], capture_output=True, text=True, check=True).stdout
+    gen = [int(v) for v in re.findall(r"\d+", out.split("\n", 1)[1])]
+    hdr = open(os.path.join(ROOT, "alpha_zero_amd", "csrc", "az_conv_sp.h")).read()
+    body = hdr[hdr.index("constexpr SpMap sp_map_table = {{") :]
+    tab = [int(v) for v in re.findall(r"\d+", body[: body.index("}};")].split("{{", 1)[1])]
+    assert len(gen) == 80 and gen == tab
+    assert sorted(gen) == [p for p in range(81) if p != 72]  # every position but the corner (8, 0), once
+
+
 def _trained_like_net(filters, blocks, seed=3):
     torch.manual_seed(seed)
     net = AlphaZeroNet((17, 9, 9), 82, blocks, filters, 128).eval()
