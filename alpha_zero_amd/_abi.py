@@ -4,14 +4,14 @@ which only ever loads the HIP build and refuses to run without a GPU."""
 import ctypes as C
 
 GAME_GO, GAME_GOMOKU = 0, 1
-FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16, FEAT_BF16_TILED = 0, 1, 2, 3, 4
+FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16, FEAT_BF16_TILED, FEAT_F16_TILED = 0, 1, 2, 3, 4, 5
 ST_NEED_ROOT, ST_SEARCH, ST_MOVE_DONE, ST_IDLE, ST_WAIT_BUF = 0, 1, 2, 3, 4
 
 SYMBOLS = [
     "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
     "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
     "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act",
-    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled", "azsp_replay_gather", "azsp_rng_probe", "azsp_harvest_moves", "azsp_fc_heads", "azsp_harvest_extra", "azsp_set_actor_state", "azsp_resblock_tiled", "azsp_select_range", "azsp_expand_backup_range", "azsp_split_bytes", "azsp_split_layout", "azsp_conv3x3_split", "azsp_split_features", "azsp_stem_split", "azsp_head_split",
+    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled", "azsp_replay_gather", "azsp_rng_probe", "azsp_harvest_moves", "azsp_fc_heads", "azsp_harvest_extra", "azsp_set_actor_state", "azsp_resblock_tiled", "azsp_select_range", "azsp_expand_backup_range", "azsp_split_bytes", "azsp_split_layout", "azsp_conv3x3_split", "azsp_split_features", "azsp_stem_split", "azsp_head_split", "azsp_conv3x3_tiled_f16", "azsp_stem_tiled_f16", "azsp_head_tiled_f16", "azsp_fc_heads_f16",
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
@@ -64,6 +64,8 @@ class Binding:
             "azsp_fc_heads": [V, V, V, V, I, V, V, I, V, C.c_float, V, V, C.c_int64, I, I, V],
             "azsp_replay_gather": [V, V, V, V, I, I, I, I, I, I, V, V, V, V], "azsp_rng_probe": [V, I, I, V, V, V], "azsp_harvest_moves": [V, V], "azsp_harvest_extra": [V, V], "azsp_set_actor_state": [V, C.c_double, I],
         }
+        for k in ("azsp_conv3x3_tiled", "azsp_stem_tiled", "azsp_head_tiled", "azsp_fc_heads"):  # the f16 variants take the same arguments
+            sig[k + "_f16"] = sig[k]
         for k, a in sig.items():
             f = getattr(cdll, k)
             f.argtypes, f.restype = a, C.c_int

@@ -96,10 +96,10 @@ class Engine:
         t_np, t_py, sq = pbc_tables(cfg.c_puct_base, cfg.c_puct_init, g.table_len)
         self._ck(self.b.dll.azsp_set_tables(self.h, t_np.ctypes.data, t_py.ctypes.data, sq.ctypes.data, g.table_len), "azsp_set_tables")
         # evaluator-facing tensors (caller-visible; the engine reads / writes them in place)
-        self.features_tiled = cfg.feature_dtype == _abi.FEAT_BF16_TILED
-        if self.features_tiled:  # the evaluator's tiled layout (include/azsp.h: AZSP_FEAT_BF16_TILED), flat and zero-initialised
+        self.features_tiled = cfg.feature_dtype in (_abi.FEAT_BF16_TILED, _abi.FEAT_F16_TILED)
+        if self.features_tiled:  # the evaluator's tiled layout (include/azsp.h: AZSP_FEAT_BF16_TILED / _F16_TILED), flat and zero-initialised
             n = self.b.dll.azsp_tiled_bytes(self.rows, self.N, 32) // 2
-            self.features = torch.zeros((n,), dtype=torch.bfloat16, device=self.device)
+            self.features = torch.zeros((n,), dtype=torch.float16 if cfg.feature_dtype == _abi.FEAT_F16_TILED else torch.bfloat16, device=self.device)
         else:
             self.features = torch.zeros((self.rows, 17, self.N, self.N), dtype=_FEAT_TORCH[cfg.feature_dtype], device=self.device)
         self.valid = torch.zeros((self.rows,), dtype=torch.uint8, device=self.device)

@@ -134,7 +134,9 @@ class InferenceNet(nn.Module):
             self.n_blocks = len(net.res_blocks)
             # hand-written MFMA convolutions (azsp_conv3x3_tiled): weights as [tap = ky*3+kx][cout][cin] bf16, bias fp32
             self.filters = net.conv_block[0].out_channels
-            self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(torch.bfloat16).contiguous(),
+            # element format of the tiled kernels: bf16 (default) or f16 (dtype = torch.float16: azsp_*_f16, same MFMA rate, 3 more significand bits)
+            pk = self.pack_dtype = torch.float16 if dtype == torch.float16 else torch.bfloat16
+            self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(pk).contiguous(),
                                                      requires_grad=False) for w, _ in convs[1:]])
             self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
             if dtype == torch.float32:  # split-precision tower (azsp_conv3x3_split)
@@ -147,7 +149,7 @@ class InferenceNet(nn.Module):
             if self.stem_ok:
                 swp = torch.zeros(9, sw.shape[0], 32)
                 swp[:, :, : sw.shape[1]] = sw.permute(2, 3, 0, 1).reshape(9, sw.shape[0], sw.shape[1])
-                self.stem_wp = nn.Parameter(swp.to(torch.bfloat16).contiguous(), requires_grad=False)
+                self.stem_wp = nn.Parameter(swp.to(pk).contiguous(), requires_grad=False)
                 self.stem_b32 = nn.Parameter(convs[0][1].float().contiguous(), requires_grad=False)
                 if dtype == torch.float32:  # azsp_stem_split: [plane][tap][cout][32 in] f16, input channels 17.. zero
                     sw32 = torch.zeros(sw.shape[0], 32, 3, 3)
@@ -171,7 +173,7 @@ class InferenceNet(nn.Module):
             def _pad_w(wt):
                 out = torch.zeros((wt.shape[0] + 31) // 32 * 32, (wt.shape[1] + 15) // 16 * 16)
                 out[: wt.shape[0], : wt.shape[1]] = wt
-                return nn.Parameter(out.to(torch.bfloat16).contiguous(), requires_grad=False)
+                return nn.Parameter(out.to(pk).contiguous(), requires_grad=False)
 
             def _pad_v(v):
                 out = torch.zeros((v.numel() + 31) // 32 * 32)
@@ -290,7 +292,7 @@ class InferenceNet(nn.Module):
         if key not in cache:
             for k in [k for k in cache if k[0] == slot]:  # a slot holds one size at a time
                 del cache[k]
-            cache[key] = [torch.zeros(n, dtype=torch.bfloat16, device=device) for _ in range(3)]
+            cache[key] = [torch.zeros(n, dtype=self.pack_dtype, device=device) for _ in range(3)]
         if slot == 0:
             self._tiled = cache[key]  # (bench.py replays the tower on the activations of the last full-batch forward)
         return cache[key]
@@ -301,7 +303,7 @@ class InferenceNet(nn.Module):
         if key not in cache:
             for k in [k for k in cache if k[0] == slot]:
                 del cache[k]
-            cache[key] = (torch.zeros((B + 1, k1), dtype=torch.bfloat16, device=device), torch.zeros((B + 1, k2), dtype=torch.bfloat16, device=device),
+            cache[key] = (torch.zeros((B + 1, k1), dtype=self.pack_dtype, device=device), torch.zeros((B + 1, k2), dtype=self.pack_dtype, device=device),
                           torch.empty((B, self.num_actions), dtype=torch.float32, device=device), torch.empty((B,), dtype=torch.float32, device=device))
         return cache[key]
 
@@ -313,7 +315,8 @@ class InferenceNet(nn.Module):
     def _blocks_tiled(self, a, m, o, B, S, C, st):
         """All residual blocks on tiled buffers; returns the buffer holding the tower output."""
         dll, ck = self.binding.dll, self._ck
-        if self.use_fused_block and (C, S) in ((64, 17), (64, 9)):
+        conv = dll.azsp_conv3x3_tiled_f16 if self.pack_dtype == torch.float16 else dll.azsp_conv3x3_tiled
+        if self.use_fused_block and (C, S) in ((64, 17), (64, 9)) and self.pack_dtype != torch.float16:
             # 64 filters: both filter banks of a block fit in a CU's registers -> one launch per ResNetBlock, intermediate in LDS
             for i in range(self.n_blocks):
                 ck(dll.azsp_resblock_tiled(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), self.wp[2 * i + 1].data_ptr(),
@@ -321,10 +324,9 @@ class InferenceNet(nn.Module):
                 a, o = o, a
             return a
         for i in range(self.n_blocks):
-            ck(dll.azsp_conv3x3_tiled(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
+            ck(conv(a.data_ptr(), self.wp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st), "azsp_conv3x3_tiled")
+            ck(conv(m.data_ptr(), self.wp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), B, S, C, 1, st),
                "azsp_conv3x3_tiled")
-            ck(dll.azsp_conv3x3_tiled(m.data_ptr(), self.wp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
-                                      B, S, C, 1, st), "azsp_conv3x3_tiled")
             a, o = o, a
         return a
 
@@ -332,7 +334,7 @@ class InferenceNet(nn.Module):
         """Which kernels the forward pass of this network runs on `device` -- reported by bench.py (`config.evaluator`) and logged
         once by SelfPlayActor, so that an unsupported shape never degrades silently to the library path."""
         if self.supports_tiled_features(board_size, device):
-            return "hand-written: tiled stem / tower / head / FC kernels (libazsp)"
+            return "hand-written: tiled stem / tower / head / FC kernels (libazsp)" + (", f16 activations and weights" if self.dtype == torch.float16 else "")
         if torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and self.binding is not None:
             s = board_size + 2 * (self.stem_pad - 1)
             if (self.filters, s) in ((128, 9), (64, 17), (64, 9), (256, 19)):
@@ -350,7 +352,9 @@ class InferenceNet(nn.Module):
         """True when the whole evaluator can run on the tiled layout (azsp_stem_tiled -> tower -> azsp_head_tiled): 9x9 Go with 128 or
         64 filters (pad-1 stem), 13x13 Gomoku with 64 filters (pad-3 stem, 17x17 planes) and 19x19 Go with 256 filters."""
         shape_ok = (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 9, 1), (64, 13, 3), (256, 19, 1))
-        return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.bfloat16 and shape_ok
+        if self.dtype == torch.float16:  # the f16 variants exist for the 9x9 x 128 evaluator (82 actions, 128 fully connected units)
+            shape_ok = (self.filters, board_size, self.stem_pad, self.num_actions, self.fc_width) == (128, 9, 1, 82, 128)
+        return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype in (torch.bfloat16, torch.float16) and shape_ok
                 and self.stem_ok and self.npol + self.nval == 3 and self.use_fused_conv and self.use_tiled_tower)
 
     @torch.no_grad()
@@ -361,26 +365,28 @@ class InferenceNet(nn.Module):
         import ctypes
 
         dll, ck = self.binding.dll, self._ck
-        st = ctypes.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream)
+        f16 = self.pack_dtype == torch.float16  # azsp_*_f16: the same kernels on f16 elements (feat is then the engine's AZSP_FEAT_F16_TILED tensor)
+        stem, head, fc = ((dll.azsp_stem_tiled_f16, dll.azsp_head_tiled_f16, dll.azsp_fc_heads_f16) if f16 else
+                          (dll.azsp_stem_tiled, dll.azsp_head_tiled, dll.azsp_fc_heads))
+        st = ctypes.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream) if feat.is_cuda else None  # (host twin: CPU tensors)
         B, C = rows, self.filters
         S = board_size + 2 * (self.stem_pad - 1)  # planes of the tower (network.py:101-105: the Gomoku stem pads by 3)
         a, m, o = self._tiled_buffers(B, S, C, feat.device, slot)
-        ck(dll.azsp_stem_tiled(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, board_size, C, self.stem_pad, 1, st),
-           "azsp_stem_tiled")
+        ck(stem(feat.data_ptr(), self.stem_wp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, board_size, C, self.stem_pad, 1, st), "azsp_stem_tiled")
         a = self._blocks_tiled(a, m, o, B, S, C, st)
         k1, k2 = self.fc_wp.shape[1], self.fc_w1.shape[1]  # head-plane rows padded to the k-steps of azsp_fc_heads (zero padding)
         pol, val, pri_buf, v_buf = self._head_buffers(B, k1, k2, feat.device, slot)
-        ck(dll.azsp_head_tiled(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), pol.data_ptr(), val.data_ptr(),
-                               B, S, C, self.npol, self.nval, k1, k2, st), "azsp_head_tiled")
+        ck(head(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), pol.data_ptr(), val.data_ptr(), B, S, C, self.npol, self.nval, k1, k2, st),
+           "azsp_head_tiled")
         nt = ((self.num_actions + 31) // 32, (self.fc_width + 31) // 32)
-        fused_fc = self.use_fused_fc and nt in ((3, 2), (3, 4), (6, 2), (6, 4), (12, 8))
+        fused_fc = self.use_fused_fc and nt in ((3, 2), (3, 4), (6, 2), (6, 4), (12, 8)) and (not f16 or nt == (3, 4))
         if not fused_fc:
             return self._fc_heads(pol[:B, : self.npol * S * S], val[:B, : self.nval * S * S], priors_out, values_out)
         pri = priors_out if priors_out is not None else pri_buf
         v = values_out if values_out is not None else v_buf
-        ck(dll.azsp_fc_heads(pol.data_ptr(), val.data_ptr(), self.fc_wp.data_ptr(), self.fc_bp.data_ptr(), k1 // 16, self.fc_w1.data_ptr(),
-                             self.fc_b1.data_ptr(), k2 // 16, self.fc_w2.data_ptr(), ctypes.c_float(self.fc_b2), pri.data_ptr(), v.data_ptr(), B,
-                             self.num_actions, self.fc_width, st), "azsp_fc_heads")
+        ck(fc(pol.data_ptr(), val.data_ptr(), self.fc_wp.data_ptr(), self.fc_bp.data_ptr(), k1 // 16, self.fc_w1.data_ptr(), self.fc_b1.data_ptr(),
+              k2 // 16, self.fc_w2.data_ptr(), ctypes.c_float(self.fc_b2), pri.data_ptr(), v.data_ptr(), B, self.num_actions, self.fc_width, st),
+           "azsp_fc_heads")
         return pri, v
 
     @torch.no_grad()
@@ -394,9 +400,9 @@ class InferenceNet(nn.Module):
             return self.forward(x, priors_out, values_out)
         import ctypes
 
-        xb = torch.zeros((B, 32, n, n), dtype=torch.bfloat16, device=x.device).contiguous(memory_format=torch.channels_last)
-        xb[:, : x.shape[1]] = x.to(torch.bfloat16)
-        feat = torch.zeros(self.binding.dll.azsp_tiled_bytes(B, n, 32) // 2, dtype=torch.bfloat16, device=x.device)
+        xb = torch.zeros((B, 32, n, n), dtype=self.pack_dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        xb[:, : x.shape[1]] = x.to(self.pack_dtype)
+        feat = torch.zeros(self.binding.dll.azsp_tiled_bytes(B, n, 32) // 2, dtype=self.pack_dtype, device=x.device)
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         self._ck(self.binding.dll.azsp_tile_layout(xb.data_ptr(), feat.data_ptr(), B, n, 32, 1, st), "azsp_tile_layout")
         pri, v = self.forward_tiled(feat, B, n, priors_out, values_out, slot=3)

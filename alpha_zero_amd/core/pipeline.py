@@ -83,7 +83,8 @@ class SelfPlayActor:
             c_puct_base=c_puct_base, c_puct_init=c_puct_init, warm_up_steps=warm_up_steps, komi=komi, num_to_win=num_to_win,
             resign_threshold=resign_threshold, check_resign_after_steps=check_resign_after_steps,
             disable_resign_ratio=disable_resign_ratio, root_noise=root_noise, deterministic=deterministic,
-            feature_dtype=_abi.FEAT_BF16_TILED if self.tiled_features else _FEAT_OF[net_dtype], training_steps=training_steps, seed=seed, rank=rank,
+            feature_dtype=((_abi.FEAT_F16_TILED if net_dtype == torch.float16 else _abi.FEAT_BF16_TILED) if self.tiled_features
+                           else _FEAT_OF[net_dtype]), training_steps=training_steps, seed=seed, rank=rank,
             device_index=self.device.index or 0)
         for k, v in (engine_kw or {}).items():  # further EngineConfig fields (move logs, max_plies, ...: tests and diagnostics)
             if not hasattr(self.cfg, k):

@@ -157,6 +157,45 @@ __device__ __forceinline__ unsigned cw_pk_max_i16(unsigned a, unsigned b) {
     return r;
 }
 
+// The evaluator kernels exist in two activation / weight formats with the same MFMA rate: bf16 (the default) and f16 (three more
+// significand bits, activations of the BatchNorm-folded networks are far inside its range).  CvFmt<F16> is everything that differs:
+// the MFMA mnemonic, the rounding of two accumulators into one dword, the widening of a packed pair.  The packed-integer ReLU
+// (v_pk_max_i16 against 0: negative floats are negative integers) and every layout are format-independent.
+typedef __attribute__((ext_vector_type(8))) _Float16 cv_f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 cv_f16x2;
+template <bool F16> struct CvFmt;
+template <> struct CvFmt<false> {
+    static __device__ __forceinline__ void mfma_a(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) { cw_mfma_a(acc, wa, b); }
+    static __device__ __forceinline__ void mfma_v(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) { cw_mfma_v(acc, wa, b); }
+    static __device__ __forceinline__ unsigned pk(float a, float b) { return cw_pk_bf16(a, b); }
+    static __device__ __forceinline__ float lo(unsigned v) { return cv_bf16_lo(v); }
+    static __device__ __forceinline__ float hi(unsigned v) { return cv_bf16_hi(v); }
+    static __device__ __forceinline__ unsigned short one(float v) { return (unsigned short)(cv_pack_bf16(v, 0.0f) & 0xffffu); }
+    static __device__ __forceinline__ cv_f32x16 mfma32(const cv_bf16x8& a, const cv_bf16x8& b, const cv_f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct CvFmt<true> {
+    static __device__ __forceinline__ void mfma_a(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(wa), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma_v(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(b));
+    }
+    static __device__ __forceinline__ unsigned pk(float a, float b) {
+        // one v_cvt_pk_f16_f32 (round to nearest even); + infinity (0x7C00) is clamped to the largest finite value by a packed integer min
+        unsigned r;
+        asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, (cv_f16x2){(_Float16)a, (_Float16)b})), "v"(0x7BFF7BFFu));
+        return r;
+    }
+    static __device__ __forceinline__ float lo(unsigned v) { return (float)__builtin_bit_cast(cv_f16x2, v)[0]; }
+    static __device__ __forceinline__ float hi(unsigned v) { return (float)__builtin_bit_cast(cv_f16x2, v)[1]; }
+    static __device__ __forceinline__ unsigned short one(float v) { return (unsigned short)(pk(v, 0.0f) & 0xffffu); }
+    static __device__ __forceinline__ cv_f32x16 mfma32(const cv_bf16x8& a, const cv_bf16x8& b, const cv_f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cv_f16x8, a), __builtin_bit_cast(cv_f16x8, b), c, 0, 0, 0);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_conv3x3_tiled<RES, NCH> (NCH = input-channel chunks of 8: 16 for the tower 128 -> 128, 4 for the stem 17 planes padded to 32 -> 128):
 // the weight-stationary convolution described above with the EPILOGUE SOFTWARE-PIPELINED into the MFMA stream.
@@ -231,12 +270,13 @@ template <int NSTEP> struct CpSched {  // static schedule of one unit's k-steps 
     }
 };
 
-template <bool RES, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
+template <bool RES, int NCH, bool F16 = false> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias,
                   const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
     constexpr int KS = NCH / 2, NSTEP = 9 * KS;
     constexpr int LBUF = NCH * CT_LBLK, XTILE = NCH * CT_GBLK, NPIECE = NCH + NCH / 4;
     typedef CpSched<NSTEP> SC;
+    typedef CvFmt<F16> FM;
     static_assert((RES ? SC::res_step(7, 2) : SC::plain_step(7)) < SC::BAR_STEP, "epilogue must end before the barrier step");
     static_assert(SC::dma_step(NPIECE - 1) < NSTEP - 4, "DMA pieces must be issued early in their unit");
     constexpr int VM_AFTER_DMA = SC::after_last_dma(RES, NPIECE);
@@ -326,18 +366,18 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
             // plain v_add_f32: the compiler would SLP-pack two adds into v_pk_add_f32, which costs ~11 cycles of matrix-core time
             // beside MFMAs (profiles/r02_mfma_valu_probe.txt) where a scalar add is free
             if (ph == 0) {
-                ev[0] = cw_add_f32(acc[q][j][rq * 4 + 0], cv_bf16_lo(r2.x));
-                ev[1] = cw_add_f32(acc[q][j][rq * 4 + 1], cv_bf16_hi(r2.x));
+                ev[0] = cw_add_f32(acc[q][j][rq * 4 + 0], FM::lo(r2.x));
+                ev[1] = cw_add_f32(acc[q][j][rq * 4 + 1], FM::hi(r2.x));
             } else if (ph == 1) {
-                ev[2] = cw_add_f32(acc[q][j][rq * 4 + 2], cv_bf16_lo(r2.y));
-                ev[3] = cw_add_f32(acc[q][j][rq * 4 + 3], cv_bf16_hi(r2.y));
+                ev[2] = cw_add_f32(acc[q][j][rq * 4 + 2], FM::lo(r2.y));
+                ev[3] = cw_add_f32(acc[q][j][rq * 4 + 3], FM::hi(r2.y));
             }
         } else if (ph == 2) {
             ev[0] = acc[q][j][rq * 4 + 0], ev[1] = acc[q][j][rq * 4 + 1], ev[2] = acc[q][j][rq * 4 + 2], ev[3] = acc[q][j][rq * 4 + 3];
         }
         if (ph == 2) {
             const unsigned gq = (lmap[mb + j] >> 16) * 16u + (unsigned)(hi * 8);
-            const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(cw_pk_bf16(ev[0], ev[1]), lo16), cw_pk_max_i16(cw_pk_bf16(ev[2], ev[3]), lo16)};
+            const cv_u32x2 o = (cv_u32x2){cw_pk_max_i16(FM::pk(ev[0], ev[1]), lo16), cw_pk_max_i16(FM::pk(ev[2], ev[3]), lo16)};
             if (store_ok) *(cv_u32x2*)(out + rq * CT_GBLK + gq) = o;
         }
     };
@@ -378,8 +418,8 @@ k_conv3x3_tiled(const unsigned char* __restrict__ x, const unsigned short* __res
                 else load_step(nb0, nb1, t + CP_RING - 1 - NSTEP, (u * NSTEP + t + CP_RING - 1) % CP_RING);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if constexpr (t < 64) cw_mfma_a(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
-                    else cw_mfma_v(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
+                    if constexpr (t < 64) FM::mfma_a(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
+                    else FM::mfma_v(acc[q][j], wf[t], bb[(u * NSTEP + t) % CP_RING][j]);
                 }
                 // ---- riders of this k-step -------------------------------------------------------------------------------------
                 if constexpr (t == NSTEP - 6) acc[pq][0] = *bias_ptr;  // next unit's accumulators start from the bias
@@ -439,7 +479,7 @@ __global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned ch
 // out[b][pl][q] = relu(sum_c w[pl][c] x[b][q][c] + bias[pl]); planes [0, npol) go to pol_out [boards][npol][81], the rest to
 // val_out [boards][NPL - npol][S*S] (bf16; plane-major per board = nn.Flatten order; rows pol_stride / val_stride elements
 // apart), any (S, C) of the tiled layout.  HBM-bound: one pass over the tower output.
-template <int NPL> __global__ void __launch_bounds__(256)
+template <int NPL, bool F16 = false> __global__ void __launch_bounds__(256)
 k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, unsigned short* __restrict__ pol_out,
              unsigned short* __restrict__ val_out, long long npos, int npol, int C, int P2, int tile_rows, int pol_stride, int val_stride) {
     extern __shared__ float ws[];  // [NPL][C]
@@ -457,7 +497,8 @@ k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll 4
     for (int c = 0; c < nch; ++c) {
         const cv_u32x4 v = *(const cv_u32x4*)(src + (size_t)c * tile_rows * 16);
-        const float f[8] = {cv_bf16_lo(v.x), cv_bf16_hi(v.x), cv_bf16_lo(v.y), cv_bf16_hi(v.y), cv_bf16_lo(v.z), cv_bf16_hi(v.z), cv_bf16_lo(v.w), cv_bf16_hi(v.w)};
+        typedef CvFmt<F16> FM;
+        const float f[8] = {FM::lo(v.x), FM::hi(v.x), FM::lo(v.y), FM::hi(v.y), FM::lo(v.z), FM::hi(v.z), FM::lo(v.w), FM::hi(v.w)};
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
@@ -466,7 +507,7 @@ k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, c
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) {
         const float v = fmaxf(acc[pl], 0.0f);
-        const unsigned short h = (unsigned short)(cv_pack_bf16(v, 0.0f) & 0xffffu);
+        const unsigned short h = CvFmt<F16>::one(v);
         if (pl < npol) pol_out[(size_t)board * pol_stride + pl * P2 + q] = h;
         else val_out[(size_t)board * val_stride + (pl - npol) * P2 + q] = h;
     }
@@ -477,7 +518,7 @@ k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, c
 // as MFMA GEMMs D[neuron][board] with one wave per 32 boards: A = zero-padded bf16 weights [NT * 32][KS * 16] streamed from L2,
 // B = the boards' head planes straight from global memory (row stride = KS * 16 elements, so every fragment is one aligned
 // 16-byte load), softmax / tanh on the accumulators (a board's 32 t neurons live in lanes l and l + 32).
-template <int NT1, int NT2> __global__ void __launch_bounds__(256)
+template <int NT1, int NT2, bool F16 = false> __global__ void __launch_bounds__(256)
 k_fc_heads(const unsigned short* __restrict__ pol, const unsigned short* __restrict__ val, const unsigned short* __restrict__ wp,
            const float* __restrict__ bp, int ks1, const unsigned short* __restrict__ w1, const float* __restrict__ b1, int ks2,
            const float* __restrict__ w2, float b2, float* __restrict__ priors, float* __restrict__ values, long long boards, int A) {
@@ -499,7 +540,7 @@ k_fc_heads(const unsigned short* __restrict__ pol, const unsigned short* __restr
 #pragma unroll
             for (int t = 0; t < NT1; ++t) {
                 const cv_bf16x8 af = *(const cv_bf16x8*)(wrow + (size_t)t * 32 * ks1 * 16 + s * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                acc[t] = CvFmt<F16>::mfma32(af, bf, acc[t]);
             }
         }
         float mx = -__builtin_inff();
@@ -548,7 +589,7 @@ k_fc_heads(const unsigned short* __restrict__ pol, const unsigned short* __restr
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
                 const cv_bf16x8 af = *(const cv_bf16x8*)(wrow + (size_t)t * 32 * ks2 * 16 + s * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                acc[t] = CvFmt<F16>::mfma32(af, bf, acc[t]);
             }
         }
         float part = 0.0f;

@@ -28,7 +28,7 @@
 
 enum { AZS_NEED_ROOT = 0, AZS_SEARCH = 1, AZS_MOVE_DONE = 2, AZS_IDLE = 3, AZS_WAIT_BUF = 4 };
 enum { AZ_ERR_NODES = 1, AZ_ERR_SAMPLE = 4, AZ_ERR_STAGE = 8 };  // bit 2 (tree depth) retired: deep paths walk parent links
-enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FEAT_BF16_TILED = 4 };
+enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FEAT_BF16_TILED = 4, AZ_FEAT_F16_TILED = 5 };
 enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
 // statistics counters (u64 each)
 enum { AZC_SIMS = 0, AZC_NODE_VISITS, AZC_BACKUP_EDGES, AZC_LEAVES, AZC_DUP_LEAVES, AZC_TERMINAL_HITS, AZC_MOVES,
@@ -644,7 +644,7 @@ template <class Wv, int N, int GAME> struct Engine {
             }
         });
     }
-    // The evaluator's tiled input layout (include/azsp.h azsp_stem_tiled): [tile = T rows][4 chunks][T NP positions][8] bf16 with
+    // The evaluator's tiled input layout (include/azsp.h azsp_stem_tiled): [tile = T rows][4 chunks][T NP positions][8] bf16 (or f16) with
     // T = max(1, 256 / NP) boards per tile (3 at 9x9), the 17 planes zero-padded to 32 channels.  Chunks 0..1 = the 16 stone planes, chunk 2 = colour plane + 7 zeros; chunk 3 and
     // the padding are never written (the tensor is zero-initialised by its owner).
     AZ_HD void emit_tiled(void* feat, int slot, int me) {
@@ -652,7 +652,8 @@ template <class Wv, int N, int GAME> struct Engine {
         const size_t r = (size_t)g * c.P + slot, tile = r / TBF;
         const int sub = (int)(r - tile * TBF);
         uint16_t* base = (uint16_t*)feat + tile * (size_t)(4 * TBF * NP * 8) + (size_t)sub * NP * 8;
-        const u32 black = me == 0 ? 0x3F80u : 0u;
+        const u32 one = c.feat_dtype == AZ_FEAT_F16_TILED ? 0x3C00u : 0x3F80u;  // 1.0 in f16 / bf16
+        const u32 black = me == 0 ? one : 0u;
         // One lane per POSITION (81 positions: lanes 0-63, then 0-16): the 16 plane words of its 64-position group are
         // wave-uniform LDS reads (broadcast), a stone is one bit-field extract, two planes make one dword (bf16 1.0 = 0x3F80) with two
         // multiply-adds, a chunk is one 16-byte store.  (The first version walked (chunk, position) pairs with 8 per-lane 64-bit
@@ -669,7 +670,7 @@ template <class Wv, int N, int GAME> struct Engine {
                     for (int k = 0; k < 4; ++k) {
                         const u64 w0 = sc.planes[cc * 8 + 2 * k][w], w1 = sc.planes[cc * 8 + 2 * k + 1][w];
                         const u32 x0 = hi_half ? (u32)(w0 >> 32) : (u32)w0, x1 = hi_half ? (u32)(w1 >> 32) : (u32)w1;
-                        d[k] = ((x0 >> sh) & 1u) * 0x3F80u + ((x1 >> sh) & 1u) * 0x3F800000u;
+                        d[k] = ((x0 >> sh) & 1u) * one + ((x1 >> sh) & 1u) * (one << 16);
                     }
                     u32* o = (u32*)(base + ((size_t)cc * TBF * NP + p) * 8);
                     o[0] = d[0];
@@ -686,7 +687,7 @@ template <class Wv, int N, int GAME> struct Engine {
         });
     }
     AZ_HD void write_features(void* feat, int slot, int me) {
-        if (c.feat_dtype == AZ_FEAT_BF16_TILED) {
+        if (c.feat_dtype == AZ_FEAT_BF16_TILED || c.feat_dtype == AZ_FEAT_F16_TILED) {
             emit_tiled(feat, slot, me);
             return;
         }

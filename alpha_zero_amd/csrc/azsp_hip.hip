@@ -135,7 +135,8 @@ static int cu_count() {
     return n_cu;
 }
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
-                         int relu, void* st) {
+                         int relu, void* st, int f16) {
+    if (f16 && (S != CV_S || C != CV_C)) return 1;  // f16 activations: the 9x9 x 128 kernels only
     if (C == C6_C && (S == 17 || S == 9)) {  // 64 filters: 17x17 planes (13x13 Gomoku network, one board per tile) or 9x9 Go (three boards per tile)
         const int n_cu = cu_count();
         if (n_cu < 0) return -1;
@@ -177,12 +178,17 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
     if (n_cu < 0) return -1;
     const long long ntiles = (boards + CV_TB - 1) / CV_TB;
     const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);  // one persistent workgroup per CU
-    if (res)
-        hipLaunchKernelGGL((k_conv3x3_tiled<true, 16>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
-                           (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
-    else
-        hipLaunchKernelGGL((k_conv3x3_tiled<false, 16>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
-                           (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu);
+#define AZ_CT(RES, F16)                                                                                                              \
+    hipLaunchKernelGGL((k_conv3x3_tiled<RES, 16, F16>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, \
+                       (const unsigned short*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)ntiles, relu)
+    if (f16) {
+        if (res) AZ_CT(true, true);
+        else AZ_CT(false, true);
+    } else {
+        if (res) AZ_CT(true, false);
+        else AZ_CT(false, false);
+    }
+#undef AZ_CT
     return AZ_HIP(hipGetLastError());
 }
 int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
@@ -200,9 +206,10 @@ int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const 
                            (const unsigned short*)w2, b2, (unsigned char*)y, (int)ntiles);
     return AZ_HIP(hipGetLastError());
 }
-int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st) {
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st, int f16) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
+    if (f16 && (S != CV_S || C != CV_C || pad != 1)) return 1;  // f16 activations: the 9x9 x 128 kernels only
     if (C == C6_C && ((S == 13 && pad == 3) || (S == 9 && pad == 1))) {  // Gomoku: 13x13 boards -> 17x17 planes; Go 9x9 x 64: three boards per tile
         const long long ntiles = S == 13 ? boards : (boards + 2) / 3;
         const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(CW_THREADS);
@@ -224,30 +231,40 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
     if (S != CV_S || C != CV_C || pad != 1) return 1;
     const long long ntiles = (boards + CV_TB - 1) / CV_TB;
     const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
-    hipLaunchKernelGGL((k_conv3x3_tiled<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w,
-                       bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)ntiles, relu);
+    if (f16)
+        hipLaunchKernelGGL((k_conv3x3_tiled<false, 4, true>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                           (const unsigned short*)w, bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)ntiles, relu);
+    else
+        hipLaunchKernelGGL((k_conv3x3_tiled<false, 4>), dim3(grid), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                           (const unsigned short*)w, bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)ntiles, relu);
     return AZ_HIP(hipGetLastError());
 }
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
-                      int pol_stride, int val_stride, void* st) {
+                      int pol_stride, int val_stride, void* st, int f16) {
     if (C % 8 || C > 1024 || npol + nval != 3) return 1;
     const long long npos = boards * S * S;
-    hipLaunchKernelGGL(k_head_tiled<3>, dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
-                       (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S, cv_tile_boards(S) * S * S,
-                       pol_stride, val_stride);
+    if (f16)
+        hipLaunchKernelGGL((k_head_tiled<3, true>), dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
+                           (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S,
+                           cv_tile_boards(S) * S * S, pol_stride, val_stride);
+    else
+        hipLaunchKernelGGL((k_head_tiled<3>), dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
+                           (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S,
+                           cv_tile_boards(S) * S * S, pol_stride, val_stride);
     return AZ_HIP(hipGetLastError());
 }
 int launch_fc_heads(const FcHeadsArgs& a, void* st) {
     const int nt1 = (a.A + 31) / 32, nt2 = (a.F + 31) / 32;
     const unsigned grid = (unsigned)((a.boards + 127) / 128);
-#define AZ_FC_CASE(T1, T2)                                                                                                              \
-    if (nt1 == T1 && nt2 == T2) {                                                                                                       \
-        hipLaunchKernelGGL((k_fc_heads<T1, T2>), dim3(grid), dim3(256), 0, (hipStream_t)st, (const unsigned short*)a.pol,                 \
+#define AZ_FC_CASE(T1, T2, F16)                                                                                                         \
+    if (nt1 == T1 && nt2 == T2 && (a.f16 != 0) == F16) {                                                                                \
+        hipLaunchKernelGGL((k_fc_heads<T1, T2, F16>), dim3(grid), dim3(256), 0, (hipStream_t)st, (const unsigned short*)a.pol,            \
                            (const unsigned short*)a.val, (const unsigned short*)a.wp, a.bp, a.ks1, (const unsigned short*)a.w1, a.b1, a.ks2, \
                            a.w2, a.b2, a.priors, a.values, a.boards, a.A);                                                               \
         return AZ_HIP(hipGetLastError());                                                                                               \
     }
-    AZ_FC_CASE(3, 2) AZ_FC_CASE(3, 4) AZ_FC_CASE(6, 2) AZ_FC_CASE(6, 4) AZ_FC_CASE(12, 8)
+    AZ_FC_CASE(3, 2, false) AZ_FC_CASE(3, 4, false) AZ_FC_CASE(6, 2, false) AZ_FC_CASE(6, 4, false) AZ_FC_CASE(12, 8, false)
+    AZ_FC_CASE(3, 4, true)  // f16: the 9x9 x 128 evaluator (82 actions, 128 units)
 #undef AZ_FC_CASE
     return 1;
 }

@@ -541,8 +541,9 @@ int launch_replay_gather(const ReplayGatherArgs& a, long long total, void* strea
 // exclusive scan of the staging-buffer lengths in rotated buffer order -> ofs[n2][2], counts[0..1] = samples / games handed out
 int launch_harvest_scan(const int* len, int* ofs, int* counts, int n2, int rot, int cap, int max_games, void* stream);
 // returns 0 ok, 1 unsupported shape, -1 launch error
+// f16 = 1: activations and weights are f16 instead of bf16 (same layouts, same kernels, the f16 MFMA / conversions: CvFmt in az_conv.h)
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
-                         int relu, void* stream);
+                         int relu, void* stream, int f16 = 0);
 int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
                           void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
@@ -560,9 +561,10 @@ struct HeadSplitArgs {
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* stream);
 int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* stream);
 int launch_head_split(const HeadSplitArgs& a, void* stream);
-int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
+                      int f16 = 0);
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
-                      int pol_stride, int val_stride, void* stream);
+                      int pol_stride, int val_stride, void* stream, int f16 = 0);
 struct FcHeadsArgs {
     const void *pol, *val, *wp, *w1;  // bf16: head planes (rows ks * 16 elements apart) and zero-padded weights [NT * 32][ks * 16]
     const float *bp, *b1, *w2;        // fp32, padded to NT * 32
@@ -570,6 +572,7 @@ struct FcHeadsArgs {
     float *priors, *values;
     long long boards;
     int ks1, ks2, A, F;
+    int f16;  // head planes and weights are f16 instead of bf16
 };
 int launch_fc_heads(const FcHeadsArgs& a, void* stream);
 }  // namespace azb
@@ -1023,12 +1026,20 @@ int azsp_tile_layout(const void* src, void* dst, int64_t boards, int32_t S, int3
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
-int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
-                       int32_t relu, void* stream) {
+static int az_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
+                            int32_t relu, void* stream, int f16) {
     if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    const int rc = azb::launch_conv3x3_tiled(x, w, bias, res, y, (long long)boards, S, C, relu, stream, f16);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+int azsp_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
+                       int32_t relu, void* stream) {
+    return az_conv3x3_tiled(x, w, bias, res, y, boards, S, C, relu, stream, 0);
+}
+int azsp_conv3x3_tiled_f16(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
+                           int32_t relu, void* stream) {
+    return az_conv3x3_tiled(x, w, bias, res, y, boards, S, C, relu, stream, 1);
 }
 
 int64_t azsp_split_bytes(int64_t boards, int32_t S, int32_t C) {
@@ -1097,32 +1108,56 @@ int azsp_replay_gather(const int8_t* ring_states, const float* ring_pi, const fl
     return azb::launch_replay_gather(a, total, stream) == 0 ? AZSP_OK : AZSP_EDEVICE;
 }
 
-int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
-                    void* stream) {
+static int az_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
+                         void* stream, int f16) {
     if (!x || !w || !bias || !y || boards < 0 || boards > 0x7fffffff || pad < 1) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_stem_tiled(x, w, bias, y, (long long)boards, S, C, pad, relu, stream);
+    const int rc = azb::launch_stem_tiled(x, w, bias, y, (long long)boards, S, C, pad, relu, stream, f16);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
+int azsp_stem_tiled(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
+                    void* stream) {
+    return az_stem_tiled(x, w, bias, y, boards, S, C, pad, relu, stream, 0);
+}
+int azsp_stem_tiled_f16(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
+                        void* stream) {
+    return az_stem_tiled(x, w, bias, y, boards, S, C, pad, relu, stream, 1);
+}
 
-int azsp_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, int64_t boards, int32_t S, int32_t C, int32_t npol,
-                    int32_t nval, int32_t pol_stride, int32_t val_stride, void* stream) {
+static int az_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, int64_t boards, int32_t S, int32_t C, int32_t npol,
+                         int32_t nval, int32_t pol_stride, int32_t val_stride, void* stream, int f16) {
     if (!x || !w || !bias || !pol || !val || boards < 0 || boards > 0x7fffffff || npol < 1 || nval < 1) return AZSP_EINVAL;
     if (pol_stride == 0) pol_stride = npol * S * S;
     if (val_stride == 0) val_stride = nval * S * S;
     if (pol_stride < npol * S * S || val_stride < nval * S * S) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_head_tiled(x, w, bias, pol, val, (long long)boards, S, C, npol, nval, pol_stride, val_stride, stream);
+    const int rc = azb::launch_head_tiled(x, w, bias, pol, val, (long long)boards, S, C, npol, nval, pol_stride, val_stride, stream, f16);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
+int azsp_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, int64_t boards, int32_t S, int32_t C, int32_t npol,
+                    int32_t nval, int32_t pol_stride, int32_t val_stride, void* stream) {
+    return az_head_tiled(x, w, bias, pol, val, boards, S, C, npol, nval, pol_stride, val_stride, stream, 0);
+}
+int azsp_head_tiled_f16(const void* x, const float* w, const float* bias, void* pol, void* val, int64_t boards, int32_t S, int32_t C, int32_t npol,
+                        int32_t nval, int32_t pol_stride, int32_t val_stride, void* stream) {
+    return az_head_tiled(x, w, bias, pol, val, boards, S, C, npol, nval, pol_stride, val_stride, stream, 1);
+}
 
-int azsp_fc_heads(const void* pol, const void* val, const void* wp, const float* bp, int32_t ks1, const void* w1, const float* b1, int32_t ks2,
-                  const float* w2, float b2, float* priors, float* values, int64_t boards, int32_t A, int32_t F, void* stream) {
+static int az_fc_heads(const void* pol, const void* val, const void* wp, const float* bp, int32_t ks1, const void* w1, const float* b1, int32_t ks2,
+                       const float* w2, float b2, float* priors, float* values, int64_t boards, int32_t A, int32_t F, void* stream, int f16) {
     if (!pol || !val || !wp || !bp || !w1 || !b1 || !w2 || !priors || !values || boards < 0 || ks1 < 1 || ks2 < 1 || A < 1 || F < 1) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    azb::FcHeadsArgs a = {pol, val, wp, w1, bp, b1, w2, b2, priors, values, (long long)boards, ks1, ks2, A, F};
+    azb::FcHeadsArgs a = {pol, val, wp, w1, bp, b1, w2, b2, priors, values, (long long)boards, ks1, ks2, A, F, f16};
     const int rc = azb::launch_fc_heads(a, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+int azsp_fc_heads(const void* pol, const void* val, const void* wp, const float* bp, int32_t ks1, const void* w1, const float* b1, int32_t ks2,
+                  const float* w2, float b2, float* priors, float* values, int64_t boards, int32_t A, int32_t F, void* stream) {
+    return az_fc_heads(pol, val, wp, bp, ks1, w1, b1, ks2, w2, b2, priors, values, boards, A, F, stream, 0);
+}
+int azsp_fc_heads_f16(const void* pol, const void* val, const void* wp, const float* bp, int32_t ks1, const void* w1, const float* b1, int32_t ks2,
+                      const float* w2, float b2, float* priors, float* values, int64_t boards, int32_t A, int32_t F, void* stream) {
+    return az_fc_heads(pol, val, wp, bp, ks1, w1, b1, ks2, w2, b2, priors, values, boards, A, F, stream, 1);
 }
 
 }  // extern "C"

@@ -326,6 +326,7 @@ def main(argv=None):
         import ctypes
 
         inf, dll = actor.infer, actor.binding.dll
+        conv_fn = dll.azsp_conv3x3_tiled_f16 if args.net_dtype == "fp16" else dll.azsp_conv3x3_tiled
         a, m, o = inf._tiled  # real activations of the last forward
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         rows = eng.rows
@@ -345,10 +346,10 @@ def main(argv=None):
                     ev[k].record()
                     a, o = o, a
                     continue
-                assert dll.azsp_conv3x3_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
+                assert conv_fn(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
                 k += 1
                 ev[k].record()
-                assert dll.azsp_conv3x3_tiled(m.data_ptr(), inf.wp[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows,
+                assert conv_fn(m.data_ptr(), inf.wp[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows,
                                               S_t, args.filters, 1, st) == 0
                 k += 1
                 ev[k].record()
@@ -439,7 +440,7 @@ def main(argv=None):
             else:
                 kname = {(9, 128): "k_conv3x3_tiled", (17, 64): "k_conv3x3_t64", (9, 64): "k_conv3x3_t64",
                          (19, 256): "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get((S_t, args.filters), "conv3x3")
-                kname += " (weight-stationary MFMA 3x3 convolution of the residual tower, bf16)"
+                kname += f" (weight-stationary MFMA 3x3 convolution of the residual tower, {'f16' if args.net_dtype == 'fp16' else 'bf16'})"
                 passes = 4.5 if S_t == 19 else 2.5
             launches_per_step = args.blocks * (1 if fused else 2)
             roofline = {"kernel": kname,

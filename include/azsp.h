@@ -37,6 +37,7 @@
  *   azsp_split_layout / azsp_split_bytes the split-precision tower's activation layout
  *   azsp_split_features / azsp_stem_split / azsp_head_split   the stem and both heads of the same fp32-class evaluator
  *                                     (core/network.py:101-156)
+ *   azsp_*_tiled_f16 / azsp_fc_heads_f16  the bf16 evaluator entries with f16 activations and weights
  *
  * Conventions: every function returns 0 on success or a negative AZSP_E* code; the message is
  * available from azsp_last_error().  No exceptions and no callbacks cross this boundary.  Pointers
@@ -61,6 +62,7 @@ extern "C" {
 #define AZSP_FEAT_BF16 2
 #define AZSP_FEAT_F16 3
 #define AZSP_FEAT_BF16_TILED 4 /* bf16 in the evaluator's tiled layout, 17 planes padded to 32 channels (azsp_stem_tiled) */
+#define AZSP_FEAT_F16_TILED 5  /* the same layout with f16 elements (azsp_stem_tiled_f16) */
 
 #define AZSP_OK 0
 #define AZSP_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -325,6 +327,21 @@ int azsp_head_tiled(const void* x_tiled_dev, const float* w_dev, const float* bi
 int azsp_fc_heads(const void* pol_dev, const void* val_dev, const void* wp_dev, const float* bp_dev, int32_t k1_steps, const void* w1_dev,
                   const float* b1_dev, int32_t k2_steps, const float* w2_dev, float b2, float* priors_dev, float* values_dev, int64_t boards,
                   int32_t num_actions, int32_t fc_width, void* stream);
+
+/* f16 variants of the bf16 evaluator entries above: identical layouts, arguments and kernels, with f16 activations / weights / head
+ * planes (the f16 MFMA runs at the bf16 rate and carries three more significand bits; outputs are clamped to f16's finite range).
+ * Features: feature_dtype = AZSP_FEAT_F16_TILED.  On the device: the 9x9 x 128 evaluator ((S, C) = (9, 128), pad 1, 82 actions,
+ * 128 fully connected units); AZSP_EINVAL for other shapes. */
+int azsp_conv3x3_tiled_f16(const void* x_dev, const void* w_packed_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
+                           int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+int azsp_stem_tiled_f16(const void* features_tiled_dev, const void* w_packed_dev, const float* bias_dev, void* y_tiled_dev, int64_t boards,
+                        int32_t board_size, int32_t channels, int32_t pad, int32_t relu, void* stream);
+int azsp_head_tiled_f16(const void* x_tiled_dev, const float* w_dev, const float* bias_dev, void* pol_out_dev, void* val_out_dev, int64_t boards,
+                        int32_t board_size, int32_t channels, int32_t policy_planes, int32_t value_planes, int32_t pol_stride,
+                        int32_t val_stride, void* stream);
+int azsp_fc_heads_f16(const void* pol_dev, const void* val_dev, const void* wp_dev, const float* bp_dev, int32_t k1_steps, const void* w1_dev,
+                      const float* b1_dev, int32_t k2_steps, const float* w2_dev, float b2, float* priors_dev, float* values_dev, int64_t boards,
+                      int32_t num_actions, int32_t fc_width, void* stream);
 
 #ifdef __cplusplus
 }

@@ -118,20 +118,21 @@ def untile_features(flat, rows, n):
     (only 0.0 / 1.0, padding channels zero)."""
     NP = n * n
     tb = max(1, 256 // NP)
+    one = 0x3C00 if flat.dtype == torch.float16 else 0x3F80  # AZSP_FEAT_F16_TILED / _BF16_TILED
     t = flat.view(torch.int16).cpu().numpy().reshape(-1, 4, tb * NP, 8)
     x = np.ascontiguousarray(t.transpose(0, 2, 1, 3)).reshape(-1, 32)[: rows * NP].reshape(rows, NP, 32)
-    assert np.all((x == 0) | (x == 0x3F80)) and not x[:, :, 17:].any()
-    return np.ascontiguousarray((x[:, :, :17] == 0x3F80).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
+    assert np.all((x == 0) | (x == one)) and not x[:, :, 17:].any()
+    return np.ascontiguousarray((x[:, :, :17] == one).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
 
 
-def tile_features(x):
-    """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_BF16_TILED tensor (flat bf16), the inverse of untile_features."""
+def tile_features(x, dtype=torch.bfloat16):
+    """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_BF16_TILED (or, dtype = float16, _F16_TILED) tensor, the inverse of untile_features."""
     rows, _, n, _ = x.shape
     NP = n * n
     tb = max(1, 256 // NP)
     ntiles = (rows + tb - 1) // tb
-    full = torch.zeros(ntiles * tb * NP, 32, dtype=torch.bfloat16)
-    full[: rows * NP, :17] = x.reshape(rows, 17, NP).permute(0, 2, 1).reshape(rows * NP, 17).to(torch.bfloat16)
+    full = torch.zeros(ntiles * tb * NP, 32, dtype=dtype)
+    full[: rows * NP, :17] = x.reshape(rows, 17, NP).permute(0, 2, 1).reshape(rows * NP, 17).to(dtype)
     return full.view(ntiles, tb * NP, 4, 8).permute(0, 2, 1, 3).contiguous().reshape(-1)
 
 

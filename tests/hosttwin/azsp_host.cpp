@@ -66,12 +66,13 @@ int launch_tile_layout(const void* src, void* dst, long long boards, int S, int 
     return 0;
 }
 int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C,
-                         int relu, void*) {
+                         int relu, void*, int f16) {
+    if (f16 && (S != 9 || C != 128)) return 1;
     const size_t n = (size_t)boards * S * S * C;
     std::vector<unsigned short> xn(n), rn(res ? n : 0), yn(n);
     host_tile_layout((const unsigned short*)x, xn.data(), boards, S, C, 0);
     if (res) host_tile_layout((const unsigned short*)res, rn.data(), boards, S, C, 0);
-    cv_host_conv3x3(xn.data(), (const unsigned short*)w, bias, res ? rn.data() : nullptr, yn.data(), (int)boards, S, C, relu);
+    cv_host_conv3x3_io(xn.data(), (const unsigned short*)w, bias, res ? rn.data() : nullptr, yn.data(), (int)boards, S, C, C, relu, f16);
     host_tile_layout(yn.data(), (unsigned short*)y, boards, S, C, 1);
     return 0;
 }
@@ -87,29 +88,6 @@ int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const 
     return 0;
 }
 // ---- split-precision tower (azsp_split_layout / azsp_conv3x3_split): plain loops on the same hi / lo f16 arithmetic ----
-static inline unsigned short sp_h_from_f32(float f) {  // fp32 -> f16, round to nearest even, subnormals kept
-    union { unsigned u; float f; } v;
-    v.f = f;
-    const unsigned sign = (v.u >> 16) & 0x8000u, x = v.u & 0x7fffffffu;
-    if (x >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
-    if (x >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);  // >= 65520 rounds to infinity
-    if (x < 0x38800000u) {                                           // below 2^-14: a multiple of 2^-24
-        v.u = x;
-        return (unsigned short)(sign | (unsigned)nearbyintf(v.f * 16777216.0f));
-    }
-    unsigned h = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
-    const unsigned rem = x & 0x1fffu;
-    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
-    return (unsigned short)(sign | h);
-}
-static inline float sp_h_to_f32(unsigned short h) {
-    const int e = (h >> 10) & 31, m = h & 0x3ff;
-    float v;
-    if (e == 0) v = ldexpf((float)m, -24);
-    else if (e == 31) v = m ? NAN : INFINITY;
-    else v = ldexpf((float)(m | 0x400), e - 25);
-    return (h & 0x8000) ? -v : v;
-}
 static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
     h = sp_h_from_f32(v);
@@ -225,7 +203,8 @@ int launch_head_split(const HeadSplitArgs& a, void*) {
     }
     return 0;
 }
-int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*) {
+int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*, int f16) {
+    if (f16 && (S != 9 || C != 128 || pad != 1)) return 1;
     // un-tile the 32-channel features, embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1), pad-1 convolution
     const int So = S + 2 * (pad - 1), off = pad - 1;
     std::vector<unsigned short> xn((size_t)boards * S * S * 32), xe((size_t)boards * So * So * 32, 0), yn((size_t)boards * So * So * C);
@@ -235,12 +214,12 @@ int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, 
             for (int xx = 0; xx < S; ++xx)
                 for (int c = 0; c < 32; ++c)
                     xe[(((size_t)b * So + yy + off) * So + xx + off) * 32 + c] = xn[(((size_t)b * S + yy) * S + xx) * 32 + c];
-    cv_host_conv3x3_io(xe.data(), (const unsigned short*)w, bias, nullptr, yn.data(), (int)boards, So, 32, C, relu);
+    cv_host_conv3x3_io(xe.data(), (const unsigned short*)w, bias, nullptr, yn.data(), (int)boards, So, 32, C, relu, f16);
     host_tile_layout(yn.data(), (unsigned short*)y, boards, So, C, 1);
     return 0;
 }
 int launch_head_tiled(const void* x, const float* w, const float* bias, void* pol, void* val, long long boards, int S, int C, int npol, int nval,
-                      int pol_stride, int val_stride, void*) {
+                      int pol_stride, int val_stride, void*, int f16) {
     const size_t n = (size_t)boards * S * S * C;
     std::vector<unsigned short> xn(n);
     host_tile_layout((const unsigned short*)x, xn.data(), boards, S, C, 0);
@@ -249,8 +228,8 @@ int launch_head_tiled(const void* x, const float* w, const float* bias, void* po
         for (int q = 0; q < P2; ++q)
             for (int pl = 0; pl < npol + nval; ++pl) {
                 float acc = bias[pl];
-                for (int ci = 0; ci < C; ++ci) acc += cv_h_bf16(xn[((size_t)b * P2 + q) * C + ci]) * w[pl * C + ci];
-                const unsigned short h = cv_h_to_bf16(acc > 0.0f ? acc : 0.0f);
+                for (int ci = 0; ci < C; ++ci) acc += cv_h_in(xn[((size_t)b * P2 + q) * C + ci], f16) * w[pl * C + ci];
+                const unsigned short h = cv_h_out(acc > 0.0f ? acc : 0.0f, f16);
                 if (pl < npol) ((unsigned short*)pol)[(size_t)b * pol_stride + pl * P2 + q] = h;
                 else ((unsigned short*)val)[(size_t)b * val_stride + (pl - npol) * P2 + q] = h;
             }
@@ -265,7 +244,7 @@ int launch_fc_heads(const FcHeadsArgs& a, void*) {
         float mx = -1e30f;
         for (int n = 0; n < a.A; ++n) {
             float acc = 0.0f;
-            for (int k = 0; k < k1; ++k) acc += cv_h_bf16(wp[(size_t)n * k1 + k]) * cv_h_bf16(pol[(size_t)b * k1 + k]);
+            for (int k = 0; k < k1; ++k) acc += cv_h_in(wp[(size_t)n * k1 + k], a.f16) * cv_h_in(pol[(size_t)b * k1 + k], a.f16);
             lg[n] = acc + a.bp[n];
             if (lg[n] > mx) mx = lg[n];
         }
@@ -278,7 +257,7 @@ int launch_fc_heads(const FcHeadsArgs& a, void*) {
         float v = 0.0f;
         for (int n = 0; n < a.F; ++n) {
             float acc = 0.0f;
-            for (int k = 0; k < k2; ++k) acc += cv_h_bf16(w1[(size_t)n * k2 + k]) * cv_h_bf16(val[(size_t)b * k2 + k]);
+            for (int k = 0; k < k2; ++k) acc += cv_h_in(w1[(size_t)n * k2 + k], a.f16) * cv_h_in(val[(size_t)b * k2 + k], a.f16);
             acc += a.b1[n];
             v += (acc > 0.0f ? acc : 0.0f) * a.w2[n];
         }

@@ -32,13 +32,14 @@ def test_search_and_actor_match_reference(name):
     pc.check_mcts_golden("host", name)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
 @pytest.mark.parametrize("name", ["go5_p4_s48_resign", "go9_p1_s50", "gomoku7_p8_s64"])
-def test_tiled_feature_layout_matches_reference(name):
-    """Observation planes written in the evaluator's tiled layout (AZSP_FEAT_BF16_TILED) carry exactly the reference's
-    planes: the whole golden game replays bit-exactly when the evaluator sees the un-tiled tensor."""
+def test_tiled_feature_layout_matches_reference(name, fmt):
+    """Observation planes written in the evaluator's tiled layout (AZSP_FEAT_BF16_TILED / AZSP_FEAT_F16_TILED) carry exactly the
+    reference's planes: the whole golden game replays bit-exactly when the evaluator sees the un-tiled tensor."""
     from alpha_zero_amd import _abi
 
-    pc.check_mcts_golden("host", name, feature_dtype=_abi.FEAT_BF16_TILED)
+    pc.check_mcts_golden("host", name, feature_dtype=_abi.FEAT_BF16_TILED if fmt == "bf16" else _abi.FEAT_F16_TILED)
 
 
 @pytest.mark.parametrize("name", ["go5_p8_s64", "go9_p8_s200", "gomoku7_p1_s40"])
