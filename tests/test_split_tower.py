@@ -104,7 +104,7 @@ def test_gpu_split_conv_error_vs_fp64(boards, C):
     """k_conv3x3_sp vs fp64, next to the library's fp32 convolution on the same inputs.  Board counts around one / two boards per
     workgroup slot (128 slots at 128 filters, 256 at 64) exercise the first-board, has-next and last-board paths of the persistent loop;
     the two large counts give every workgroup 17 boards + some an 18th: a full 16-board corner group followed by a partial one.
-    Bound: max |y - y64| <= 2e-6 max|y64| and at most 2x the library's own fp32 error + 2e-7 (measured on MI355X over the 48 cases,
+    Bound: max |y - y64| <= 2e-6 max|y64| and at most 2x the library's own fp32 error + 5e-7 (measured on MI355X over the 48 cases,
     profiles/r03_split_conv_error.jsonl: kernel max 6.5e-7 / mean 4.6e-7, library fp32 max 8.8e-7 / mean 5.6e-7)."""
     from alpha_zero_amd import _lib
 
@@ -129,7 +129,7 @@ def test_gpu_split_conv_error_vs_fp64(boards, C):
             f.write(json.dumps(o) + "\n")
     for o in out:
         assert o["layout_roundtrip_rel"] <= 2.0 ** -21, o
-        assert o["err"] <= 2e-6 and o["err"] <= 2 * o["library_fp32_err"] + 2e-7, o
+        assert o["err"] <= 2e-6 and o["err"] <= 2 * o["library_fp32_err"] + 5e-7, o
 
 
 @pytest.mark.gpu
