@@ -115,7 +115,7 @@ class Engine:
     def _stream(self):
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
-            if self.on_launch is not None:  # SelfPlayActor: joins its two half-batch streams before anything runs on another stream
+            if self.on_launch is not None:  # experiment hook (tools/overlap_actor.py joins its two half-batch streams here); never set by the product
                 self.on_launch(cur)
             return C.c_void_p(cur.cuda_stream)
         return None

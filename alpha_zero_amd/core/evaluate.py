@@ -154,7 +154,13 @@ def play_eval_games_parallel(game, board_size, players, num_simulations, num_par
         if openings is not None:
             assert len(openings) == G
             for t in range(max(len(o) for o in openings)):
-                eng.env_step(np.array([o[t] if t < len(o) else -2 for o in openings], dtype=np.int32))
+                acts = np.array([o[t] if t < len(o) else -2 for o in openings], dtype=np.int32)
+                out = eng.env_step(acts)
+                # the env kernel skips an illegal or post-terminal action and flags it (scalars[10]); an opening that was not
+                # played as given would shift the colour / evaluator pairing by one ply and report moves that never happened
+                bad = np.nonzero((acts != -2) & (out["scalars"][:, 10] != 0))[0]
+                if len(bad):
+                    raise ValueError(f"opening move {t} of game {int(bad[0])} (action {int(acts[bad[0]])}) was rejected by the rules")
         # distinct evaluator objects and, per game and colour, which one searches
         evs, who = [], np.zeros((G, 2), dtype=np.int64)
         for g, pair in enumerate(players):

@@ -33,8 +33,10 @@ def unpack_samples(rows, state_shape, A):
     nb = (nel + 7) // 8
     bits = rows[:, :nb]
     planes = ((bits.unsqueeze(-1) & _bit_weights(rows.device)) != 0).to(torch.int8).reshape(n, nb * 8)[:, :nel].reshape((n,) + tuple(state_shape))
-    pi = rows[:, nb:nb + 4 * A].clone().view(torch.float32).reshape(n, A)  # (clone: a fresh, 4-byte aligned storage)
-    z = rows[:, nb + 4 * A:nb + 4 * A + 4].clone().view(torch.float32).reshape(n)
+    # a fresh, DENSE, 4-byte aligned storage: a [1, k] slice of a row whose length is not a multiple of 4 (9x9 Go: 505 B) counts as
+    # dense under preserve_format and would keep the row stride, which the float32 view rejects
+    pi = rows[:, nb:nb + 4 * A].clone(memory_format=torch.contiguous_format).view(torch.float32).reshape(n, A)
+    z = rows[:, nb + 4 * A:nb + 4 * A + 4].clone(memory_format=torch.contiguous_format).view(torch.float32).reshape(n)
     return planes, pi, z
 
 

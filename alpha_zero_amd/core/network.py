@@ -93,9 +93,16 @@ def widen_network(net: "AlphaZeroNet", num_filters: int) -> "AlphaZeroNet":
     return out
 
 
+F16_MAX = 65504.0
+
+
 def split_weights_f16(w):
     """Convolution weights [Cout,Cin,3,3] fp32 -> the packing of the split-precision kernels (include/azsp.h, azsp_conv3x3_split):
-    [plane: hi, lo][tap = ky*3+kx][Cout][Cin] f16 with hi = f16(w) and lo = f16((w - hi) * 2048)."""
+    [plane: hi, lo][tap = ky*3+kx][Cout][Cin] f16 with hi = f16(w) and lo = f16((w - hi) * 2048).  A (BatchNorm-folded) weight that is
+    not finite or lies beyond f16's finite range cannot be carried by the split format: ValueError, never a silent clamp / inf."""
+    if not bool(torch.isfinite(w).all()) or float(w.abs().max()) > F16_MAX:
+        raise ValueError(f"split-precision packing: folded convolution weights must be finite and within +-{F16_MAX} "
+                         f"(max |w| = {float(w.abs().max())}); evaluate this network with use_split_tower = False (library fp32)")
     w9 = w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).float()
     hi = w9.to(torch.float16)
     lo = ((w9 - hi.float()) * 2048.0).to(torch.float16)
@@ -200,48 +207,62 @@ class InferenceNet(nn.Module):
                 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17), (64, 9), (256, 19))
                 and x.is_contiguous(memory_format=torch.channels_last))
 
+    SPLIT_TOWER_SHAPES = ((128, 9), (64, 9), (64, 17))          # (filters, tower planes) with an azsp_conv3x3_split kernel
+    SPLIT_EVAL_SHAPES = ((128, 9, 1), (64, 9, 1), (64, 13, 3))  # (filters, board, stem pad) whose whole evaluator runs on the split kernels
+
     def _split_tower_ok(self, x):
-        """fp32 networks on 9x9 planes with 128 or 64 filters: the tower runs on azsp_conv3x3_split (include/azsp.h) -- the reference's
-        precision class (pipeline.py:91-123 evaluates in fp32) at the f16 MFMA rate."""
+        """fp32 networks on 9x9 planes with 128 or 64 filters and on 17x17 planes with 64 filters (the 13x13 Gomoku tower): the tower
+        runs on azsp_conv3x3_split (include/azsp.h) -- the reference's precision class (pipeline.py:91-123 evaluates in fp32) at the f16
+        MFMA rate."""
         return (self.binding is not None and self.use_fused_conv and self.use_split_tower and x.is_cuda and x.dtype == torch.float32
-                and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 9))
+                and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in self.SPLIT_TOWER_SHAPES
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     def supports_split_features(self, board_size, device):
         """True when the WHOLE fp32 evaluator runs on the split-precision kernels (azsp_split_features -> azsp_stem_split ->
-        azsp_conv3x3_split tower -> azsp_head_split): fp32 networks, 9x9 Go with 128 or 64 filters (pad-1 stem)."""
+        azsp_conv3x3_split tower -> azsp_head_split): fp32 networks, 9x9 Go with 128 or 64 filters (pad-1 stem), 13x13 Gomoku with 64
+        filters (pad-3 stem, 17x17 planes)."""
         return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.use_fused_conv
                 and self.use_split_tower and self.use_split_heads and self.stem_ok and self.npol + self.nval == 3
-                and (self.filters, board_size, self.stem_pad) in ((128, 9, 1), (64, 9, 1)))
+                and (self.filters, board_size, self.stem_pad) in self.SPLIT_EVAL_SHAPES)
+
+    def _split_buffers(self, B, S, C, device, slot=0):
+        """Scratch of the split-precision evaluator per `slot` (the scheme of _tiled_buffers): three rotating tower buffers, the stem's
+        feature buffer and the output rows.  A slot holds one batch size at a time; slot 0 is the engine-facing forward (the one
+        SelfPlayActor captures in a hipGraph -- its buffers must never be freed by another caller of the same InferenceNet), slot 3
+        every other call (evaluation games, drop-in eval_func wrappers, tests)."""
+        dll = self.binding.dll
+        nb, nf = dll.azsp_split_bytes(B, S, C) // 2, dll.azsp_split_bytes(B, S, 32) // 2
+        cache = self.__dict__.setdefault("_split_cache", {})
+        key = (slot, B, S, str(device))
+        if key not in cache:
+            for k in [k for k in cache if k[0] == slot]:
+                del cache[k]
+            cache[key] = ([torch.zeros(nb, dtype=torch.float16, device=device) for _ in range(3)],
+                          torch.zeros(nf, dtype=torch.float16, device=device),
+                          torch.empty((B, self.num_actions), dtype=torch.float32, device=device),
+                          torch.empty((B,), dtype=torch.float32, device=device))
+        return cache[key]
 
     @torch.no_grad()
-    def forward_split(self, planes, priors_out=None, values_out=None):
+    def forward_split(self, planes, priors_out=None, values_out=None, slot=None):
         """planes: observation planes [B,17,N,N] fp32, contiguous NCHW (the engine's AZSP_FEAT_F32 features).  The whole evaluator at
-        the reference's precision class (pipeline.py:91-123 evaluates in fp32) on hand-written kernels."""
+        the reference's precision class (pipeline.py:91-123 evaluates in fp32) on hand-written kernels.  slot: scratch buffers to use
+        (see _split_buffers); None = 0 when the outputs go to caller tensors (the engine's forward), 3 otherwise."""
         import ctypes
 
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(planes.device).cuda_stream) if planes.is_cuda else None  # (host twin: CPU tensors)
         B, cin, n, _ = planes.shape
-        C, S = self.filters, n
-        nb, nf = dll.azsp_split_bytes(B, S, C) // 2, dll.azsp_split_bytes(B, S, 32) // 2
-        cache = self.__dict__.setdefault("_split_cache", {})
-        key = (nb, str(planes.device))
-        if key not in cache:
-            cache.clear()
-            cache[key] = [torch.zeros(nb, dtype=torch.float16, device=planes.device) for _ in range(3)]
-        fkey = ("feat", nf, B, str(planes.device))
-        if fkey not in cache:
-            for k in [k for k in cache if k[0] == "feat"]:
-                del cache[k]
-            cache[fkey] = (torch.zeros(nf, dtype=torch.float16, device=planes.device),
-                           torch.empty((B, self.num_actions), dtype=torch.float32, device=planes.device),
-                           torch.empty((B,), dtype=torch.float32, device=planes.device))
-        a, m, o = cache[key]
-        feat, pri_buf, v_buf = cache[fkey]
-        self._split = (a, m, o, B)
+        C = self.filters
+        S = n + 2 * (self.stem_pad - 1)  # planes of the tower (network.py:101-105: the Gomoku stem pads by 3)
+        if slot is None:
+            slot = 0 if priors_out is not None else 3
+        (a, m, o), feat, pri_buf, v_buf = self._split_buffers(B, S, C, planes.device, slot)
+        self._split = (a, m, o, B)  # marks that the split kernels ran (tests); bench.py replays the tower on slot 0's buffers
         ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, st), "azsp_split_features")
-        ck(dll.azsp_stem_split(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_stem_split")
+        ck(dll.azsp_stem_split(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, n, C, self.stem_pad, 1, st),
+           "azsp_stem_split")
         a = self._blocks_split(a, m, o, B, S, C, st)
         pri = priors_out if priors_out is not None else pri_buf
         v = values_out if values_out is not None else v_buf
@@ -249,6 +270,16 @@ class InferenceNet(nn.Module):
                                self.val_fc1_wt.data_ptr(), self.val_fc1_b32.data_ptr(), self.val_fc2_w32.data_ptr(), ctypes.c_float(self.fc_b2),
                                pri.data_ptr(), v.data_ptr(), B, S, C, self.num_actions, self.fc_width, self.npol, st), "azsp_head_split")
         return (pri, v) if priors_out is not None else (pri.clone(), v.clone())  # the cached output buffers are reused by the next call
+
+    def split_range_status(self, reset=False, stream=None):
+        """(events, max_abs) of the split-precision evaluator's sticky range record (include/azsp.h azsp_split_range_status): how many
+        kernel lanes met a value beyond f16's finite range (clamped to +-65504 where the reference's fp32 network would carry it) since
+        the last reset, and the largest such |v|.  Synchronises the stream."""
+        import ctypes
+
+        ev, mx = ctypes.c_uint32(0), ctypes.c_float(0.0)
+        self._ck(self.binding.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), int(bool(reset)), stream), "azsp_split_range_status")
+        return int(ev.value), float(mx.value)
 
     def _blocks_split(self, a, m, o, B, S, C, st):
         """All residual blocks on split-layout buffers; returns the buffer holding the tower output."""
@@ -284,8 +315,9 @@ class InferenceNet(nn.Module):
         return F.relu_(y)
 
     def _tiled_buffers(self, B, S, C, device, slot=0):
-        """Three rotating tower buffers (block input, middle, block output) per `slot`: forwards that may be in flight at the same time
-        (SelfPlayActor's two half-batches on two streams) use different slots and never share scratch memory."""
+        """Three rotating tower buffers (block input, middle, block output) per `slot`: callers whose forwards must not share scratch
+        memory use different slots (slot 0: the actor's graph-captured forward; slot 3: forward_planes, i.e. evaluation games / drop-in
+        eval_func calls on the same InferenceNet; slots 1-2: the half-batch experiment of tools/overlap_actor.py)."""
         n = self.binding.dll.azsp_tiled_bytes(B, S, C) // 2
         cache = self.__dict__.setdefault("_tiled_cache", {})
         key = (slot, n, str(device))
@@ -343,7 +375,7 @@ class InferenceNet(nn.Module):
             return ("fp32 class, hand-written: split-precision stem / tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, "
                     "fp32 accumulation) / fp32 heads (libazsp)")
         if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower:
-            if (self.filters, board_size + 2 * (self.stem_pad - 1)) in ((128, 9), (64, 9)):
+            if (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_TOWER_SHAPES:
                 return ("fp32 class: hand-written split-precision tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 "
                         "accumulation) behind a library fp32 stem and heads")
         return f"library convolutions + azsp_bias_act epilogue (no hand-written kernel for {self.filters} filters on {board_size}x{board_size}, {self.dtype})"
@@ -434,7 +466,7 @@ class InferenceNet(nn.Module):
         ck(dll.azsp_tile_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_tile_layout")
         return x
 
-    def _tower_split(self, x):
+    def _tower_split(self, x, slot=3):
         """The whole residual tower of an fp32 network on the split layout (azsp_split_layout / azsp_conv3x3_split): activations are
         converted once on entry and once on exit; x is channels-last fp32 [B,C,S,S] and is overwritten with the tower's output."""
         import ctypes
@@ -442,14 +474,8 @@ class InferenceNet(nn.Module):
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         B, C, S = x.shape[0], x.shape[1], x.shape[2]
-        n = dll.azsp_split_bytes(B, S, C) // 2
-        cache = self.__dict__.setdefault("_split_cache", {})
-        key = (n, str(x.device))
-        if key not in cache:
-            cache.clear()
-            cache[key] = [torch.zeros(n, dtype=torch.float16, device=x.device) for _ in range(3)]
-        a, m, o = cache[key]
-        self._split = (a, m, o, B)  # (bench.py replays the tower on the activations of the last forward)
+        (a, m, o), _, _, _ = self._split_buffers(B, S, C, x.device, slot)
+        self._split = (a, m, o, B)
         ck(dll.azsp_split_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_split_layout")
         a = self._blocks_split(a, m, o, B, S, C, st)
         ck(dll.azsp_split_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_split_layout")
@@ -465,7 +491,7 @@ class InferenceNet(nn.Module):
         if self._tiled_tower_ok(x):
             x = self._tower_tiled(x)
         elif self._split_tower_ok(x):
-            x = self._tower_split(x)
+            x = self._tower_split(x, slot=0 if priors_out is not None else 3)
         else:
             for i in range(self.n_blocks):
                 y = self._conv(x, 2 * i)

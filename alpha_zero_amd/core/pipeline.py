@@ -59,10 +59,14 @@ class SelfPlayActor:
 
     def __init__(self, network: AlphaZeroNet, *, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8,
                  c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
-                 resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.bfloat16,
+                 resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.float32,
                  use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None):
-        """tiled_features: None = use the evaluator's tiled input layout whenever the network / board shape has the hand-written
-        stem / tower / head kernels (9x9, 128 filters, bf16 on the GPU); False = always NCHW planes + library stem."""
+        """net_dtype: precision class of the leaf evaluator.  The default is the REFERENCE'S: fp32 (pipeline.py:91-123 evaluates in fp32,
+        no autocast anywhere) -- on the hand-written split-precision kernels (hi + lo f16 pairs, three MFMA products, fp32 accumulation:
+        include/azsp.h azsp_conv3x3_split) for 9x9 x {128, 64} and 13x13 Gomoku x 64 networks, on library fp32 convolutions (announced
+        by a RuntimeWarning) for any other shape.  torch.bfloat16 / torch.float16 are the opt-in lower-precision evaluators.
+        tiled_features: None = use the evaluator's tiled input layout whenever the network / board shape has the hand-written bf16 / f16
+        stem / tower / head kernels; False = always NCHW planes + library stem."""
         from .. import _lib
 
         self.binding = binding or _lib.load(require_gpu=True)
@@ -74,7 +78,7 @@ class SelfPlayActor:
         self.tiled_features = probe.supports_tiled_features(board_size, self.device) if tiled_features is None else bool(tiled_features)
         self.evaluator_path = probe.evaluator_path(board_size, self.device) if self.tiled_features or tiled_features is None else \
             "library stem (tiled features disabled by the caller)"
-        if self.device.type == "cuda" and not self.tiled_features and net_dtype == torch.bfloat16:
+        if self.device.type == "cuda" and "hand-written" not in self.evaluator_path:
             import warnings
 
             warnings.warn(f"alpha_zero_amd: evaluator falls back to {self.evaluator_path}", RuntimeWarning, stacklevel=2)
@@ -95,6 +99,7 @@ class SelfPlayActor:
         self._graph = None
         self.rounds = 0
         self.straddled_games = 0  # harvested games that were in progress across a weight hot-swap (see harvest())
+        self.range_events, self.range_max_abs = 0, 0.0  # fp32-class evaluator: clamped out-of-range activations seen so far (_check_evaluator_range)
         self.drop_straddling_games = False
         self.set_network(network, training_steps)
 
@@ -165,7 +170,24 @@ class SelfPlayActor:
         next harvest overwrites them in place.  clone=True returns private copies (for consumers that keep them across harvests,
         e.g. an asynchronous learner or a replay insert on another stream)."""
         st, pi, z, games = self.engine.harvest()
+        self._check_evaluator_range()
         return (st.clone(), pi.clone(), z.clone(), games) if clone else (st, pi, z, games)
+
+    def _check_evaluator_range(self):
+        """fp32-class evaluator: its kernels carry values as f16 pairs and clamp what exceeds +-65504 -- the reference's fp32 network
+        would carry such a value on.  The kernels record every such event (azsp_split_range_status); it is polled here, once per
+        harvest (the harvest has synchronised the stream already), counted in `range_events` and announced: never silent."""
+        if self.device.type != "cuda" or self.net_dtype != torch.float32 or "split-precision" not in self.evaluator_path:
+            return
+        ev, mx = self.infer.split_range_status(reset=True)
+        if ev:
+            import warnings
+
+            self.range_events += ev
+            self.range_max_abs = max(self.range_max_abs, mx)
+            warnings.warn(f"alpha_zero_amd: the fp32-class evaluator clamped {ev} activation lanes beyond f16's range (largest |v| = {mx:.6g}); "
+                          "the reference's fp32 network would have carried them -- evaluate this network with use_split_tower = False",
+                          RuntimeWarning, stacklevel=3)
 
     def harvest(self, with_moves=False):
         """Finished games as the reference actor emits them: [(game_seq: list[Transition], stats: dict)]
@@ -173,6 +195,7 @@ class SelfPlayActor:
         with_moves=True yields (game_seq, stats, moves): the game's move list as env.history holds it (flat actions, N*N = pass;
         a final resignation is not a history move, base.py:224-226) -- what to_sgf() needs (pipeline.py:276-281)."""
         got = self.engine.harvest(with_moves=with_moves)
+        self._check_evaluator_range()
         states, pi, z, games = got[:4]
         extra = self.engine.last_extra
         if len(games) == 0:
@@ -212,19 +235,44 @@ class SelfPlayActor:
         return self.engine.counters(reset)
 
 
+def load_checkpoint_state(path, allow_pickle=None):
+    """Checkpoint dictionary of the learner (pipeline.py:597-606: 'network', 'training_steps', optimizer / scheduler state) from `path`.
+    Loaded with weights_only=True: tensors, numbers, strings, containers -- no pickled code runs.  Only when the safe loader REJECTS the
+    file's content (pickle.UnpicklingError: an object type outside its allow-list, e.g. a pickled scheduler object) and the caller opted
+    in (allow_pickle=True, or the environment variable AZSP_ALLOW_PICKLE_CKPT=1) is the file re-read with the full unpickler, and that
+    is logged.  I/O errors and corrupt files propagate; they are never retried with the unsafe loader."""
+    import logging
+    import os
+    import pickle
+
+    import collections
+
+    try:  # MultiStepLR.state_dict() (training_go.py:273) holds its milestones as a collections.Counter: plain data, allow-listed
+        with torch.serialization.safe_globals([collections.Counter, collections.OrderedDict]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if allow_pickle is None:
+            allow_pickle = os.environ.get("AZSP_ALLOW_PICKLE_CKPT", "0") == "1"
+        if not allow_pickle:
+            raise
+        logging.getLogger("alpha_zero_amd").warning("checkpoint %s needs the full unpickler (%s): loading with weights_only=False", path, e)
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_simulations, num_parallel, c_puct_base, c_puct_init,
                             warm_up_steps, check_resign_after_steps, disable_resign_ratio, save_sgf_dir=None, save_sgf_interval=0,
                             logs_dir=None, load_ckpt=None, log_level="INFO", var_ckpt=None, var_resign_threshold=None,
-                            ckpt_event=None, stop_event=None, num_games=4096, net_dtype=torch.bfloat16, harvest_every=64, binding=None):
+                            ckpt_event=None, stop_event=None, num_games=4096, net_dtype=torch.float32, harvest_every=64, binding=None):
     """Same role and argument list as the reference actor entry point (pipeline.py:166-189), extended by
     `num_games`: one call drives `num_games` games on `device` and puts (game_seq, stats) tuples on
-    `data_queue` exactly as `num_games` reference actors would."""
+    `data_queue` exactly as `num_games` reference actors would.  `net_dtype` defaults to the reference's evaluator precision (fp32,
+    see SelfPlayActor)."""
     import os
 
     game = "go" if env.has_pass_move else "gomoku"
     training_steps = 0
     if load_ckpt is not None and os.path.exists(load_ckpt):  # pipeline.py:208-212
-        st = torch.load(load_ckpt, map_location="cpu", weights_only=False)
+        st = load_checkpoint_state(load_ckpt)
         network.load_state_dict(st["network"])
         training_steps = st["training_steps"]
     thr = var_resign_threshold.value if (var_resign_threshold is not None and env.has_resign_move) else -1.0
@@ -249,10 +297,7 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
         if var_ckpt is not None:
             new_ckpt = var_ckpt.value.decode("utf-8") if isinstance(var_ckpt.value, bytes) else str(var_ckpt.value)
             if new_ckpt != "" and new_ckpt != last_ckpt and os.path.exists(new_ckpt):  # pipeline.py:232-239
-                try:  # a checkpoint that holds only tensors and numbers loads without executing pickled code
-                    st = torch.load(new_ckpt, map_location="cpu", weights_only=True)
-                except Exception:  # the reference's full checkpoints also carry optimizer / scheduler objects (pipeline.py:597-606)
-                    st = torch.load(new_ckpt, map_location="cpu", weights_only=False)
+                st = load_checkpoint_state(new_ckpt)
                 network.load_state_dict(st["network"])
                 actor.set_network(network, st["training_steps"])
                 last_ckpt = new_ckpt

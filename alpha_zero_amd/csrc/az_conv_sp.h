@@ -106,6 +106,17 @@ __device__ __forceinline__ void sp_split(float v, _Float16& h, _Float16& l) {
     l = (_Float16)((v - (float)h) * SP_SCALE);     // the difference is exact in fp32
 }
 __device__ __forceinline__ float sp_join(_Float16 h, _Float16 l) { return fmaf((float)l, SP_INV_SCALE, (float)h); }
+// Sticky range record of the split-precision evaluator (read and reset by azsp_split_range_status): [0] = number of lanes that met a
+// value beyond f16's finite range while splitting it (the value was clamped to +-65504 where the reference's fp32 network would carry
+// it on), [1] = the bits of the largest such |v| (positive floats order like unsigned integers).  Every kernel that splits values
+// keeps the largest |v| it produced in a register (one v_max_f32 per element) and reports once, at its end, if that exceeded the range.
+__device__ unsigned g_sp_range[2];
+__device__ __forceinline__ void sp_range_report(float mx) {
+    if (mx > SP_F16_MAX) {  // (rare: one atomic pair per lane that saw an overflow; NaN compares false and is not a range event)
+        atomicAdd(&g_sp_range[0], 1u);
+        atomicMax(&g_sp_range[1], __float_as_uint(mx));
+    }
+}
 __device__ __forceinline__ unsigned sp_pack(_Float16 a, _Float16 b) { return __builtin_bit_cast(unsigned, (sp_f16x2){a, b}); }
 __device__ __forceinline__ _Float16 sp_lo16(unsigned v) { return __builtin_bit_cast(sp_f16x2, v)[0]; }
 __device__ __forceinline__ _Float16 sp_hi16(unsigned v) { return __builtin_bit_cast(sp_f16x2, v)[1]; }
@@ -125,8 +136,13 @@ k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict_
         const float f[8] = {__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z), __uint_as_float(a0.w),
                             __uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z), __uint_as_float(a1.w)};
         _Float16 h[8], l[8];
+        float mx = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sp_split(f[e], h[e], l[e]);
+        for (int e = 0; e < 8; ++e) {
+            mx = fmaxf(mx, fabsf(f[e]));
+            sp_split(f[e], h[e], l[e]);
+        }
+        sp_range_report(mx);
         *(cv_u32x4*)(dst + so) = (cv_u32x4){sp_pack(h[0], h[1]), sp_pack(h[2], h[3]), sp_pack(h[4], h[5]), sp_pack(h[6], h[7])};
         *(cv_u32x4*)(dst + so + plane) = (cv_u32x4){sp_pack(l[0], l[1]), sp_pack(l[2], l[3]), sp_pack(l[4], l[5]), sp_pack(l[6], l[7])};
     } else {
@@ -152,11 +168,15 @@ k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst,
     const long long b = i / (4 * p2);
     const int r = (int)(i - b * 4 * p2), c = r / p2, p = r - c * p2;
     _Float16 h[8], l[8];
+    float mx = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = 8 * c + e;
-        sp_split(ch < cin ? src[((size_t)b * cin + ch) * p2 + p] : 0.0f, h[e], l[e]);
+        const float v = ch < cin ? src[((size_t)b * cin + ch) * p2 + p] : 0.0f;
+        mx = fmaxf(mx, fabsf(v));
+        sp_split(v, h[e], l[e]);
     }
+    sp_range_report(mx);
     const size_t plane = (size_t)4 * p2 * 16, so = (size_t)b * 2 * plane + ((size_t)c * p2 + p) * 16;
     *(cv_u32x4*)(dst + so) = (cv_u32x4){sp_pack(h[0], h[1]), sp_pack(h[2], h[3]), sp_pack(h[4], h[5]), sp_pack(h[6], h[7])};
     *(cv_u32x4*)(dst + so + plane) = (cv_u32x4){sp_pack(l[0], l[1]), sp_pack(l[2], l[3]), sp_pack(l[4], l[5]), sp_pack(l[6], l[7])};
@@ -271,7 +291,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     constexpr int NP = (G::CELLS + 63) / 64;
     constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;
     constexpr int NF = 2 * KS, NF_A = NF < 64 ? NF : 64;
-    constexpr int E_OPS = RES ? 12 : 8, CT_OPS = 4 * E_OPS + 6;  // epilogue micro-ops per element / per column tile
+    constexpr int E_OPS = RES ? 13 : 9, CT_OPS = 4 * E_OPS + 6;  // epilogue micro-ops per element / per column tile
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert((2 * KS) % R == 0, "a board's k-steps keep the ring phase");
     static_assert(KS - 1 >= NPIECE, "the next board's pieces ride in unit 0");
@@ -314,7 +334,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     c6_f32x4 bv;  // bias in the D layout (rows = couts 4 kg + e of the wave's 16): the C operand of the first k-step
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = bias[cg * 64 + wave * 16 + 4 * kg + e];
-    const float lo_bound = relu ? 0.0f : -SP_F16_MAX;
+    const float lo_relu = relu ? 0.0f : -__builtin_inff();
 
     // LDS-DMA plan: a strip is NP pieces of 64 cells; wave q moves strips SPW q .. SPW q + SPW - 1 (strip = plane * NCH + chunk)
     unsigned dsrc[NP];
@@ -382,7 +402,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             accm[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accc[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             rr[a][j][0] = (cv_u32x2){0u, 0u}, rr[a][j][1] = (cv_u32x2){0u, 0u};
         }
-    float ev = 0.0f, t0 = 0.0f, t1 = 0.0f;
+    float ev = 0.0f, t0 = 0.0f, t1 = 0.0f, mx = 0.0f;  // mx: the largest |value| this lane produced (range record, sp_range_report)
     _Float16 hh[4], ll[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) hh[e] = (_Float16)0.0f, ll[e] = (_Float16)0.0f;
@@ -398,13 +418,14 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             else if (RES && k == 2) t1 = (float)((e & 1) ? sp_hi16(rl) : sp_lo16(rl));
             else if (RES && k == 3) t0 = fmaf(t1, SP_INV_SCALE, t0);
             else if (RES && k == 4) ev = cw_add_f32(ev, t0);
-            else if (tail == 1) ev = fmaxf(ev, lo_bound);
-            else if (tail == 2) ev = fminf(ev, SP_F16_MAX);
-            else if (tail == 3) hh[e] = (_Float16)ev;
-            else if (tail == 4) t0 = (float)hh[e];
-            else if (tail == 5) t1 = ev - t0;
-            else if (tail == 6) t1 = t1 * SP_SCALE;
-            else if (tail == 7) ll[e] = (_Float16)t1;
+            else if (tail == 1) ev = fmaxf(ev, lo_relu);
+            else if (tail == 2) mx = fmaxf(mx, __builtin_fabsf(ev));                          // what the reference would carry on ...
+            else if (tail == 3) ev = __builtin_amdgcn_fmed3f(ev, -SP_F16_MAX, SP_F16_MAX);  // ... is clamped here (and recorded)
+            else if (tail == 4) hh[e] = (_Float16)ev;
+            else if (tail == 5) t0 = (float)hh[e];
+            else if (tail == 6) t1 = ev - t0;
+            else if (tail == 7) t1 = t1 * SP_SCALE;
+            else if (tail == 8) ll[e] = (_Float16)t1;
         } else {
             const int k = o - 4 * E_OPS;
             const unsigned gq = lmap[mj] >> 16;
@@ -539,7 +560,11 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             }
             _Float16 h[4], l[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sp_split(fmaxf(v[e], lo_bound), h[e], l[e]);
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaxf(v[e], lo_relu);
+                if (l15 < n_ok) mx = fmaxf(mx, fabsf(v[e]));
+                sp_split(v[e], h[e], l[e]);
+            }
             if (l15 < n_ok) {
                 *(cv_u32x2*)(y + co) = (cv_u32x2){sp_pack(h[0], h[1]), sp_pack(h[2], h[3])};
                 *(cv_u32x2*)(y + co + YPLANE) = (cv_u32x2){sp_pack(l[0], l[1]), sp_pack(l[2], l[3])};
@@ -553,6 +578,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     for (int j = 0; j < NJ1; ++j)
 #pragma unroll
         for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, NJ0 + j, yprev, o, true);
+    sp_range_report(mx);
 }
 
 #endif  // __HIPCC__

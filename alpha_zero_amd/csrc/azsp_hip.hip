@@ -9,6 +9,7 @@
 #include "az_conv64.h"
 #include "az_conv19.h"
 #include "az_conv_sp.h"
+#include "az_conv_sp17.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -293,8 +294,19 @@ static int launch_sp(const void* x, const void* w, const float* bias, const void
                        (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
     return AZ_HIP(hipGetLastError());
 }
+template <bool RES, int NCH>
+static int launch_sp17(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles
+    hipLaunchKernelGGL((k_conv3x3_sp17<RES, NCH>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+    return AZ_HIP(hipGetLastError());
+}
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void* st) {
+    if (S == Sp17Geo::S && C == 64)  // 17x17 planes x 64 filters: the 13x13 Gomoku tower (half-board tiles)
+        return res ? launch_sp17<true, 8>(x, w, bias, res, y, boards, relu, st) : launch_sp17<false, 8>(x, w, bias, res, y, boards, relu, st);
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
     if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st);
     return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st);
@@ -306,9 +318,18 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
                        S * S);
     return AZ_HIP(hipGetLastError());
 }
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* st) {
-    if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st) {
+    if (S == 13 && C == 64 && pad == 3) return launch_sp17<false, 4>(x, w, bias, nullptr, y, boards, relu, st);  // 13x13 boards -> 17x17 planes
+    if (S != SpGeo9::S || (C != 128 && C != 64) || pad != 1) return 1;
     return C == 128 ? launch_sp<false, 4, 2>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp<false, 4, 1>(x, w, bias, nullptr, y, boards, relu, st);
+}
+int split_range_status(unsigned out[2], int reset, void* st) {
+    if (AZ_HIP(hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(g_sp_range), 2 * sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)st))) return -1;
+    if (reset) {
+        static const unsigned zero[2] = {0u, 0u};
+        if (AZ_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sp_range), zero, 2 * sizeof(unsigned), 0, hipMemcpyHostToDevice, (hipStream_t)st))) return -1;
+    }
+    return AZ_HIP(hipStreamSynchronize((hipStream_t)st));
 }
 int launch_head_split(const HeadSplitArgs& a, void* st) {
     const int P2 = a.S * a.S;

@@ -559,7 +559,8 @@ struct HeadSplitArgs {
     int S, C, A, F, npol;
 };
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* stream);
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void* stream);
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
+int split_range_status(unsigned out[2], int reset, void* stream);  // synchronises the stream
 int launch_head_split(const HeadSplitArgs& a, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
                       int f16 = 0);
@@ -1069,11 +1070,20 @@ int azsp_split_features(const float* planes, void* dst, int64_t boards, int32_t 
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
-int azsp_stem_split(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t relu, void* stream) {
+int azsp_stem_split(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
+                    void* stream) {
     if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, relu, stream);
+    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_split_range_status(uint32_t* events, float* max_abs, int32_t reset, void* stream) {
+    unsigned r[2] = {0u, 0u};
+    if (azb::split_range_status(r, reset, stream) != 0) return AZSP_EDEVICE;
+    if (events) *events = r[0];
+    if (max_abs) memcpy(max_abs, &r[1], sizeof(float));
+    return AZSP_OK;
 }
 
 int azsp_head_split(const void* x, const float* head_w, const float* head_b, const float* pol_fc_wt, const float* pol_fc_b, const float* val_fc1_wt,

@@ -166,9 +166,11 @@ int azsp_begin_move(void* engine, const double* noise_host, int32_t warm_up, voi
 int azsp_select(void* engine, void* features_dev, uint8_t* valid_dev, void* stream);
 int azsp_expand_backup(void* engine, const float* priors_dev, const float* values_dev, void* stream);
 /* The same two phases for the games [g0, g1) only (g0 % 32 == 0; the tensors are the full-batch ones, indexed by game as above).
- * Games never interact during a search (mcts_v2.py:568-625 runs per game), so disjoint ranges may run on different streams in any
- * order with bit-identical results: SelfPlayActor runs two half-batches on two streams so that the select / backup kernels of one
- * half execute while the other half's leaf batch is inside the evaluator. */
+ * Games never interact during a search (mcts_v2.py:568-625 runs per game), so disjoint ranges in any order are the whole batch,
+ * bit for bit (tested).  EXPERIMENTAL: no product path calls these two entries -- SelfPlayActor runs whole-batch rounds on ONE
+ * stream.  They exist for the half-batch overlap experiment (tools/overlap_actor.py; DESIGN "Two streams": measured +0.3 %, not
+ * adopted).  The ENGINE kernels of disjoint ranges are exact on two streams; two evaluator FORWARDS in flight at the same time
+ * are a separate matter, see DESIGN before putting two forwards on one device. */
 int azsp_select_range(void* engine, void* features_dev, uint8_t* valid_dev, int32_t g0, int32_t g1, void* stream);
 int azsp_expand_backup_range(void* engine, const float* priors_dev, const float* values_dev, int32_t g0, int32_t g1, void* stream);
 int azsp_round(void* engine, const float* priors_dev, const float* values_dev, void* features_dev, uint8_t* valid_dev,
@@ -266,12 +268,16 @@ int azsp_resblock_tiled(const void* x_dev, const void* w1_packed_dev, const floa
  * gfx950 multiplies fp32 matrices at 1/16 of its f16 rate and has no TF32, so here an fp32 value v travels as two f16 numbers,
  * hi = f16(v) and lo = f16((v - hi) * 2048), and a product is three f16 MFMAs (w_hi x_hi; w_hi x_lo + w_lo x_hi scaled by 1/2048)
  * accumulated in fp32: 22-bit significands, per-product error <= 3 * 2^-22, i.e. fp32 round-off class (bounded against fp64 next to
- * the library's fp32 convolution in tests/test_network.py).  Values are clamped to +-65504 when split.
+ * the library's fp32 convolution in tests/test_split_tower.py).  RANGE: a value beyond f16's finite range (|v| > 65504) cannot be
+ * split; it is clamped to +-65504 where the reference's fp32 network would carry it on.  That never happens silently: every kernel
+ * that splits values records such an event in a sticky device-side record, see azsp_split_range_status below (BatchNorm-folded
+ * AlphaZero towers stay far inside the range: activations of the shipped networks peak at ~1e2).
  * "Split layout": [board][plane: hi, lo][C/8 channel chunks][S*S positions][8 ch] f16 = azsp_split_bytes(boards, S, C) bytes;
  * azsp_split_layout converts fp32 channels-last rows [boards][S][S][C] to (to_split = 1) / from (0) it.
  * azsp_conv3x3_split: y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y in the split layout (x must not alias y; residual
  * may), w_split [2 planes: hi, lo][9 taps (ky*3+kx)][C out][C in] f16 with lo = (w - hi) * 2048, bias float[C].  On the device:
- * (S, C) = (9, 128) and (9, 64); AZSP_EINVAL for other shapes. */
+ * (S, C) = (9, 128), (9, 64) and (17, 64) (the 13x13 Gomoku tower behind its pad-3 stem, network.py:101-105; half-board tiles,
+ * az_conv_sp17.h); AZSP_EINVAL for other shapes. */
 int64_t azsp_split_bytes(int64_t boards, int32_t board_size, int32_t channels);
 int azsp_split_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t to_split,
                       void* stream);
@@ -281,20 +287,27 @@ int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* 
 /* The rest of the fp32-class evaluator on the split layout (core/network.py:101-156):
  * azsp_split_features: observation planes [boards][in_channels <= 32][S][S] fp32 (the engine's AZSP_FEAT_F32 features) -> split
  *   layout with 32 channels (the missing ones zero), azsp_split_bytes(boards, S, 32) bytes.
- * azsp_stem_split: the stem convolution + BatchNorm + ReLU (network.py:101-110, padding 1): x from azsp_split_features, w_split
- *   [2 planes][9 taps][C out][32 in] f16 (input channels >= the network's zero), y in the tower's split layout.  (S, C) as
- *   azsp_conv3x3_split.
+ * azsp_stem_split: the stem convolution + BatchNorm + ReLU (network.py:101-110): x from azsp_split_features (board_size x
+ *   board_size), w_split [2 planes][9 taps][C out][32 in] f16 (input channels >= the network's zero), y in the tower's split layout
+ *   with planes of board_size + 2 (pad - 1): pad = 1 for Go, pad = 3 for Gomoku (network.py:101-105).  On the device: (board 9,
+ *   C 128 or 64, pad 1) and (board 13, C 64, pad 3).
  * azsp_head_split: both heads in fp32 in one pass over the tower output (network.py:118-156): the two 1x1 convolutions + BatchNorm +
  *   ReLU (head_w [3][C], head_b [3]: npol policy planes first), policy Linear + softmax over all A actions (pol_fc_wt = the Linear's
  *   weight TRANSPOSED, [npol*S*S][A], inputs in nn.Flatten order), value Linear + ReLU + Linear + tanh (val_fc1_wt transposed
  *   [(3-npol)*S*S][F], val_fc2_w [F], val_fc2_b); priors float [boards][A], values float [boards].  Any (S, C) with C % 8 == 0. */
 int azsp_split_features(const float* planes_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t in_channels, void* stream);
 int azsp_stem_split(const void* x_split32_dev, const void* w_split_dev, const float* bias_dev, void* y_dev, int64_t boards, int32_t board_size,
-                    int32_t channels, int32_t relu, void* stream);
+                    int32_t channels, int32_t pad, int32_t relu, void* stream);
 int azsp_head_split(const void* x_dev, const float* head_w_dev, const float* head_b_dev, const float* pol_fc_wt_dev, const float* pol_fc_b_dev,
                     const float* val_fc1_wt_dev, const float* val_fc1_b_dev, const float* val_fc2_w_dev, float val_fc2_b, float* priors_dev,
                     float* values_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t num_actions, int32_t fc_units, int32_t npol,
                     void* stream);
+
+/* Range record of the split-precision evaluator (process-wide, sticky): *events_host = how many kernel lanes have met a value with
+ * |v| > 65504 since the last reset (each such value was clamped; the reference would have carried it: core/pipeline.py:91-123
+ * evaluates in fp32), *max_abs_host = the largest such |v| (0 if none).  Either pointer may be NULL; reset != 0 clears the record.
+ * Synchronises `stream`.  alpha_zero_amd.core.pipeline.SelfPlayActor polls it at every harvest and raises a RuntimeWarning. */
+int azsp_split_range_status(uint32_t* events_host, float* max_abs_host, int32_t reset, void* stream);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch
  * tensors and apply_random_transformation): out_states[b] = T_op(ring_states[idx[b]]) cast to state_dtype (AZSP_FEAT_I8 / F32 /

@@ -98,6 +98,15 @@ def check_device_route_arena(kind, golden_dir):
                                       binding=binding, device=dev, openings=op)
         assert r2[0]["moves"][:2] == [12, 6] and r2[1]["moves"][:2] == [12, 6] and r2[0]["game_length"] == len(r2[0]["moves"])
 
+        # an opening move the rules reject (the occupied point 12) raises instead of silently shifting the evaluator pairing by a ply
+        try:
+            play_eval_games_parallel("go", 5, [(strong_d, weak_d), (weak_d, strong_d)], cfg["sims"], cfg["P"], 19652, 1.25, komi=cfg["komi"],
+                                     binding=binding, device=dev, openings=[[12, 6], [12, 12]])
+        except ValueError as e:
+            assert "opening move 1 of game 1" in str(e)
+        else:
+            raise AssertionError("an illegal opening move was accepted")
+
     class Boom:
         def __call__(self, *a, **k):
             raise KeyError("evaluator failed")

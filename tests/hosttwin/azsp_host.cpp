@@ -88,7 +88,15 @@ int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const 
     return 0;
 }
 // ---- split-precision tower (azsp_split_layout / azsp_conv3x3_split): plain loops on the same hi / lo f16 arithmetic ----
+static unsigned g_sp_range_host[2] = {0u, 0u};  // the device library's sticky range record (azsp_split_range_status), per split value here
 static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
+    if (fabsf(v) > 65504.0f) {
+        unsigned bits;
+        const float a = fabsf(v);
+        memcpy(&bits, &a, 4);
+        g_sp_range_host[0] += 1u;
+        if (bits > g_sp_range_host[1]) g_sp_range_host[1] = bits;
+    }
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
     h = sp_h_from_f32(v);
     l = sp_h_from_f32((v - sp_h_to_f32(h)) * 2048.0f);
@@ -148,8 +156,13 @@ static int host_conv_split(const void* x, const void* w, const float* bias, cons
 }
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void*) {
-    if (S != 9 || (C != 128 && C != 64)) return 1;
+    if (!((S == 9 && (C == 128 || C == 64)) || (S == 17 && C == 64))) return 1;
     return host_conv_split(x, w, bias, res, y, boards, S, C, C, relu);
+}
+int split_range_status(unsigned out[2], int reset, void*) {
+    out[0] = g_sp_range_host[0], out[1] = g_sp_range_host[1];
+    if (reset) g_sp_range_host[0] = g_sp_range_host[1] = 0u;
+    return 0;
 }
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void*) {
     if (cin < 1 || cin > 32) return 1;
@@ -164,9 +177,19 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
             }
     return 0;
 }
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int relu, void*) {
-    if (S != 9 || (C != 128 && C != 64)) return 1;
-    return host_conv_split(x, w, bias, nullptr, y, boards, S, 32, C, relu);
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*) {
+    if (!((S == 9 && (C == 128 || C == 64) && pad == 1) || (S == 13 && C == 64 && pad == 3))) return 1;
+    if (pad == 1) return host_conv_split(x, w, bias, nullptr, y, boards, S, 32, C, relu);
+    // embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1): the pad-3 convolution of the board is the pad-1 convolution of that plane
+    const int So = S + 2 * (pad - 1), off = pad - 1, P2 = S * S, Po = So * So;
+    std::vector<unsigned short> xe((size_t)boards * 2 * 4 * Po * 8, 0);
+    const unsigned short* xs = (const unsigned short*)x;
+    for (long long b = 0; b < boards; ++b)
+        for (int pc = 0; pc < 8; ++pc)  // (plane, chunk)
+            for (int yy = 0; yy < S; ++yy)
+                for (int xx = 0; xx < S; ++xx)
+                    memcpy(&xe[(((size_t)b * 8 + pc) * Po + (size_t)(yy + off) * So + xx + off) * 8], &xs[(((size_t)b * 8 + pc) * P2 + (size_t)yy * S + xx) * 8], 16);
+    return host_conv_split(xe.data(), w, bias, nullptr, y, boards, So, 32, C, relu);
 }
 int launch_head_split(const HeadSplitArgs& a, void*) {
     const int P2 = a.S * a.S, nch = a.C / 8, kp = a.npol * P2, kv = (3 - a.npol) * P2;

@@ -3,6 +3,7 @@ import os
 import subprocess
 import sys
 
+import pytest
 import numpy as np
 import torch
 
@@ -429,3 +430,23 @@ def test_harvest_is_deterministic_and_capacity_keeps_a_prefix():
             if u in first and u < 40:  # first game of a slot: not yet affected by the slots that stalled on a full harvest
                 assert torch.equal(st[int(g[i, 0]):int(g[i, 0]) + int(g[i, 1])], first[u][0])
     assert set(uid_small[:8]) <= set(uid_big)
+
+
+@pytest.mark.parametrize("n_samples", [1, 2, 7])
+@pytest.mark.parametrize("shape,A", [((17, 9, 9), 82), ((17, 13, 13), 169), ((17, 19, 19), 362), ((17, 5, 5), 26)])
+def test_pack_unpack_round_trip_every_row_count(n_samples, shape, A):
+    """The wire format of the sample gather (core/gather.py) round-trips bit for bit for ANY sample count -- a single sample included:
+    at 9x9 Go a row is 173 + 328 + 4 = 505 bytes (not a multiple of 4), and a [1, k] slice of such a row must still become a dense,
+    4-byte aligned buffer before it is viewed as float32 (one-sample harvests crashed the replay rank)."""
+    from alpha_zero_amd.core.gather import pack_samples, unpack_samples
+
+    g = torch.Generator().manual_seed(n_samples * 1000 + A)
+    st = (torch.rand((n_samples,) + shape, generator=g) < 0.3).to(torch.int8)
+    pi = torch.rand((n_samples, A), generator=g)
+    z = torch.rand((n_samples,), generator=g) * 2 - 1
+    rows = pack_samples(st, pi, z)
+    assert rows.shape == (n_samples, (int(np.prod(shape)) + 7) // 8 + 4 * A + 4)
+    # the receiving side sees the rows as a slice of one flat byte buffer (gather_samples: out[r][: n * rb].reshape(n, rb))
+    flat = torch.cat([rows.reshape(-1), torch.zeros(13, dtype=torch.uint8)])
+    s2, p2, z2 = unpack_samples(flat[: rows.numel()].reshape(n_samples, rows.shape[1]), shape, A)
+    assert torch.equal(s2, st) and torch.equal(p2, pi) and torch.equal(z2, z)

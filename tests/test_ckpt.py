@@ -51,3 +51,42 @@ def test_gpu_shipped_checkpoint_on_the_hand_written_kernels(golden_dir):
     dp, dv = (pri.cpu() - ref_p).abs().max().item(), (v.cpu() - torch.from_numpy(g["value"])).abs().max().item()
     agree = (pri.cpu().argmax(-1) == ref_p.argmax(-1)).float().mean().item()
     assert dp <= 6e-2 and dv <= 6e-2 and agree >= 0.95, (dp, dv, agree)
+
+
+def test_checkpoint_loader_never_unpickles_code_by_default(tmp_path, monkeypatch):
+    """load_checkpoint_state (the actor's start-up load and its hot-swap, pipeline.py:208-212 / :232-239 in the reference): the
+    learner's dictionary (network, optimizer state, MultiStepLR state with its collections.Counter, training_steps) loads with the
+    safe loader; a file that needs the full unpickler is REFUSED unless the caller opts in, and a missing / corrupt file raises its
+    own error instead of being retried unsafely."""
+    import collections
+    import pickle
+
+    import pytest
+
+    from alpha_zero_amd.core.pipeline import load_checkpoint_state
+
+    good = os.path.join(str(tmp_path), "good.ckpt")
+    torch.save({"network": {"w": torch.ones(3)}, "optimizer": {"state": {}, "param_groups": [{"lr": 0.1}]},
+                "lr_scheduler": {"milestones": collections.Counter({100: 1, 200: 1}), "gamma": 0.1, "last_epoch": 5}, "training_steps": 7}, good)
+    st = load_checkpoint_state(good)
+    assert st["training_steps"] == 7 and st["lr_scheduler"]["milestones"][100] == 1 and torch.equal(st["network"]["w"], torch.ones(3))
+
+    marker = os.path.join(str(tmp_path), "code_ran")
+
+    class Code:  # unpickling this object calls a function (here: os.mkdir): exactly what weights_only=True exists to stop
+        def __reduce__(self):
+            return (os.mkdir, (marker,))
+
+    bad = os.path.join(str(tmp_path), "bad.ckpt")
+    torch.save({"network": {}, "training_steps": 1, "extra": Code()}, bad)
+    monkeypatch.delenv("AZSP_ALLOW_PICKLE_CKPT", raising=False)
+    with pytest.raises(pickle.UnpicklingError):
+        load_checkpoint_state(bad)
+    assert not os.path.exists(marker)
+    assert load_checkpoint_state(bad, allow_pickle=True)["training_steps"] == 1 and os.path.isdir(marker)  # explicit opt-in only
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint_state(os.path.join(str(tmp_path), "missing.ckpt"))
+    trunc = os.path.join(str(tmp_path), "trunc.ckpt")
+    open(trunc, "wb").write(open(good, "rb").read()[:100])
+    with pytest.raises(Exception):
+        load_checkpoint_state(trunc)
