@@ -11,6 +11,10 @@ Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 
 concurrent games per GPU, 200 sims/move with the reference budget semantics (root.N >= sims + P,
 inherited visits count: mcts_v2.py:568), num_parallel P = 8, 10-block x 128-filter AlphaZeroNet
 (random Kaiming init, torch.manual_seed(1)), Dirichlet root noise, sub-tree reuse, resign disabled.
+The evaluator runs at the REFERENCE'S precision class (fp32: pipeline.py:91-123, no autocast anywhere in the reference) on the
+hand-written split-precision kernels (az_conv_sp.h: every value a hi + lo f16 pair, a product = three f16 MFMAs into fp32
+accumulators; as close to fp64 as the library's fp32 convolution, tests/test_split_tower.py).  `--net-dtype bf16 / fp16` select the
+lower-precision evaluators; the default run reports the bf16 one as a labelled companion, never as `value`.
 One "step" = one engine round over all games: expand/backup of the previous G*P leaf batch, end-of-move
 work, selection of the next P leaves per game, observation planes, and the network forward on G*P rows.
 All inputs live in HBM; nothing crosses PCIe inside the timed region except the harvests of finished games.
@@ -28,14 +32,22 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# Multi-process GPU work on this pool needs dmabuf IPC (the host driver supports no legacy IPC handles: without this RCCL fails in
+# hipIpcGetMemHandle).  It is exported in the build container and on the GPU boxes; bench.py sets it for itself and for the ranks it
+# launches so that an N-GPU run does not depend on the caller's environment.  Must be in place before the HSA runtime initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
+SPLIT_PRODUCTS = 3  # f16 MFMA products per fp32-class multiply-add of the split-precision kernels (w_hi x_hi, w_hi x_lo, w_lo x_hi)
+DTYPE_LABEL = {"fp32": "fp32-class evaluator (f16 hi+lo pairs, 3 MFMA products, fp32 accumulate) / f32-f64 tree",
+               "bf16": "bf16 evaluator / f32-f64 tree", "fp16": "fp16 evaluator / f32-f64 tree"}
 
 
 def net_flops_per_eval(n, A, blocks, filters, fc, gomoku):
@@ -76,7 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--parallel", type=int, default=8)
     ap.add_argument("--blocks", type=int, default=10)
     ap.add_argument("--filters", type=int, default=128)
-    ap.add_argument("--net-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--net-dtype", default="fp32", choices=["bf16", "fp16", "fp32"],
+                    help="evaluator precision class: fp32 (default) = the reference's (pipeline.py:91-123 evaluates in fp32) on the hand-written "
+                         "split-precision kernels (hi + lo f16 pairs, three MFMA products, fp32 accumulation); bf16 / fp16 = the lower-precision evaluators")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
     ap.add_argument("--preroll-rounds", type=int, default=300, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
@@ -85,7 +99,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=60.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="0 = all usable host cores (cgroup quota aware)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-evaluator companion measurement (fp32_moves_per_s)")
+    ap.add_argument("--no-companions", "--no-fp32", dest="no_companions", action="store_true",
+                    help="skip the companion measurements (lower-precision bf16 evaluator, library fp32 evaluator)")
     ap.add_argument("--no-fresh-tree", action="store_true",
                     help="skip the sub-tree-reuse-off companion measurement (fresh_tree_moves_per_s, SURVEY 8d's upper-work variant)")
     ap.add_argument("--no-miopen-find", action="store_true", help="disable torch.backends.cudnn.benchmark (MIOpen find) for the convs")
@@ -245,6 +260,118 @@ def per_rank_report(cnt, elapsed, world, dev):
             "harvest_gather_share_of_time": round(float(t[:, 4].max()), 5)}  # of each rank's own timed region, the largest
 
 
+def tower_replay(actor, args, dev, reps=5):
+    """Replays the forward's own tower launch sequence on the live activations of the last forward, one HIP event after every launch
+    (the events are recorded on the stream the kernels are launched on).  Returns None when the tower is not on hand-written kernels."""
+    import ctypes
+
+    inf, dll = actor.infer, actor.binding.dll
+    n = args.board
+    S_t = n + 2 * (inf.stem_pad - 1)  # tower planes (17x17 behind the Gomoku pad-3 stem)
+    rows = actor.engine.rows
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    split = args.net_dtype == "fp32" and getattr(inf, "_split", None) is not None and inf.supports_split_features(n, dev)
+    tiled = args.net_dtype != "fp32" and getattr(inf, "_tiled", None) is not None and actor.tiled_features
+    if not (split or tiled):
+        return None
+    fused = tiled and inf.use_fused_block and (args.filters, S_t) in ((64, 17), (64, 9)) and args.net_dtype == "bf16"  # one launch per ResNetBlock
+    if split:
+        (a, m, o), _, _, _ = inf._split_buffers(rows, S_t, args.filters, dev, 0)  # slot 0 = the engine-facing forward's buffers
+        conv_fn, wts = dll.azsp_conv3x3_split, inf.wsp
+    else:
+        a, m, o = inf._tiled
+        conv_fn, wts = (dll.azsp_conv3x3_tiled_f16 if args.net_dtype == "fp16" else dll.azsp_conv3x3_tiled), inf.wp
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps * inf.n_blocks + 1)]
+    torch.cuda.synchronize(dev)
+    k = 0
+    ev[0].record()
+    for _ in range(reps):
+        for i in range(inf.n_blocks):  # the forward's own launch sequence
+            if fused:
+                assert dll.azsp_resblock_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), inf.wp[2 * i + 1].data_ptr(),
+                                               inf.b32[2 * i + 1].data_ptr(), o.data_ptr(), rows, S_t, args.filters, st) == 0
+                k += 1
+                ev[k].record()
+                a, o = o, a
+                continue
+            assert conv_fn(a.data_ptr(), wts[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
+            k += 1
+            ev[k].record()
+            assert conv_fn(m.data_ptr(), wts[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows, S_t, args.filters, 1, st) == 0
+            k += 1
+            ev[k].record()
+            a, o = o, a
+    torch.cuda.synchronize(dev)
+    d = [ev[j].elapsed_time(ev[j + 1]) for j in range(k)]
+    return {"launches": k, "avg_ms": float(np.mean(d)), "planes": S_t, "fused_block": fused, "split": split,
+            "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2]))}
+
+
+def tower_roofline(conv, args, step_ms):
+    """`roofline` object of the step's dominant kernel from tower_replay's timings."""
+    n = args.board
+    rows = args.games * args.parallel
+    S_t, fused, split = conv["planes"], conv["fused_block"], conv["split"]
+    convs_per_launch = 2 if fused else 1
+    # algorithmic work per launch = the dense 3x3 convolution (padding taps counted, the usual convention): 2 * rows * S^2 * C * C * 9 flop
+    conv_flops = 2.0 * rows * S_t * S_t * args.filters * args.filters * 9 * convs_per_launch
+    launches_per_step = args.blocks * (1 if fused else 2)
+    # HBM traffic per launch is NOT measured in this run: it comes from a separate `rocprofv3 --pmc` pass (the guide's recipe: counters in
+    # their own run) whose summary is committed under profiles/ -- labelled as such in `traffic_source`
+    if split:
+        cname = "split_kernel_pmc.json" if S_t == 9 else "split17_kernel_pmc.json"
+    else:
+        cname = "block64_kernel_pmc.json" if fused else ("conv_kernel_pmc.json" if (S_t == 9 and args.filters == 128) else "conv64_kernel_pmc.json")
+    ctraffic, csrc = None, None
+    cprof = os.path.join(ROOT, "profiles", cname)
+    if os.path.exists(cprof):
+        try:
+            pj = json.load(open(cprof))
+            if pj.get("rows") == rows and pj.get("board") == n and pj.get("channels") == args.filters:
+                ctraffic, csrc = pj.get("hbm_bytes_per_launch"), "from_profiles: profiles/" + cname + " (separate rocprofv3 --pmc pass, not this run)"
+        except Exception:
+            ctraffic = None
+    if split:
+        # fp32-class arithmetic on the f16 matrix pipe: every multiply-add of the algorithm is SPLIT_PRODUCTS f16 MFMA products (hi x hi, hi x lo,
+        # lo x hi).  `achieved` counts the products the kernel has to issue -- that is what the MFMA roofline bounds -- and the
+        # fp32-equivalent rate (algorithmic flops / time) is reported beside it.
+        issued = SPLIT_PRODUCTS * conv_flops
+        tf = issued / (conv["avg_ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS["fp16"]
+        kname = ("k_conv3x3_sp" if S_t == 9 else "k_conv3x3_sp17") + (" (split-precision 3x3 convolution of the residual tower: hi + lo f16 pairs, "
+                                                                     "three f16 MFMA products per multiply, fp32 accumulation; weight-stationary)")
+        elem, passes = 4, 2.5  # hi + lo f16 = 4 bytes per activation element; x in, y out, residual on every second layer
+        extra = {"mfma_products_per_multiply": SPLIT_PRODUCTS, "alg_flops_per_launch": conv_flops, "issued_f16_mfma_flops_per_launch": issued,
+                 "fp32_equivalent_tflops": round(conv_flops / (conv["avg_ms"] * 1e-3) / 1e12, 2), "fp32_mfma_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
+                 "fp32_equivalent_over_fp32_mfma_peak": round(conv_flops / (conv["avg_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["fp32"], 3),
+                 "peak_note": "2500 TFLOP/s = dense f16 MFMA peak; achieved = issued f16 MFMA products (3 per multiply of the fp32-class algorithm)"}
+    else:
+        tf = conv_flops / (conv["avg_ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.net_dtype]
+        if fused:
+            kname = "k_resblock64 (one whole ResNetBlock per launch: both 3x3 convolutions, intermediate activation in LDS, skip from the resident input tile)"
+            passes = 2.0   # x in, y out
+        else:
+            kname = {(9, 128): "k_conv3x3_tiled", (17, 64): "k_conv3x3_t64", (9, 64): "k_conv3x3_t64",
+                     (19, 256): "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get((S_t, args.filters), "conv3x3")
+            kname += f" (weight-stationary MFMA 3x3 convolution of the residual tower, {'f16' if args.net_dtype == 'fp16' else 'bf16'})"
+            passes = 4.5 if S_t == 19 else 2.5
+        elem = 2
+        extra = {"alg_flops_per_launch": conv_flops}
+    roofline = {"kernel": kname, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5),
+                "traffic": ctraffic, "traffic_source": csrc, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * elem * passes),
+                "avg_launch_ms": round(conv["avg_ms"], 4),
+                "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4) if conv["avg_ms_plain"] is not None else None,
+                "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4) if conv["avg_ms_residual"] is not None else None,
+                "launches_per_step": launches_per_step, "share_of_step": round(launches_per_step * conv["avg_ms"] / step_ms, 4),
+                # annotation, not a measurement of this run: the MFMA-only ceiling on post-ReLU-like operands at the 1400 W package limit,
+                # measured by tools/probes/mfma_power_probe.hip
+                "power_limited_mfma_only_tflops": {"value": 1840.0, "source": "from_profiles: profiles/r02_mfma_power_probe.txt"},
+                "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
+    roofline.update(extra)
+    return roofline
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -257,7 +384,7 @@ def main(argv=None):
                 raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible; refusing to report fewer ranks than asked")
         import subprocess
 
-        raise SystemExit(subprocess.call(self_launch_cmd(args, argv)))
+        raise SystemExit(subprocess.call(self_launch_cmd(args, argv), env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ["HSA_ENABLE_IPC_MODE_LEGACY"])))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -321,43 +448,7 @@ def main(argv=None):
         raise SystemExit("bench.py: no move was committed inside the timed region -- the pre-roll did not reach the steady state")
 
     # ---- dominant kernel (the tower convolution): average launch duration, HIP events on the launch stream -----------
-    conv = None
-    if rank == 0 and getattr(actor.infer, "_tiled", None) is not None and actor.tiled_features:
-        import ctypes
-
-        inf, dll = actor.infer, actor.binding.dll
-        conv_fn = dll.azsp_conv3x3_tiled_f16 if args.net_dtype == "fp16" else dll.azsp_conv3x3_tiled
-        a, m, o = inf._tiled  # real activations of the last forward
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rows = eng.rows
-        S_t = n + 2 * (inf.stem_pad - 1)  # tower planes (17x17 behind the Gomoku pad-3 stem)
-        reps = 5
-        fused = inf.use_fused_block and (args.filters, S_t) in ((64, 17), (64, 9))  # one launch per ResNetBlock (azsp_resblock_tiled)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps * inf.n_blocks + 1)]
-        torch.cuda.synchronize(dev)
-        k = 0
-        ev[0].record()
-        for _ in range(reps):
-            for i in range(inf.n_blocks):  # the forward's own launch sequence, one event after every launch
-                if fused:
-                    assert dll.azsp_resblock_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), inf.wp[2 * i + 1].data_ptr(),
-                                                   inf.b32[2 * i + 1].data_ptr(), o.data_ptr(), rows, S_t, args.filters, st) == 0
-                    k += 1
-                    ev[k].record()
-                    a, o = o, a
-                    continue
-                assert conv_fn(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
-                k += 1
-                ev[k].record()
-                assert conv_fn(m.data_ptr(), inf.wp[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows,
-                                              S_t, args.filters, 1, st) == 0
-                k += 1
-                ev[k].record()
-                a, o = o, a
-        torch.cuda.synchronize(dev)
-        d = [ev[j].elapsed_time(ev[j + 1]) for j in range(k)]
-        conv = {"launches": k, "avg_ms": float(np.mean(d)), "planes": S_t, "fused_block": fused,
-                "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2]))}
+    conv = tower_replay(actor, args, dev) if rank == 0 else None
 
     if args.split_round and rank == 0:
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -407,107 +498,46 @@ def main(argv=None):
                                           "achieved_GBs": round(bk_bytes / (bk_ms * 1e-3) / 1e9, 2)}}
         flops_eval = net_flops_per_eval(n, A, args.blocks, args.filters, args.filters, game != "go")
         nn_tflops = flops_eval * args.games * args.parallel / (nn_ms * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[args.net_dtype]
-        nn_roof = {"kernel": "whole evaluator forward on G*P rows (stem + tower + heads)", "bound": "mfma",
-                   "achieved": round(nn_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+        split_eval = conv is not None and conv["split"]
+        # fp32-class evaluator: every multiply is SPLIT_PRODUCTS f16 MFMA products, so the bound on ALGORITHMIC flops is the f16 peak / 3
+        peak = MFMA_PEAK_TFLOPS["fp16"] / SPLIT_PRODUCTS if split_eval else MFMA_PEAK_TFLOPS[args.net_dtype]
+        nn_roof = {"kernel": "whole evaluator forward on G*P rows (stem + tower + heads)" + (", algorithmic (fp32-equivalent) flops; peak = f16 MFMA peak / 3 products" if split_eval else ""),
+                   "bound": "mfma", "achieved": round(nn_tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                    "frac": round(nn_tflops / peak, 5), "avg_forward_ms": round(nn_ms, 3),
                    "share_of_step": round(nn_ms / (bk_ms + k_ms + nn_ms), 4),
                    "batch_fill": round((cnt["leaves"] + cnt["root_evals"]) / (steps * args.games * args.parallel), 4)}
-        if conv is not None:
-            # the step's dominant kernel: 2 * blocks launches per forward.  Algorithmic work per launch = the dense 3x3
-            # convolution (padding taps counted, the usual convention): 2 * rows * N^2 * C * C * 9 flop.
-            rows = args.games * args.parallel
-            S_t = conv["planes"]
-            fused = conv["fused_block"]
-            convs_per_launch = 2 if fused else 1
-            conv_flops = 2.0 * rows * S_t * S_t * args.filters * args.filters * 9 * convs_per_launch
-            tf = conv_flops / (conv["avg_ms"] * 1e-3) / 1e12
-            # HBM traffic per launch is NOT measured in this run: it comes from a separate `rocprofv3 --pmc` pass (the guide's recipe:
-            # counters in their own run) whose summary is committed under profiles/ -- labelled as such in `traffic_source`
-            ctraffic, csrc = None, None
-            cname = "block64_kernel_pmc.json" if fused else ("conv_kernel_pmc.json" if (S_t == 9 and args.filters == 128) else "conv64_kernel_pmc.json")
-            cprof = os.path.join(ROOT, "profiles", cname)
-            if os.path.exists(cprof):
-                try:
-                    pj = json.load(open(cprof))
-                    if pj.get("rows") == rows and pj.get("board") == n and pj.get("channels") == args.filters:
-                        ctraffic, csrc = pj.get("hbm_bytes_per_launch"), "from_profiles: profiles/" + cname + " (separate rocprofv3 --pmc pass, not this run)"
-                except Exception:
-                    ctraffic = None
-            if fused:
-                kname = "k_resblock64 (one whole ResNetBlock per launch: both 3x3 convolutions, intermediate activation in LDS, skip from the resident input tile)"
-                passes = 2.0   # x in, y out
-            else:
-                kname = {(9, 128): "k_conv3x3_tiled", (17, 64): "k_conv3x3_t64", (9, 64): "k_conv3x3_t64",
-                         (19, 256): "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get((S_t, args.filters), "conv3x3")
-                kname += f" (weight-stationary MFMA 3x3 convolution of the residual tower, {'f16' if args.net_dtype == 'fp16' else 'bf16'})"
-                passes = 4.5 if S_t == 19 else 2.5
-            launches_per_step = args.blocks * (1 if fused else 2)
-            roofline = {"kernel": kname,
-                        "bound": "mfma",
-                        "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5), "traffic": ctraffic, "traffic_source": csrc,
-                        "alg_flops_per_launch": conv_flops, "alg_hbm_bytes_per_launch": round(rows * S_t * S_t * args.filters * 2 * passes),
-                        "avg_launch_ms": round(conv["avg_ms"], 4),
-                        "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4) if conv["avg_ms_plain"] is not None else None,
-                        "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4) if conv["avg_ms_residual"] is not None else None,
-                        "launches_per_step": launches_per_step,
-                        "share_of_step": round(launches_per_step * conv["avg_ms"] / (bk_ms + k_ms + nn_ms), 4),
-                        # annotation, not a measurement of this run: the MFMA-only ceiling on post-ReLU-like operands at the 1400 W package
-                        # limit, measured by tools/probes/mfma_power_probe.hip
-                        "power_limited_mfma_only_tflops": {"value": 1840.0, "source": "from_profiles: profiles/r02_mfma_power_probe.txt"},
-                        "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
-        else:
-            roofline = engine_roof
-        fp32 = fp32_lib = None
-        if world == 1 and args.net_dtype != "fp32" and not args.no_fp32:
-            # the reference's evaluator precision (pipeline.py:91-123 runs the network in fp32): same engine, same workload, fp32-class
-            # network, shorter pre-roll and window -- companion numbers, never `value`.  Two evaluators: (a) the tower on the
-            # hand-written split-precision kernel (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 accumulation;
-            # as close to fp64 as the library's fp32 convolution, tests/test_split_tower.py) where the shape has it, (b) the
-            # library's fp32 convolutions + fused epilogue kernel.
-            def companion(split, steps, pre):
-                a = make_actor("fp32")
-                a.infer.use_split_tower = split
+        roofline = tower_roofline(conv, args, bk_ms + k_ms + nn_ms) if conv is not None else engine_roof
+        # ---- companions (world == 1 only): the same engine and workload with another evaluator -- labelled, never `value` ----------
+        lowp = fp32_lib = None
+        if world == 1 and not args.no_companions:
+            def companion(dtype_name, split, steps, pre, label):
+                a = make_actor(dtype_name)
+                if dtype_name == "fp32":
+                    a.infer.use_split_tower = split
+                    a._graph = None
                 prer = preroll(a, args, world, dev, min_rounds=pre)
                 el, c, ev, _ = timed(a, args, world, dev, 5, steps)
-                used_split = getattr(a.infer, "_split", None) is not None
-                tower = None
-                if used_split:  # the split-precision tower convolution, replayed on the activations of the last forward (HIP events)
-                    import ctypes
-
-                    inf, dll = a.infer, a.binding.dll
-                    xa, xm, xo, rows_s = inf._split
-                    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-                    S_s, C_s = args.board, args.filters
-                    ms = {}
-                    for nm, rp in (("plain", None), ("residual", xa)):
-                        for rep in range(2):  # first pass: warm-up
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for _ in range(10):
-                                dll.azsp_conv3x3_split(xm.data_ptr(), inf.wsp[1].data_ptr(), inf.b32[1].data_ptr(), rp.data_ptr() if rp is not None else None,
-                                                       xo.data_ptr(), rows_s, S_s, C_s, 1, st)
-                            e1.record()
-                            torch.cuda.synchronize(dev)
-                            ms[nm] = e0.elapsed_time(e1) / 10
-                    avg = 0.5 * (ms["plain"] + ms["residual"])
-                    fl = 2.0 * rows_s * S_s * S_s * C_s * C_s * 9
-                    tower = {"kernel": "k_conv3x3_sp (split-precision 3x3 convolution: hi + lo f16 pairs, three f16 MFMA products, fp32 accumulation)",
-                             "avg_launch_ms": round(avg, 4), "avg_launch_ms_plain": round(ms["plain"], 4), "avg_launch_ms_residual": round(ms["residual"], 4),
-                             "fp32_equivalent_tflops": round(fl / avg / 1e9, 1), "fp32_mfma_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
-                             "f16_mfma_flops_tflops": round(3 * fl / avg / 1e9, 1), "frac_of_f16_mfma_peak": round(3 * fl / avg / 1e9 / MFMA_PEAK_TFLOPS["fp16"], 4),
-                             "launches_per_step": 2 * args.blocks}
+                path = a.infer.evaluator_path(n, dev)
+                cv = tower_replay(a, argparse.Namespace(**{**vars(args), "net_dtype": dtype_name}), dev, reps=2) if (dtype_name != "fp32" or split) else None
                 r = {"moves_per_s": round(c["moves"] / el, 2), "sims_per_sec": round(c["sims"] / el, 1), "ms_per_step": round(el / steps * 1e3, 3),
-                     "sims_per_move": round(c["sims"] / max(1, c["moves"]), 2), "steps": steps, "warmup": 5, "preroll_rounds": prer,
-                     "forward_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev])), 3),
-                     "evaluator": a.evaluator_path if used_split else "fp32, library convolutions + fused epilogue kernel", "tower_kernel": tower}
+                     "sims_per_move": round(c["sims"] / max(1, c["moves"]), 2), "steps": steps, "warmup": 5, "preroll_rounds": prer, "protocol": label,
+                     "forward_ms": round(float(np.mean([e[2].elapsed_time(e[3]) for e in ev])), 3), "dtype": DTYPE_LABEL[dtype_name] if (dtype_name != "fp32" or split) else "fp32 (library convolutions) / f32-f64 tree",
+                     "evaluator": path,
+                     "tower_kernel_avg_launch_ms": round(cv["avg_ms"], 4) if cv else None}
                 del a, ev
                 torch.cuda.empty_cache()
-                return r, used_split
+                return r
 
-            fp32, used_split = companion(True, 40, 60)
-            if used_split:
-                fp32_lib, _ = companion(False, 20, 30)
+            if args.net_dtype == "fp32":
+                # (a) the lower-precision evaluator (bf16 hand-written kernels): what rounds 1-3 reported as the headline.  Narrower arithmetic
+                # than the reference's, bounded against it in tests/test_precision_parity.py; full protocol (same pre-roll as the headline)
+                lowp = companion("bf16", True, args.steps, args.preroll_rounds, "full (the headline's pre-roll and window)")
+                # (b) the reference's precision on LIBRARY convolutions (+ azsp_bias_act): what the hand-written fp32-class kernels replace
+                if conv is not None and conv["split"]:
+                    fp32_lib = companion("fp32", False, min(20, args.steps), 30, "short protocol (30-round pre-roll, <= 20 steps: 180 ms per round)")
+            else:
+                # a lower-precision run: the reference-precision evaluator as the companion
+                lowp = companion("fp32", True, min(40, args.steps), 60, "short protocol (60-round pre-roll, <= 40 steps)")
         fresh = None
         if world == 1 and not args.no_fresh_tree:
             # SURVEY 8d's "fresh-tree" variant: sub-tree reuse off (mcts_v2.py:436-446 never runs), every move pays the full budget of
@@ -553,7 +583,8 @@ def main(argv=None):
             "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "process_group": process_group,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": f"{args.net_dtype} evaluator / f32-f64 tree", "data": "synthetic",
+            "dtype": DTYPE_LABEL[args.net_dtype] if (args.net_dtype != "fp32" or (conv is not None and conv["split"])) else "fp32 (library convolutions) / f32-f64 tree",
+            "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
                                    f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",
                        "evaluator": actor.evaluator_path,
@@ -568,8 +599,10 @@ def main(argv=None):
             "serial_step_ms": round(bk_ms + k_ms + nn_ms, 3),
             "samples_gathered": samples_at_root, "preroll_rounds": preroll_rounds, "per_rank": ranks,
             "dup_leaf_rate": round(cnt["dup_leaves"] / max(1, cnt["leaves"]), 5), "terminal_hit_rate": round(cnt["terminal_hits"] / max(1, cnt["sims"]), 5),
-            "fp32_moves_per_s": fp32["moves_per_s"] if fp32 else None, "fp32_companion": fp32,
+            ("bf16_moves_per_s" if args.net_dtype == "fp32" else "fp32_moves_per_s"): lowp["moves_per_s"] if lowp else None,
+            ("lower_precision_companion" if args.net_dtype == "fp32" else "fp32_companion"): lowp,
             "fp32_library_moves_per_s": fp32_lib["moves_per_s"] if fp32_lib else None, "fp32_library_companion": fp32_lib,
+            "speedup_vs_library_fp32": round(total_moves / elapsed_max / fp32_lib["moves_per_s"], 2) if fp32_lib and fp32_lib["moves_per_s"] > 0 else None,
             "fresh_tree_moves_per_s": fresh["moves_per_s"] if fresh else None, "fresh_tree_companion": fresh,
             "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,

@@ -83,3 +83,20 @@ def test_bench_measurement_flow_two_ranks_gloo(tmp_path):
     for r, f in enumerate((f0, f1)):
         assert abs(f0["per_rank"]["moves_per_s"][r] - f["local_moves"] / f["elapsed"]) <= 0.06
     assert f0["per_rank"]["harvest_gather_calls"] == 240 // 7 and min(f0["per_rank"]["harvest_gather_ms_mean"]) > 0
+
+
+def test_bench_exports_dmabuf_ipc_mode_for_itself_and_its_ranks(monkeypatch):
+    """Multi-process GPU work on this pool needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; RCCL otherwise fails in hipIpcGetMemHandle):
+    bench.py puts it in its own environment at import (before the HSA runtime starts) -- never overriding a caller's choice -- and hands
+    it to the ranks it self-launches (VERDICT r3 #7: the nccl tests exported it, the self-launch did not)."""
+    import importlib
+    import subprocess
+    import sys
+
+    src = ("import os; os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); import bench; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY']);"
+           "os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '1'; import importlib; importlib.reload(bench); print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])")
+    out = subprocess.run([sys.executable, "-c", src], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["0", "1"]
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'subprocess.call(self_launch_cmd(args, argv), env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=' in text

@@ -219,7 +219,7 @@ def test_gpu_parallel_evaluation_games_match_reference(golden_dir):
     ac.check_device_route_arena("gpu", golden_dir)
 
 
-def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, min_games):
+def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, min_games, dtype=None, want=None):
     """Size-independent properties of everything the actor emits: every harvested game alternates colours, z is +1 for the winner's
     samples and -1 for the loser's, every pi is a distribution that never puts mass on an occupied point of its own position,
     lengths are within max_steps, counters are consistent, no stall / fault."""
@@ -232,9 +232,12 @@ def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, 
     torch.manual_seed(1)
     NP = n * n
     net = AlphaZeroNet((17, n, n), NP + 1, blocks, filters, filters)
-    a = SelfPlayActor(net, game="go", board_size=n, num_games=G, num_simulations=sims, num_parallel=8, device="cuda", net_dtype=torch.bfloat16,
+    dtype = torch.bfloat16 if dtype is None else dtype
+    a = SelfPlayActor(net, game="go", board_size=n, num_games=G, num_simulations=sims, num_parallel=8, device="cuda", net_dtype=dtype,
                       binding=_lib.load())
-    assert a.tiled_features
+    assert "hand-written" in a.evaluator_path and (want is None or want in a.evaluator_path), a.evaluator_path
+    assert a.tiled_features == (dtype != torch.float32)
+    digests = []
     # short games so that many finish: long random openings, then the search plays them out
     rng = np.random.Generator(np.random.PCG64(5))
     plies = rng.integers(open_lo, open_hi + 1, size=G)
@@ -251,6 +254,9 @@ def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, 
         if not len(rows):
             continue
         stc, pic, zc = st.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+        import hashlib
+
+        digests.append(hashlib.sha1(stc.tobytes() + pic.tobytes() + zc.tobytes() + np.ascontiguousarray(rows).tobytes()).hexdigest())
         assert np.all(np.isin(zc, (-1.0, 0.0, 1.0))) and np.allclose(pic.sum(axis=1), 1.0, atol=1e-4)
         occupied = (stc[:, 0] + stc[:, 1]).reshape(len(stc), NP) > 0   # planes 0 / 1: the current position's stones
         assert not np.any((pic[:, :NP] > 0) & occupied)               # no visit on an occupied point
@@ -268,12 +274,61 @@ def _selfplay_properties(n, G, sims, blocks, filters, open_lo, open_hi, rounds, 
     c = a.counters()
     assert games >= min_games and samples > 10 * min_games and c["stalls"] == 0
     assert c["sims"] == c["leaves"] + c["terminal_hits"] and c["games"] >= games and c["moves"] > 0
+    assert a.range_events == 0
+    return digests
 
 
 @pytest.mark.gpu
 def test_gpu_full_size_selfplay_properties():
     """BASELINE size: 9x9 Go, G = 4096, 200 sims, P = 8, 10x128 bf16 on the hand-written evaluator, 600 rounds."""
     _selfplay_properties(9, 4096, 200, 10, 128, 100, 150, 600, 1000)
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_selfplay_properties_fp32_class_evaluator():
+    """The HEADLINE configuration (bench.py default): 9x9 Go, G = 4096, 200 sims, P = 8, 10x128 at the reference's precision class on the
+    hand-written split-precision evaluator (hi + lo f16 pairs, three MFMA products), 600 rounds: every harvested game / sample property
+    of the bf16 run above, no out-of-range activation (range record stays 0), and DETERMINISM at full size: a second actor with the
+    same seed reproduces the harvest stream of the first 300 rounds bit for bit (search, evaluator under hipGraph replay, production
+    randomness, harvest row assignment)."""
+    import torch
+
+    d600 = _selfplay_properties(9, 4096, 200, 10, 128, 100, 150, 600, 1000, dtype=torch.float32, want="split-precision")
+    d300 = _selfplay_properties(9, 4096, 200, 10, 128, 100, 150, 300, 300, dtype=torch.float32, want="split-precision")
+    assert len(d300) >= 4 and d600[: len(d300)] == d300
+
+
+@pytest.mark.gpu
+def test_gpu_gomoku13_selfplay_fp32_class_evaluator_same_seed_same_stream():
+    """BASELINE C2 shape at the reference's precision: 13x13 Gomoku, 6 x 64, the hand-written split-precision evaluator on 17x17 planes
+    (az_conv_sp17.h), G = 1024, 64 simulations: two actors with the same seed give the same harvest stream bit for bit; games end with a
+    winner or a draw, z follows the winner, pi is a distribution on empty points."""
+    import torch
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    torch.manual_seed(4)
+    net = AlphaZeroNet((17, 13, 13), 169, 6, 64, 64, gomoku=True)
+    streams = []
+    for _ in range(2):
+        act = SelfPlayActor(net, game="gomoku", board_size=13, num_games=1024, num_simulations=64, num_parallel=8, warm_up_steps=8, seed=5, device="cuda",
+                            engine_kw={"max_steps": 40})
+        assert "split-precision" in act.evaluator_path and "hand-written" in act.evaluator_path, act.evaluator_path
+        out = []
+        for _ in range(6):
+            act.run_rounds(60)
+            st, pi, z, games = act.harvest_tensors(clone=True)
+            out.append((st.cpu(), pi.cpu(), z.cpu(), games.copy()))
+        assert act.range_events == 0
+        streams.append((out, act.counters()))
+        del act
+    (a, ca), (b, cb) = streams
+    assert ca == cb and sum(len(g) for *_, g in a) > 300
+    for (s0, p0, z0, g0), (s1, p1, z1, g1) in zip(a, b):
+        assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(g0, g1)
+        assert torch.allclose(p0.sum(1), torch.ones(len(p0)), atol=1e-4)
+        occupied = (s0[:, 0] + s0[:, 1]).reshape(len(s0), 169) > 0
+        assert not bool(((p0 > 0) & occupied).any())
 
 
 @pytest.mark.gpu
@@ -313,7 +368,7 @@ def test_gpu_game_range_rounds_and_half_batch_forwards_equal_whole_batch_rounds(
     out = []
     for split in (False, True):
         act = SelfPlayActor(net, game=game, board_size=n, num_games=G, num_simulations=24, num_parallel=P, warm_up_steps=4, resign_threshold=-1.0,
-                            seed=7, device="cuda", use_graph=False, engine_kw={"max_steps": 24})
+                            seed=7, device="cuda", use_graph=False, net_dtype=torch.bfloat16, engine_kw={"max_steps": 24})
         e = act.engine
         games_by_uid = {}
         for _ in range(6):
@@ -346,9 +401,11 @@ def test_gpu_game_range_rounds_and_half_batch_forwards_equal_whole_batch_rounds(
 
 
 @pytest.mark.gpu
-def test_gpu_same_seed_gives_the_same_harvest_stream():
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float32"])
+def test_gpu_same_seed_gives_the_same_harvest_stream(dtype_name):
     """Two actors with the same seed produce the same harvest stream -- the same games in the same output rows, bit for bit: search,
-    evaluator (hand-written bf16 kernels, hipGraph replay), production randomness and the harvest's row assignment are all deterministic.
+    evaluator (hand-written bf16 kernels / the fp32-class split-precision kernels, hipGraph replay), production randomness and the
+    harvest's row assignment are all deterministic.
     (Round 2 reserved harvest rows with a CAS race; a missing barrier behind the LDS zero fill of the 9x9 convolution kernel could,
     rarely, perturb a forward -- both would show here.)"""
     import numpy as np
@@ -361,7 +418,8 @@ def test_gpu_same_seed_gives_the_same_harvest_stream():
     streams = []
     for _ in range(2):
         act = SelfPlayActor(net, game="go", board_size=9, num_games=1024, num_simulations=24, num_parallel=8, warm_up_steps=4, resign_threshold=-1.0,
-                            seed=11, device="cuda", engine_kw={"max_steps": 30})
+                            seed=11, device="cuda", net_dtype=getattr(torch, dtype_name), engine_kw={"max_steps": 30})
+        assert "hand-written" in act.evaluator_path
         out = []
         for _ in range(8):
             act.run_rounds(50)

@@ -22,7 +22,8 @@ def test_gpu_search_with_shipped_checkpoint_fp32_and_bf16(golden_dir):
     reference exactly.  (2) fp32 on the device (InferenceNet fp32: library convolutions + azsp_bias_act) differs from the CPU's fp32 in
     the last bits, so a PUCT arg-max can flip: teacher-forced on the reuse-free golden every move is an independent comparison; stated
     tolerance: >= 90 % of the moves identical (pi to 1e-6, same sampled move), all moves |pi - pi_ref|_inf <= 0.08, |root_Q - ref| <=
-    0.02.  (3) bf16 hand-written kernels (checkpoint widened 40 -> 64 filters): reported, with loose bounds."""
+    0.02.  (3) bf16 hand-written kernels (checkpoint widened 40 -> 64 filters): reported, with loose bounds.  (4) the fp32-class
+    hand-written evaluator (checkpoint widened to 64 filters, split-precision kernels on 17x17 planes): the bounds of (2).  """
     from alpha_zero_amd import _lib
     from alpha_zero_amd.core.network import InferenceNet, widen_network
 
@@ -41,8 +42,29 @@ def test_gpu_search_with_shipped_checkpoint_fp32_and_bf16(golden_dir):
     out["bf16_kernels_teacher_forced"] = s16
     recs, total = rc.run_golden("gpu", "gomoku13_ckpt200000_p1_s100", rc.inference_eval_func(inf32, 13, tiled=False), teacher_forced=False)
     out["fp32_device_free_run_with_reuse"] = rc.summarize(recs, total)
+    assert "library" in inf32.evaluator_path(13, "cuda")  # (10 x 40: no hand-written kernel at this width -- that is what (4) widens for)
+    # (4) round 4: the reference's precision class on HAND-WRITTEN kernels: the checkpoint widened 40 -> 64 filters (function-preserving)
+    # on the split-precision evaluator (azsp_stem_split pad 3 -> azsp_conv3x3_split at 17x17 -> azsp_head_split).  Same statement and
+    # bounds as the library fp32 path, on all three goldens (teacher-forced without reuse; free-running with reuse, P = 1 and P = 8).
+    infsp = InferenceNet(widen_network(net, 64), dtype=torch.float32, binding=_lib.load()).cuda()
+    assert "hand-written" in infsp.evaluator_path(13, "cuda") and "split-precision" in infsp.evaluator_path(13, "cuda")
+    ssp = {}
+    for key, name, tf in (("teacher_forced", "gomoku13_ckpt200000_p1_s100_fresh", True), ("free_run_with_reuse", "gomoku13_ckpt200000_p1_s100", False),
+                          ("free_run_parallel_p8_s200", "gomoku13_ckpt200000_p8_s200", False)):
+        infsp._split = None
+        recs, total = rc.run_golden("gpu", name, rc.inference_eval_func(infsp, 13, tiled=False), teacher_forced=tf)
+        assert infsp._split is not None, "the split-precision kernels did not run"
+        ssp[key] = rc.summarize(recs, total)
+    out["fp32_class_hand_written_kernels"] = ssp
+    assert infsp.split_range_status(reset=True)[0] == 0
     os.makedirs(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "realnet_search_parity.json"), "w"), indent=1)
     assert s32["moves_compared"] == s32["moves_in_golden"] >= 40
     assert s32["exact_moves"] >= 0.9 * s32["moves_compared"] and s32["max_dpi"] <= 0.08 and s32["max_dq"] <= 0.02, s32
     assert s16["same_move"] >= 0.8 and s16["top1"] >= 0.8 and s16["mean_dpi"] <= 0.05 and s16["mean_dq"] <= 0.03, s16
+    t = ssp["teacher_forced"]
+    assert t["moves_compared"] == t["moves_in_golden"] >= 40
+    assert t["exact_moves"] >= 0.9 * t["moves_compared"] and t["max_dpi"] <= 0.08 and t["max_dq"] <= 0.02, ssp
+    for key in ("free_run_with_reuse", "free_run_parallel_p8_s200"):  # free-running: compared until the first differing move of a game
+        f = ssp[key]
+        assert f["moves_compared"] >= 0.8 * f["moves_in_golden"] and f["exact_moves"] >= 0.9 * f["moves_compared"] and f["max_dq"] <= 0.02, ssp

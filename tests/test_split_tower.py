@@ -84,6 +84,59 @@ def test_split_abi_host_twin():
     assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.clone().data_ptr(), 1, 11, 64, 1, None) != 0  # unsupported plane size
 
 
+def test_split_abi_host_twin_17x17_and_pad3_stem():
+    """The 13x13 Gomoku shapes through the ABI on the host twin: azsp_conv3x3_split at (S, C) = (17, 64), and the pad-3 stem (13x13
+    feature board -> 17x17 planes, network.py:101-105) + tower + heads through InferenceNet.forward_split vs the fp64 module."""
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    x, r, w, b = _inputs(1, 64, 17, 5)
+    y, rt = _run_split_conv(bnd, x, r, w, b, 1, "cpu")
+    ref = _ref64(x, r, w, b, 1)
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() <= 2e-6 and rt <= 2.0 ** -21
+    net = _trained_like_gomoku_net(64, 1)
+    inf = InferenceNet(net, dtype=torch.float32, binding=bnd)
+    xs = (torch.rand(2, 17, 13, 13, generator=torch.Generator().manual_seed(2)) > 0.6).float()
+    pri, v = inf.forward_split(xs)
+    with torch.no_grad():
+        lg, v64 = net.double()(xs.double())
+    dp, dv = (pri.double() - torch.softmax(lg, -1)).abs().max().item(), (v.double() - v64.squeeze(1)).abs().max().item()
+    assert dp <= 2e-6 and dv <= 2e-6, (dp, dv)
+    # shapes without a kernel are refused, not guessed
+    z = torch.zeros(2 * 2 * 169 * 64, dtype=torch.float16)
+    assert bnd.dll.azsp_stem_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.clone().data_ptr(), 1, 13, 64, 1, 1, None) != 0  # 13x13 with pad 1
+    assert bnd.dll.azsp_stem_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.clone().data_ptr(), 1, 9, 64, 3, 1, None) != 0
+
+
+def test_split_range_record_host_twin_and_weight_check():
+    """Out-of-range values are clamped AND recorded (azsp_split_range_status: events, largest |v|, reset); folded weights beyond f16's
+    range are refused when they are packed (ValueError) instead of turning into inf / a silent clamp."""
+    import ctypes
+
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    ev, mx = ctypes.c_uint32(7), ctypes.c_float(7.0)
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 1, None) == 0  # reset whatever earlier tests left
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 0, None) == 0 and ev.value == 0 and mx.value == 0.0
+    x = torch.tensor([1.0, -3.0, 65504.0, 1e-7, 0.0, 3.0, -2.5e-5, 60000.0]).reshape(1, 8, 1, 1).contiguous(memory_format=torch.channels_last)
+    s = torch.zeros(2 * 8, dtype=torch.float16)
+    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None) == 0
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 0, None) == 0 and ev.value == 0  # +-65504 itself is in range
+    x[0, 1, 0, 0], x[0, 5, 0, 0] = -1e5, 70000.0
+    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None) == 0
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), None, 0, None) == 0 and ev.value == 2
+    assert bnd.dll.azsp_split_range_status(None, ctypes.byref(mx), 1, None) == 0 and mx.value == 1e5
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 0, None) == 0 and ev.value == 0 and mx.value == 0.0
+    w = torch.randn(8, 8, 3, 3)
+    assert split_weights_f16(w).shape == (2, 9, 8, 8)
+    for bad in (7e4, float("inf"), float("nan")):
+        w2 = w.clone()
+        w2[3, 2, 1, 1] = bad
+        with pytest.raises(ValueError):
+            split_weights_f16(w2)
+
+
 def test_split_tower_clamps_at_f16_range_host_twin():
     """Values beyond f16's largest finite number are clamped when they are split (documented in include/azsp.h), never inf / NaN."""
     import engine_util as eu
@@ -165,6 +218,16 @@ def test_column_tile_map_in_the_header_is_the_generated_one():
     tab = [int(v) for v in re.findall(r"\d+", body[: body.index("}};")].split("{{", 1)[1])]
     assert len(gen) == 80 and gen == tab
     assert sorted(gen) == [p for p in range(81) if p != 72]  # every position but the corner (8, 0), once
+
+
+def _trained_like_gomoku_net(filters, blocks, seed=3, fc=64):
+    torch.manual_seed(seed)
+    net = AlphaZeroNet((17, 13, 13), 169, blocks, filters, fc, gomoku=True).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2), m.running_var.uniform_(0.5, 1.5), m.weight.uniform_(0.7, 1.3), m.bias.normal_(0, 0.2)
+    return net
 
 
 def _trained_like_net(filters, blocks, seed=3):
@@ -249,3 +312,136 @@ def test_gpu_split_stem_and_heads_vs_fp64(boards):
             lg, v64 = net.double()(x.double())
         dp, dv = (pri.cpu().double() - torch.softmax(lg, -1)).abs().max().item(), (v.cpu().double() - v64.squeeze(1)).abs().max().item()
         assert dp <= 2e-6 and dv <= 4e-6, (filters, boards, dp, dv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 2, 255, 256, 257, 300, 600, 1100])
+def test_gpu_split_conv17_error_vs_fp64(boards):
+    """k_conv3x3_sp17 (17x17 planes x 64 filters: the 13x13 Gomoku tower, half-board tiles) vs fp64, next to the library's fp32
+    convolution.  Board counts around one / two / four boards per workgroup (256 persistent workgroups) exercise the first-board,
+    has-next and last-board paths of the two-tiles-per-board loop.  Same bound as the 9x9 kernel: max |y - y64| <= 2e-6 max|y64| and
+    at most 2x the library's own fp32 error + 5e-7."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    out = []
+    for res, relu in ((False, 1), (True, 1), (True, 0)):
+        x, r, w, b = _inputs(boards, 64, 17, 300 + boards)
+        if not relu:
+            x = x - 0.3
+        y, rt = _run_split_conv(bnd, x, r if res else None, w, b, relu, "cuda")
+        ref = _ref64(x, r if res else None, w, b, relu)
+        lib = F.conv2d(x.cuda(), w.cuda(), b.cuda(), padding=1)
+        if res:
+            lib = lib + r.cuda()
+        lib = (torch.relu(lib) if relu else lib).cpu()
+        scale = ref.abs().max().item()
+        d = (y.double() - ref).abs()
+        err, lib_err = d.max().item() / scale, (lib.double() - ref).abs().max().item() / scale
+        worst = [int(v) for v in torch.nonzero(d == d.max())[0]]  # (board, channel, row, column) of the worst element: a layout bug shows here
+        out.append(dict(boards=boards, S=17, C=64, residual=res, relu=relu, err=err, library_fp32_err=lib_err, layout_roundtrip_rel=rt, worst=worst))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "split_conv17_error.jsonl"), "a") as f:
+        for o in out:
+            f.write(json.dumps(o) + "\n")
+    for o in out:
+        assert o["layout_roundtrip_rel"] <= 2.0 ** -21, o
+        assert o["err"] <= 2e-6 and o["err"] <= 2 * o["library_fp32_err"] + 5e-7, o
+
+
+@pytest.mark.gpu
+def test_gpu_fp32_gomoku_network_on_the_split_kernels():
+    """The whole fp32-class evaluator of the 13x13 Gomoku network (BASELINE C2: 6 x 64; azsp_split_features -> azsp_stem_split with the
+    pad-3 stem -> azsp_conv3x3_split at 17x17 -> azsp_head_split) and the all-library fp32 InferenceNet, each against the fp64 module.
+    Same bound as the 9x9 networks: within 2e-4 of fp64 and at most 4x + 2e-5 the library path's distance."""
+    from alpha_zero_amd import _lib
+
+    net = _trained_like_gomoku_net(64, 6)
+    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    assert inf.supports_split_features(13, "cuda") and "hand-written" in inf.evaluator_path(13, "cuda")
+    x = (torch.rand(131, 17, 13, 13, generator=torch.Generator().manual_seed(1)) > 0.6).float()
+    with torch.no_grad():
+        lg, v64 = net.double()(x.double())
+    p64, v64 = torch.softmax(lg, -1), v64.squeeze(1)
+
+    def dist(pv):
+        return (pv[0].cpu().double() - p64).abs().max().item(), (pv[1].cpu().double() - v64).abs().max().item()
+
+    d = dict(filters=64, board=13)
+    inf._split = None
+    d["split_evaluator_vs_fp64"] = dist(inf(x.cuda()))
+    assert inf._split is not None, "the split kernels did not run"
+    inf.use_split_heads, inf._split = False, None
+    d["split_tower_library_heads_vs_fp64"] = dist(inf(x.cuda()))
+    assert inf._split is not None and "azsp_conv3x3_split" in inf.evaluator_path(13, "cuda")
+    inf.use_split_tower = False
+    d["library_vs_fp64"] = dist(inf(x.cuda()))
+    assert inf.split_range_status(reset=True)[0] == 0
+    print(json.dumps(d))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(d, open(os.path.join(ROOT, "gpurun_out", "split_network_error_gomoku13_64.json"), "w"))
+    for name in ("split_evaluator_vs_fp64", "split_tower_library_heads_vs_fp64"):
+        for k in (0, 1):
+            assert d[name][k] <= 2e-4 and d[name][k] <= 4 * d["library_vs_fp64"][k] + 2e-5, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 3, 4, 5, 259])
+def test_gpu_split_gomoku_stem_and_heads_vs_fp64(boards):
+    """azsp_split_features + azsp_stem_split (13x13 board, pad 3 -> 17x17 planes) and azsp_head_split (289 positions, 169 actions) on
+    their own (a 0-block network = stem -> heads) vs the fp64 module."""
+    from alpha_zero_amd import _lib
+
+    net = _trained_like_gomoku_net(64, 0, seed=boards, fc=80)
+    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    x = (torch.rand(boards, 17, 13, 13, generator=torch.Generator().manual_seed(boards)) > 0.6).float()
+    inf._split = None
+    pri, v = inf(x.cuda())
+    assert inf._split is not None
+    with torch.no_grad():
+        lg, v64 = net.double()(x.double())
+    dp, dv = (pri.cpu().double() - torch.softmax(lg, -1)).abs().max().item(), (v.cpu().double() - v64.squeeze(1)).abs().max().item()
+    assert dp <= 2e-6 and dv <= 4e-6, (boards, dp, dv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C", [(9, 128), (9, 64), (17, 64)])
+def test_gpu_split_range_record_trips_and_resets(S, C):
+    """The +-65504 clamp of the split kernels is OBSERVABLE: in-range launches leave the sticky record at zero; an
+    activation that leaves f16's range inside the convolution's epilogue (here: a 9-tap sum of 3e4-sized inputs, and a residual that
+    pushes one output over) is clamped, counted and its magnitude reported; the layout conversion reports out-of-range inputs; reset
+    clears the record.  The clamped result itself is finite (65504), never inf / NaN."""
+    import ctypes
+
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    dll = bnd.dll
+
+    def status(reset=0):
+        ev, mx = ctypes.c_uint32(0), ctypes.c_float(0.0)
+        assert dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), reset, None) == 0
+        return ev.value, mx.value
+
+    status(1)
+    x, r, w, b = _inputs(5, C, S, 11)
+    y, _ = _run_split_conv(bnd, x, r, w, b, 1, "cuda")
+    assert status() == (0, 0.0)
+    # identity-like filter bank (centre tap of channel c -> c, weight 4): y = 4 x + b (+ r)
+    w2 = torch.zeros(C, C, 3, 3)
+    w2[torch.arange(C), torch.arange(C), 1, 1] = 4.0
+    x2 = torch.full((5, C, S, S), 100.0)
+    x2[3, 5, S - 1, 0] = 3e4          # 4 * 3e4 = 1.2e5 > 65504 in the epilogue of the convolution (the 9x9 kernel's corner position)
+    x2[1, 7, 2, 3] = 2e4              # 8e4: an ordinary position
+    b2 = torch.zeros(C)
+    y2, _ = _run_split_conv(bnd, x2, None, w2, b2, 1, "cuda")
+    ev, mx = status()
+    assert ev >= 2 and mx == 120000.0, (ev, mx)
+    assert torch.isfinite(y2).all() and y2[3, 5, S - 1, 0] == 65504.0 and y2[1, 7, 2, 3] == 65504.0 and abs(y2[0, 0, 0, 0].item() - 400.0) < 1e-3
+    assert status(1)[0] == ev and status() == (0, 0.0)
+    # the conversion into the split layout reports what it clamps, too
+    x3 = x.clone()
+    x3[2, 1, 0, 0] = -1e6
+    xs = torch.zeros(dll.azsp_split_bytes(5, S, C) // 2, dtype=torch.float16, device="cuda")
+    assert dll.azsp_split_layout(x3.cuda().contiguous(memory_format=torch.channels_last).data_ptr(), xs.data_ptr(), 5, S, C, 1, None) == 0
+    assert status(1) == (1, 1e6)

@@ -17,7 +17,7 @@ from alpha_zero_amd.core.pipeline import SelfPlayActor  # noqa: E402
 torch.manual_seed(1)
 net = AlphaZeroNet((17, 9, 9), 82, 10, 128, 128)
 act = SelfPlayActor(net, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8, resign_threshold=-1.0, seed=1,
-                    device="cuda", use_graph=True)
+                    device="cuda", use_graph=True, net_dtype=torch.bfloat16)
 act.run_rounds(120)
 torch.cuda.synchronize()
 e = act.engine

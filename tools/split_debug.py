@@ -14,7 +14,7 @@ n, filters, A, G, P, tb, g_split = 9, 128, 82, 1184, 8, 3, 576
 torch.manual_seed(4)
 net = AlphaZeroNet((17, n, n), A, 2, filters, 64)
 mk = lambda: SelfPlayActor(net, game="go", board_size=n, num_games=G, num_simulations=24, num_parallel=P, warm_up_steps=4, resign_threshold=-1.0,
-                           seed=7, device="cuda", use_graph=False, engine_kw={"max_steps": 24})
+                           seed=7, device="cuda", use_graph=False, net_dtype=torch.bfloat16, engine_kw={"max_steps": 24})
 W, S = mk(), mk()
 harvest = os.environ.get("SPLIT_DEBUG_HARVEST", "1") == "1"
 for r in range(240):
