@@ -62,9 +62,10 @@ def test_gpu_search_with_shipped_checkpoint_fp32_and_bf16(golden_dir):
     assert s32["moves_compared"] == s32["moves_in_golden"] >= 40
     assert s32["exact_moves"] >= 0.9 * s32["moves_compared"] and s32["max_dpi"] <= 0.08 and s32["max_dq"] <= 0.02, s32
     assert s16["same_move"] >= 0.8 and s16["top1"] >= 0.8 and s16["mean_dpi"] <= 0.05 and s16["mean_dq"] <= 0.03, s16
-    t = ssp["teacher_forced"]
-    assert t["moves_compared"] == t["moves_in_golden"] >= 40
-    assert t["exact_moves"] >= 0.9 * t["moves_compared"] and t["max_dpi"] <= 0.08 and t["max_dq"] <= 0.02, ssp
-    for key in ("free_run_with_reuse", "free_run_parallel_p8_s200"):  # free-running: compared until the first differing move of a game
+    # measured on MI355X (profiles/r04_realnet_search_parity.json): 54 / 54, 54 / 54 and 52 / 52 moves identical, pi identical, |dQ| <= 1.2e-7.
+    # The hand-written kernels pick no algorithm at run time (unlike the library), so the statement is box-independent: EVERY move of
+    # all three goldens identical (pi to 1e-6, same sampled move), |root_Q - ref| and |best_child_Q - ref| <= 1e-6.
+    for key in ("teacher_forced", "free_run_with_reuse", "free_run_parallel_p8_s200"):
         f = ssp[key]
-        assert f["moves_compared"] >= 0.8 * f["moves_in_golden"] and f["exact_moves"] >= 0.9 * f["moves_compared"] and f["max_dq"] <= 0.02, ssp
+        assert f["moves_compared"] == f["moves_in_golden"] >= 40 and f["exact_moves"] == f["moves_compared"], ssp
+        assert f["max_dpi"] <= 1e-6 and f["max_dq"] <= 1e-6 and f["max_dcq"] <= 1e-6, ssp
