@@ -479,12 +479,15 @@ __global__ void k_tile_layout(const unsigned char* __restrict__ src, unsigned ch
 // out[b][pl][q] = relu(sum_c w[pl][c] x[b][q][c] + bias[pl]); planes [0, npol) go to pol_out [boards][npol][81], the rest to
 // val_out [boards][NPL - npol][S*S] (bf16; plane-major per board = nn.Flatten order; rows pol_stride / val_stride elements
 // apart), any (S, C) of the tiled layout.  HBM-bound: one pass over the tower output.
+// The NPL x C weights are read through wave-uniform (scalar) loads straight from global memory -- the kernel uses NO LDS.  Rounds 1-3
+// staged them in an LDS table first; with two evaluator forwards in flight on two streams a wave of that version occasionally
+// computed with a value other than the table held before and after (round 4, tools/probes/make_head_probe.py + tools/concurrency_probe2.py,
+// profiles/r04_concurrency_probe2_*.txt: LDS table -> 36 / 40 rounds differ from a serial run; weights from global memory -> 0 / 40;
+// the table verified intact at the end of every workgroup; tower input identical).  Without the table the question does not arise.
 template <int NPL, bool F16 = false> __global__ void __launch_bounds__(256)
 k_head_tiled(const unsigned char* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, unsigned short* __restrict__ pol_out,
              unsigned short* __restrict__ val_out, long long npos, int npol, int C, int P2, int tile_rows, int pol_stride, int val_stride) {
-    extern __shared__ float ws[];  // [NPL][C]
-    for (int i = threadIdx.x; i < NPL * C; i += 256) ws[i] = w[i];
-    __syncthreads();
+    const float* __restrict__ ws = w;  // [NPL][C], wave-uniform indices below -> s_load
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= npos) return;
     const int nch = C / 8;

@@ -121,6 +121,43 @@ __device__ __forceinline__ unsigned sp_pack(_Float16 a, _Float16 b) { return __b
 __device__ __forceinline__ _Float16 sp_lo16(unsigned v) { return __builtin_bit_cast(sp_f16x2, v)[0]; }
 __device__ __forceinline__ _Float16 sp_hi16(unsigned v) { return __builtin_bit_cast(sp_f16x2, v)[1]; }
 
+// ---- epilogue building blocks (one VALU instruction each; the epilogues below issue them as micro-ops between MFMAs) ----
+// (f16) half `H` of rl * 2^-11 + (f16) half `H` of rh in ONE v_fma_mix_f32 = sp_join of a packed residual element (f16 inputs are exact
+// in fp32 and the fma rounds once: bit-identical to the convert / convert / fma sequence)
+template <int H> __device__ __forceinline__ float sp_mix_join(unsigned rh, unsigned rl) {
+    float r;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(rl), "s"(SP_INV_SCALE), "v"(rh));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(rl), "s"(SP_INV_SCALE), "v"(rh));
+    return r;
+}
+// s - 2^11 * (f16) half `H` of hpk, with s = 2^11 v: the scaled remainder (v - hi) 2^11 of sp_split in one v_fma_mix_f32 (both products
+// are exact in fp32 and so is their difference: bit-identical to the subtract-then-scale of sp_split)
+template <int H> __device__ __forceinline__ float sp_mix_rem(unsigned hpk, float s) {
+    float r;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "s"(-SP_SCALE), "v"(s));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "s"(-SP_SCALE), "v"(s));
+    return r;
+}
+__device__ __forceinline__ unsigned sp_cvt_pk(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, (sp_f16x2){(_Float16)a, (_Float16)b});
+}
+// Static schedule of a riding epilogue: P_OPS micro-ops spread evenly over the MFMA slots [S0, S0 + AVAIL) of the carrying unit
+// (a 16-cycle MFMA hides about one VALU instruction: a flat ceil(P_OPS / AVAIL) per slot would issue bursts of two early and none late)
+template <int P_OPS, int S0, int AVAIL> struct SpSpread {
+    static constexpr int MAXPER = (P_OPS + AVAIL - 1) / AVAIL;
+    static constexpr int cum(int sl) {  // micro-ops issued in the slots <= sl
+        if (sl < S0) return 0;
+        const long long c = ((long long)(sl - S0 + 1) * P_OPS + AVAIL - 1) / AVAIL;
+        return c > P_OPS ? P_OPS : (int)c;
+    }
+    static constexpr int slot_of(int o) {  // the slot that issues micro-op o
+        int sl = S0;
+        while (cum(sl) <= o) ++sl;
+        return sl;
+    }
+    static_assert(AVAIL > 0 && cum(S0 + AVAIL - 1) == P_OPS, "every micro-op has a slot");
+};
+
 // fp32 channels-last rows [boards * P2][C] <-> split layout; one thread per (board, chunk, position), positions fastest
 // (the 16-byte accesses of the split side are contiguous per chunk strip)
 __global__ void __launch_bounds__(256)
@@ -268,6 +305,33 @@ static_assert(SP_HEAD_BPB == 4, "one wave per board in the last phase of k_head_
 __device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, const sp_f16x8& b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(wa), "v"(b));
 }
+// Vector-memory instructions a wave of k_conv3x3_sp issues between the last LDS-DMA piece of the next board (unit 0, k-step NPIECE) and
+// the board's barrier (unit 1, k-step KS - 2): the stores of the riding epilogues (2 per column tile) and unit 1's residual loads (2 per
+// column tile, first slots of the unit).  Mirrors the kernel's schedule (same constants, same SpSpread arithmetic).
+template <bool RES, int NCH> __host__ __device__ constexpr int sp9_vm_younger() {
+    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (SpGeo9::CELLS + 63) / 64, NPIECE = NP * (2 * NCH / 4);
+    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
+    int n = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int nj = i == 0 ? 3 : 2, pnj = i == 0 ? 2 : 3, NQ = 3 * nj, P_OPS = pnj * CT_OPS;
+        const int AVAIL = (i == 1 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
+        auto cum = [&](int sl) {
+            if (sl < S0) return 0;
+            const long long c = ((long long)(sl - S0 + 1) * P_OPS + AVAIL - 1) / AVAIL;
+            return c > P_OPS ? P_OPS : (int)c;
+        };
+        for (int c = 0; c < pnj; ++c)
+            for (int st = 0; st < 2; ++st) {  // the two stores of column tile c are its last two micro-ops
+                const int o = c * CT_OPS + CT_OPS - 2 + st;
+                int sl = S0;
+                while (cum(sl) <= o) ++sl;
+                if (i > 0 || sl / NQ > NPIECE) ++n;  // a DMA piece is issued behind all MFMA slots of its k-step
+            }
+        if (RES && i > 0) n += 2 * nj;  // (unit 0 loads its residual in its first slots, before the first piece)
+    }
+    return n;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_conv3x3_sp<RES, NCH, NCG>: NCH = input-channel chunks of 8 (16: 128 -> C layer, 8: 64 -> C layer, 4: the stem, 17 planes padded to 32
 // -> C); NCG = cout groups of 64 (C = 64 NCG).
@@ -291,7 +355,9 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     constexpr int NP = (G::CELLS + 63) / 64;
     constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;
     constexpr int NF = 2 * KS, NF_A = NF < 64 ? NF : 64;
-    constexpr int E_OPS = RES ? 13 : 9, CT_OPS = 4 * E_OPS + 6;  // epilogue micro-ops per element / per column tile
+    // epilogue micro-ops: per element E1 (join, [residual join, add,] ReLU, range record, clamp), per pair of elements 6 more (packed hi
+    // convert, 2 scalings, 2 remainders, packed lo convert), per column tile 2 stores
+    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert((2 * KS) % R == 0, "a board's k-steps keep the ring phase");
     static_assert(KS - 1 >= NPIECE, "the next board's pieces ride in unit 0");
@@ -402,40 +468,36 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             accm[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accc[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             rr[a][j][0] = (cv_u32x2){0u, 0u}, rr[a][j][1] = (cv_u32x2){0u, 0u};
         }
-    float ev = 0.0f, t0 = 0.0f, t1 = 0.0f, mx = 0.0f;  // mx: the largest |value| this lane produced (range record, sp_range_report)
-    _Float16 hh[4], ll[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) hh[e] = (_Float16)0.0f, ll[e] = (_Float16)0.0f;
-    unsigned pk0 = 0, pk1 = 0;
-    // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`
+    float evv[2] = {0.0f, 0.0f}, sc[2] = {0.0f, 0.0f}, t0 = 0.0f, mx = 0.0f;  // mx: the largest |value| this lane produced (range record, sp_range_report)
+    unsigned hpk[2] = {0u, 0u}, lpk[2] = {0u, 0u};
+    // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`: ONE VALU / memory instruction
     auto epi_op = [&](int set, int j, int mj, unsigned char* out, int o, bool store_ok) {
-        if (o < 4 * E_OPS) {
-            const int e = o / E_OPS, k = o % E_OPS;
-            const unsigned rh = (e < 2 ? rr[set][j][0].x : rr[set][j][0].y), rl = (e < 2 ? rr[set][j][1].x : rr[set][j][1].y);
-            const int tail = RES ? k - 4 : k;  // ops after the residual part
-            if (k == 0) ev = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
-            else if (RES && k == 1) t0 = (float)((e & 1) ? sp_hi16(rh) : sp_lo16(rh));
-            else if (RES && k == 2) t1 = (float)((e & 1) ? sp_hi16(rl) : sp_lo16(rl));
-            else if (RES && k == 3) t0 = fmaf(t1, SP_INV_SCALE, t0);
-            else if (RES && k == 4) ev = cw_add_f32(ev, t0);
-            else if (tail == 1) ev = fmaxf(ev, lo_relu);
-            else if (tail == 2) mx = fmaxf(mx, __builtin_fabsf(ev));                          // what the reference would carry on ...
-            else if (tail == 3) ev = __builtin_amdgcn_fmed3f(ev, -SP_F16_MAX, SP_F16_MAX);  // ... is clamped here (and recorded)
-            else if (tail == 4) hh[e] = (_Float16)ev;
-            else if (tail == 5) t0 = (float)hh[e];
-            else if (tail == 6) t1 = ev - t0;
-            else if (tail == 7) t1 = t1 * SP_SCALE;
-            else if (tail == 8) ll[e] = (_Float16)t1;
+        if (o < 2 * PAIR) {
+            const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
+            if (k < 2 * E1) {
+                const int ei = k / E1, kk = k % E1, e = 2 * pr + ei;
+                const unsigned rh = pr == 0 ? rr[set][j][0].x : rr[set][j][0].y, rl = pr == 0 ? rr[set][j][1].x : rr[set][j][1].y;
+                const int tail = kk - (RES ? 3 : 1);
+                if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
+                else if (RES && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
+                else if (RES && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
+                else if (tail == 0) evv[ei] = fmaxf(evv[ei], lo_relu);
+                else if (tail == 1) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
+                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], -SP_F16_MAX, SP_F16_MAX);                   // ... is clamped here (and recorded)
+            } else {
+                const int kk = k - 2 * E1;
+                if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
+                else if (kk == 1) sc[0] = evv[0] * SP_SCALE;
+                else if (kk == 2) sc[1] = evv[1] * SP_SCALE;
+                else if (kk == 3) sc[0] = sp_mix_rem<0>(hpk[pr], sc[0]);
+                else if (kk == 4) sc[1] = sp_mix_rem<1>(hpk[pr], sc[1]);
+                else lpk[pr] = sp_cvt_pk(sc[0], sc[1]);
+            }
         } else {
-            const int k = o - 4 * E_OPS;
             const unsigned gq = lmap[mj] >> 16;
-            if (k == 0) pk0 = sp_pack(hh[0], hh[1]);
-            else if (k == 1) pk1 = sp_pack(hh[2], hh[3]);
-            else if (k == 2) {
-                if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){pk0, pk1};
-            } else if (k == 3) pk0 = sp_pack(ll[0], ll[1]);
-            else if (k == 4) pk1 = sp_pack(ll[2], ll[3]);
-            else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){pk0, pk1};
+            if (o == 2 * PAIR) {
+                if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){hpk[0], hpk[1]};
+            } else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){lpk[0], lpk[1]};
         }
     };
 
@@ -471,16 +533,24 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             constexpr int pnj = i == 0 ? NJ1 : NJ0, pj0 = i == 0 ? NJ0 : 0;        // the previous unit's
             constexpr int nnj = pnj, nj0 = pj0;                                     // the next unit's (= the other one)
             constexpr int NQ = 3 * nj, P_OPS = pnj * CT_OPS;                        // MFMAs per k-step; micro-ops of the riding epilogue
-            constexpr int PER = (P_OPS + (NQ * KS - S0 - 4) - 1) / (NQ * KS - S0 - 4);  // micro-ops per MFMA gap
-            static_assert(PER <= (NCH >= 16 ? 1 : NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
+            // the riders are spread evenly over the unit's MFMA gaps and end 4 slots before the unit does; in unit 1 they end before the
+            // barrier (whose counted wait knows exactly which vector-memory instructions are younger than the next board's DMA pieces)
+            constexpr int AVAIL = (i == 1 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
+            typedef SpSpread<P_OPS, S0, AVAIL> SP;
+            static_assert(SP::MAXPER <= (NCH >= 16 ? 1 : NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
             unsigned char* pout = i == 0 ? yprev : ybase;
             const bool pstore = i > 0 || have_prev;
             cp_for_each([&](auto TC) __attribute__((always_inline)) {
                 constexpr int t = decltype(TC)::value;
                 constexpr int g = i * KS + t;  // running k-step of the board
                 if constexpr (i == 1 && t == KS - (R - 1)) {
-                    // every read of this buffer has been issued; this wave's pieces of the next board (unit 0) have completed
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // every read of this buffer has been issued.  This wave's pieces of the next board (unit 0) are older than the
+                    // VM_YOUNGER youngest vector-memory instructions it has issued (stores of the riding epilogues, unit 1's residual
+                    // loads: counted at compile time, each is issued unconditionally); those may stay in flight
+                    constexpr int VM_YOUNGER = sp9_vm_younger<RES, NCH>();
+                    static_assert(VM_YOUNGER < 63, "vmcnt field");
+                    if (have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first board: the stores riding in its unit 0 were skipped
                     CV_BARRIER();
                 }
                 if constexpr (t + R - 1 < KS) load_step(Xs, j0, nj, t + R - 1, (g + R - 1) % R);
@@ -501,9 +571,9 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                     }
                     constexpr int sl = t * NQ + q;  // MFMA slot of the unit
                     cp_for_each([&](auto KC) __attribute__((always_inline)) {
-                        constexpr int o = (sl - S0) * PER + decltype(KC)::value;
-                        if constexpr (sl >= S0 && o < P_OPS) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
-                    }, typename CpMakeSeq<PER>::type{});
+                        constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
+                        if constexpr (o < SP::cum(sl)) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
+                    }, typename CpMakeSeq<SP::MAXPER>::type{});
                     if constexpr (RES && sl < 2 * nj) {  // this unit's residual (used by its epilogue inside the next unit)
                         constexpr int rj = sl >> 1, rp = sl & 1;
                         rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * YPLANE + (lmap[j0 + rj] >> 16));

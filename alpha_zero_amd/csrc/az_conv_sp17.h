@@ -22,7 +22,8 @@
 //     shadow of the first unit's MFMAs; ONE barrier per tile.
 //   * a tile is 4 units of <= 3 column tiles with two accumulator sets; the epilogue of unit i - 1 (join of the two accumulators,
 //     residual, range check, clamp, split into hi / lo, two 8-byte stores per column tile) rides in the MFMA stream of unit i as
-//     micro-ops; the B-fragment ring (3 k-steps) runs on across units, tiles and boards.
+//     one-instruction micro-ops spread evenly over the unit's MFMA gaps (v_fma_mix_f32 joins / remainders straight on the packed f16
+//     halves, packed converts: 38 micro-ops per column tile against 54 MFMAs); the B-fragment ring (3 k-steps) runs on across units, tiles and boards.
 //   * NCH = 4 is the STEM (17 planes padded to 32 channels -> 64): the input is the 13x13 feature board of azsp_split_features, embedded
 //     at (2, 2) of the zero 17x17 plane by the DMA masks -- a pad-3 convolution of the board IS the pad-1 convolution of that plane.
 // Per board and wave: 19 column tiles x 18 k-steps x 3 products = 1026 MFMAs (v_mfma_f32_16x16x32_f16); HBM: each tensor once
@@ -120,6 +121,35 @@ __host__ __device__ constexpr int sp17_uj0(int h, int u) {
 }
 static_assert(sp17_uj0(0, 3) + sp17_unj(0, 3) == Sp17Geo::NCT0 && sp17_uj0(1, 3) + sp17_unj(1, 3) == Sp17Geo::NCT, "units cover the column tiles");
 
+// Vector-memory instructions a wave issues between the last LDS-DMA piece of the next tile (unit 0, k-step NPIECE) and the barrier of
+// the tile (unit 3, k-step KS - 2) of half h: the stores of the riding epilogues (2 per column tile) and the residual loads (2 per
+// column tile, first slots of a unit).  Mirrors the schedule of k_conv3x3_sp17 below (same constants, same SpSpread).
+template <bool RES, int NCH> __host__ __device__ constexpr int sp17_vm_younger(int h) {
+    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (Sp17Geo::CELLS + 63) / 64, NPIECE = NP * (2 * NCH / 4);
+    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
+    int n = 0;
+    for (int u = 0; u < 4; ++u) {
+        const int nj = sp17_unj(h, u), NQ = 3 * nj;
+        const int ph = u == 0 ? h ^ 1 : h, pu = (u + 3) & 3, pnj = sp17_unj(ph, pu), P_OPS = pnj * CT_OPS;
+        const int AVAIL = (u == 3 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
+        // slot -> cumulative micro-ops (SpSpread::cum with run-time arguments)
+        auto cum = [&](int sl) {
+            if (sl < S0) return 0;
+            const long long c = ((long long)(sl - S0 + 1) * P_OPS + AVAIL - 1) / AVAIL;
+            return c > P_OPS ? P_OPS : (int)c;
+        };
+        for (int c = 0; c < pnj; ++c)
+            for (int st = 0; st < 2; ++st) {  // the two stores of column tile c are its last two micro-ops
+                const int o = c * CT_OPS + CT_OPS - 2 + st;
+                int sl = S0;
+                while (cum(sl) <= o) ++sl;
+                if (u > 0 || sl / NQ > NPIECE) ++n;  // a DMA piece is issued behind all MFMA slots of its k-step
+            }
+        if (RES && u > 0) n += 2 * nj;  // (unit 0 loads its residual in its first slots, before the first piece)
+    }
+    return n;
+}
+
 // NCH = input-channel chunks of 8: 8 = tower layer (64 -> 64), 4 = stem (17 planes padded to 32 -> 64, 13x13 input board at (2, 2)).
 // w: [plane: hi, lo][9 taps][64 couts][8 NCH cin] f16 with lo = (w - hi) * 2^11; bias fp32 [64].
 template <bool RES, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
@@ -136,7 +166,9 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
     constexpr int NP = (G::CELLS + 63) / 64;                 // DMA pieces of 64 cells per strip
     constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips and DMA pieces per wave and tile
     constexpr int NF = 2 * KS;
-    constexpr int E_OPS = RES ? 13 : 9, CT_OPS = 4 * E_OPS + 6;  // epilogue micro-ops per element / per column tile
+    // epilogue micro-ops: per element E1 (join, [residual join, add,] ReLU, range record, clamp), per pair of elements 6 more (packed hi
+    // convert, 2 scalings, 2 remainders, packed lo convert), per column tile 2 stores
+    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert(NF <= 64, "all A fragments live in AGPRs");
     static_assert((4 * KS) % R == 0, "a tile's k-steps keep the ring phase");
@@ -230,40 +262,36 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
             accm[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accc[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             rr[a][j][0] = (cv_u32x2){0u, 0u}, rr[a][j][1] = (cv_u32x2){0u, 0u};
         }
-    float ev = 0.0f, t0 = 0.0f, t1 = 0.0f, mx = 0.0f;  // mx: largest |value| this lane produced (range record)
-    _Float16 hh[4], ll[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) hh[e] = (_Float16)0.0f, ll[e] = (_Float16)0.0f;
-    unsigned pk0 = 0, pk1 = 0;
-    // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`
+    float evv[2] = {0.0f, 0.0f}, sc[2] = {0.0f, 0.0f}, t0 = 0.0f, mx = 0.0f;  // mx: largest |value| this lane produced (range record)
+    unsigned hpk[2] = {0u, 0u}, lpk[2] = {0u, 0u};
+    // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`: ONE VALU / memory instruction
     auto epi_op = [&](int set, int j, int mj, unsigned char* out, int o, bool store_ok) {
-        if (o < 4 * E_OPS) {
-            const int e = o / E_OPS, k = o % E_OPS;
-            const unsigned rh = (e < 2 ? rr[set][j][0].x : rr[set][j][0].y), rl = (e < 2 ? rr[set][j][1].x : rr[set][j][1].y);
-            const int tail = RES ? k - 4 : k;  // ops after the residual part
-            if (k == 0) ev = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
-            else if (RES && k == 1) t0 = (float)((e & 1) ? sp_hi16(rh) : sp_lo16(rh));
-            else if (RES && k == 2) t1 = (float)((e & 1) ? sp_hi16(rl) : sp_lo16(rl));
-            else if (RES && k == 3) t0 = fmaf(t1, SP_INV_SCALE, t0);
-            else if (RES && k == 4) ev = cw_add_f32(ev, t0);
-            else if (tail == 1) ev = fmaxf(ev, lo_relu);
-            else if (tail == 2) mx = fmaxf(mx, __builtin_fabsf(ev));
-            else if (tail == 3) ev = __builtin_amdgcn_fmed3f(ev, -SP_F16_MAX, SP_F16_MAX);
-            else if (tail == 4) hh[e] = (_Float16)ev;
-            else if (tail == 5) t0 = (float)hh[e];
-            else if (tail == 6) t1 = ev - t0;
-            else if (tail == 7) t1 = t1 * SP_SCALE;
-            else if (tail == 8) ll[e] = (_Float16)t1;
+        if (o < 2 * PAIR) {
+            const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
+            if (k < 2 * E1) {
+                const int ei = k / E1, kk = k % E1, e = 2 * pr + ei;
+                const unsigned rh = pr == 0 ? rr[set][j][0].x : rr[set][j][0].y, rl = pr == 0 ? rr[set][j][1].x : rr[set][j][1].y;
+                const int tail = kk - (RES ? 3 : 1);
+                if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
+                else if (RES && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
+                else if (RES && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
+                else if (tail == 0) evv[ei] = fmaxf(evv[ei], lo_relu);
+                else if (tail == 1) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
+                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], -SP_F16_MAX, SP_F16_MAX);                   // ... is clamped here (and recorded)
+            } else {
+                const int kk = k - 2 * E1;
+                if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
+                else if (kk == 1) sc[0] = evv[0] * SP_SCALE;
+                else if (kk == 2) sc[1] = evv[1] * SP_SCALE;
+                else if (kk == 3) sc[0] = sp_mix_rem<0>(hpk[pr], sc[0]);
+                else if (kk == 4) sc[1] = sp_mix_rem<1>(hpk[pr], sc[1]);
+                else lpk[pr] = sp_cvt_pk(sc[0], sc[1]);
+            }
         } else {
-            const int k = o - 4 * E_OPS;
             const unsigned gq = lmap[mj] >> 16;
-            if (k == 0) pk0 = sp_pack(hh[0], hh[1]);
-            else if (k == 1) pk1 = sp_pack(hh[2], hh[3]);
-            else if (k == 2) {
-                if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){pk0, pk1};
-            } else if (k == 3) pk0 = sp_pack(ll[0], ll[1]);
-            else if (k == 4) pk1 = sp_pack(ll[2], ll[3]);
-            else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){pk0, pk1};
+            if (o == 2 * PAIR) {
+                if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){hpk[0], hpk[1]};
+            } else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){lpk[0], lpk[1]};
         }
     };
 
@@ -287,8 +315,11 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
             constexpr int NH = U == 3 ? H ^ 1 : H, NU = (U + 1) & 3;                 // the next unit (the ring runs on into it)
             constexpr int nnj = sp17_unj(NH, NU), nj0 = sp17_uj0(NH, NU);
             constexpr int NQ = 3 * nj, P_OPS = pnj * CT_OPS;                         // MFMAs per k-step; micro-ops of the riding epilogue
-            constexpr int PER = (P_OPS + (NQ * KS - S0 - 4) - 1) / (NQ * KS - S0 - 4);  // micro-ops per MFMA gap
-            static_assert(PER <= (NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
+            // the riders end 4 slots before the unit does; in the tile's last unit they end before the barrier (whose counted wait
+            // knows exactly which vector-memory instructions are younger than the next tile's DMA pieces)
+            constexpr int AVAIL = (U == 3 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
+            typedef SpSpread<P_OPS, S0, AVAIL> SP;
+            static_assert(SP::MAXPER <= (NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
             const unsigned char* Xs = lds + H * LBUF;
             const unsigned char* Xn = lds + (H ^ 1) * LBUF;
             // previous unit's output: the first unit of a board finishes the previous board's lower half
@@ -302,8 +333,13 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                 constexpr int t = decltype(TC)::value;
                 constexpr int g = U * KS + t;  // running k-step of the tile
                 if constexpr (U == 3 && t == KS - (R - 1)) {
-                    // every read of this buffer has been issued; this wave's pieces of the next tile (unit 0) have completed
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // every read of this buffer has been issued.  This wave's pieces of the next tile (unit 0) are older than the
+                    // VM_YOUNGER youngest vector-memory instructions it has issued (residual loads and stores of units 0-3, counted at
+                    // compile time: each is issued unconditionally); those may stay in flight
+                    constexpr int VM_YOUNGER = sp17_vm_younger<RES, NCH>(H);
+                    static_assert(VM_YOUNGER < 63, "vmcnt field");
+                    if (H == 0 && !have_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: the stores riding in its unit 0 were skipped
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");
                     CV_BARRIER();
                 }
                 if constexpr (t + R - 1 < KS) load_step(Xs, j0, nj, t + R - 1, (g + R - 1) % R);
@@ -323,9 +359,9 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                     }
                     constexpr int sl = t * NQ + q;  // MFMA slot of the unit
                     cp_for_each([&](auto KC) __attribute__((always_inline)) {
-                        constexpr int o = (sl - S0) * PER + decltype(KC)::value;
-                        if constexpr (sl >= S0 && o < P_OPS) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
-                    }, typename CpMakeSeq<PER>::type{});
+                        constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
+                        if constexpr (o < SP::cum(sl)) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
+                    }, typename CpMakeSeq<SP::MAXPER>::type{});
                     if constexpr (RES && sl < 2 * nj) {  // this unit's residual (used by its epilogue inside the next unit)
                         constexpr int rj = sl >> 1, rp = sl & 1;
                         rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * YPLANE + (lmap[j0 + rj] >> 16));

@@ -245,11 +245,11 @@ int launch_head_tiled(const void* x, const float* w, const float* bias, void* po
     if (C % 8 || C > 1024 || npol + nval != 3) return 1;
     const long long npos = boards * S * S;
     if (f16)
-        hipLaunchKernelGGL((k_head_tiled<3, true>), dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
+        hipLaunchKernelGGL((k_head_tiled<3, true>), dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, (hipStream_t)st,
                            (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S,
                            cv_tile_boards(S) * S * S, pol_stride, val_stride);
     else
-        hipLaunchKernelGGL((k_head_tiled<3>), dim3((unsigned)((npos + 255) / 256)), dim3(256), 3 * C * sizeof(float), (hipStream_t)st,
+        hipLaunchKernelGGL((k_head_tiled<3>), dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, (hipStream_t)st,
                            (const unsigned char*)x, w, bias, (unsigned short*)pol, (unsigned short*)val, npos, npol, C, S * S,
                            cv_tile_boards(S) * S * S, pol_stride, val_stride);
     return AZ_HIP(hipGetLastError());

@@ -321,14 +321,17 @@ def tower_roofline(conv, args, step_ms):
     if split:
         cname = "split_kernel_pmc.json" if S_t == 9 else "split17_kernel_pmc.json"
     else:
-        cname = "block64_kernel_pmc.json" if fused else ("conv_kernel_pmc.json" if (S_t == 9 and args.filters == 128) else "conv64_kernel_pmc.json")
+        cname = "block64_kernel_pmc.json" if fused else {(9, 128): "conv_kernel_pmc.json", (19, 256): "conv19_kernel_pmc.json"}.get((S_t, args.filters), "conv64_kernel_pmc.json")
     ctraffic, csrc = None, None
     cprof = os.path.join(ROOT, "profiles", cname)
     if os.path.exists(cprof):
         try:
             pj = json.load(open(cprof))
-            if pj.get("rows") == rows and pj.get("board") == n and pj.get("channels") == args.filters:
-                ctraffic, csrc = pj.get("hbm_bytes_per_launch"), "from_profiles: profiles/" + cname + " (separate rocprofv3 --pmc pass, not this run)"
+            if pj.get("board") == n and pj.get("channels") == args.filters and pj.get("rows"):
+                # per-launch bytes scale with the boards of a launch (every board is read / written once): a pass at another batch
+                # size is scaled linearly and labelled
+                ctraffic = round(pj["hbm_bytes_per_launch"] * rows / pj["rows"])
+                csrc = "from_profiles: profiles/" + cname + " (separate rocprofv3 --pmc pass, not this run" + ("" if pj["rows"] == rows else f"; measured at {pj['rows']} boards per launch, scaled linearly to {rows}") + ")"
         except Exception:
             ctraffic = None
     if split:

@@ -315,7 +315,7 @@ def test_gpu_gomoku13_selfplay_fp32_class_evaluator_same_seed_same_stream():
                             engine_kw={"max_steps": 40})
         assert "split-precision" in act.evaluator_path and "hand-written" in act.evaluator_path, act.evaluator_path
         out = []
-        for _ in range(6):
+        for _ in range(8):  # 64 simulations / P = 8: ~9 rounds per move, games of <= 40 plies: most slots finish a game within 480 rounds
             act.run_rounds(60)
             st, pi, z, games = act.harvest_tensors(clone=True)
             out.append((st.cpu(), pi.cpu(), z.cpu(), games.copy()))
@@ -323,7 +323,7 @@ def test_gpu_gomoku13_selfplay_fp32_class_evaluator_same_seed_same_stream():
         streams.append((out, act.counters()))
         del act
     (a, ca), (b, cb) = streams
-    assert ca == cb and sum(len(g) for *_, g in a) > 300
+    assert ca == cb and sum(len(g) for *_, g in a) > 150
     for (s0, p0, z0, g0), (s1, p1, z1, g1) in zip(a, b):
         assert torch.equal(s0, s1) and torch.equal(p0, p1) and torch.equal(z0, z1) and np.array_equal(g0, g1)
         assert torch.allclose(p0.sum(1), torch.ones(len(p0)), atol=1e-4)

@@ -530,3 +530,62 @@ def test_gpu_fc_heads_match_torch(boards, P2, A, Fw):
     from alpha_zero_amd import _lib
 
     _fc_heads_check(_lib.load(), boards, P2, A, Fw, "cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float32"])
+def test_gpu_two_forwards_in_flight_on_two_streams_equal_the_serial_results(dtype_name):
+    """Two evaluator forwards of one InferenceNet in flight at the same time on two HIP streams (different scratch slots) give, bit for
+    bit, the results of the same forwards run one after the other -- 30 rounds, batches large enough that the two forwards really
+    overlap on the device (~4.6 k rows each: every tower launch fills all CUs).  Round 3 saw the head planes of the forward launched
+    first differ in 36 of 40 such rounds; round 4 traced it to the head kernel's LDS weight table (tools/probes/make_head_probe.py,
+    profiles/r04_concurrency_probe2_*.txt) and removed the table (az_conv.h k_head_tiled).  The fp32-class path (whose head kernel keeps
+    its planes in LDS by design) is run through the same check."""
+    import json
+    import os
+
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    dt = getattr(torch, dtype_name)
+    torch.manual_seed(2)
+    net = AlphaZeroNet((17, 9, 9), 82, 3, 128, 128).eval()
+    inf = InferenceNet(net, dtype=dt, binding=_lib.load()).cuda()
+    rows = (4608, 4863)
+    g = torch.Generator().manual_seed(7)
+    planes = [(torch.rand(r, 17, 9, 9, generator=g) > 0.6).float() for r in rows]
+    if dt == torch.float32:
+        assert inf.supports_split_features(9, "cuda")
+        feats = [p.cuda().contiguous() for p in planes]
+        fwd = lambda k: inf.forward_split(feats[k], slot=1 + k)  # noqa: E731
+    else:
+        assert inf.supports_tiled_features(9, "cuda")
+        feats = [eu.tile_features(p).cuda() for p in planes]
+
+        def fwd(k):
+            pri, v = inf.forward_tiled(feats[k], rows[k], 9, slot=1 + k)
+            return pri.clone(), v.clone()
+
+    serial = []
+    for k in range(2):
+        serial.append(fwd(k))
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    main = torch.cuda.current_stream()
+    bad = []
+    for r in range(30):
+        out = [None, None]
+        for k in range(2):
+            streams[k].wait_stream(main)
+            with torch.cuda.stream(streams[k]):
+                out[k] = fwd(k)
+        for s in streams:
+            main.wait_stream(s)
+        torch.cuda.synchronize()
+        for k in range(2):
+            if not (torch.equal(out[k][0], serial[k][0]) and torch.equal(out[k][1], serial[k][1])):
+                bad.append((r, k, float((out[k][0] - serial[k][0]).abs().max()), float((out[k][1] - serial[k][1]).abs().max())))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(dict(dtype=dtype_name, rounds=30, rows=rows, differing=bad), open(os.path.join(root, "gpurun_out", f"two_stream_forwards_{dtype_name}.json"), "w"))
+    assert not bad, bad[:5]

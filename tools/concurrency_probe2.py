@@ -74,3 +74,17 @@ for r in range(40):
                 found.setdefault((k, name), []).append((r, int(nz.numel()), nz[:8].tolist(), float(d.max())))
                 break
 print("first differing stage per (half, stage) over 40 rounds:", {k: (len(v), v[:3]) for k, v in found.items()} or "none", flush=True)
+# where the differing head-plane elements sit: (row of the head buffer = board, column = plane * P2 + position) -> head workgroup = flat position // 256
+for (k, name), v in found.items():
+    if name in ("pol", "val"):
+        pol, val, _, _ = inf._head_buffers((act._halves[k][1] - act._halves[k][0]) * e.P, inf.fc_wp.shape[1], inf.fc_w1.shape[1], e.features.device, 1 + k)
+        width = (pol if name == "pol" else val).shape[1]
+        for r, cnt, idx, dmax in v[:6]:
+            print(f"  half {k} {name} round {r}: {cnt} elements, first (board, column): {[(i // width, i % width) for i in idx]}, max |d| {dmax}")
+dll = act.binding.dll
+if hasattr(dll, "azsp_probe_head_dbg"):
+    import ctypes
+
+    out = (ctypes.c_uint32 * 4)()
+    assert dll.azsp_probe_head_dbg(out, 0) == 0
+    print("head probe record: LDS weight mismatches", out[0], " threads whose second read gave other planes", out[1], " threads checked", out[2], flush=True)

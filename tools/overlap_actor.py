@@ -26,6 +26,7 @@ from alpha_zero_amd.core.pipeline import SelfPlayActor  # noqa: E402
 
 class OverlapActor(SelfPlayActor):
     def __init__(self, network, *a, overlap=True, one_stream=False, **kw):
+        kw.setdefault("net_dtype", torch.bfloat16)  # the experiment is about the tiled bf16 evaluator (SelfPlayActor's own default is fp32)
         super().__init__(network, *a, **kw)
         self._halves, self._streams, self._hgraphs, self._forked = None, None, [None, None], False
         self.overlap = False

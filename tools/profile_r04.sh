@@ -17,13 +17,9 @@ for FAM in ${PMC_FAMILIES:-split9 split17 tiled9 hb19}; do
     python - "$(find /tmp/pb -name '*.db' | head -1)" >> $O/pmc_$FAM.txt 2>&1 <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-# per dispatch (in launch order) so that plain / residual launches can be told apart
-rows = list(db.execute("select kernel_name, counter_name, value from counters_collection where kernel_name like '%conv3x3%' order by rowid"))
-agg = {}
-for k, c, v in rows:
-    agg.setdefault((k[:70], c), []).append(v)
-for (k, c), v in agg.items():
-    print("  ", k, c, "n=%d" % len(v), "mean=%.6g" % (sum(v) / len(v)), "per-dispatch:", " ".join("%.6g" % x for x in v[:12]))
+# one row per kernel (the plain and the residual variant are different template instantiations) and counter: dispatches, mean per dispatch
+for r in db.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) from counters_collection where kernel_name like '%conv3x3%' group by kernel_name, counter_name"):
+    print("  ", r[0][:70], r[1], "n=%d" % r[2], "mean=%.6g min=%.6g max=%.6g" % (r[3], r[4], r[5]))
 PY
   done
   cat $O/pmc_$FAM.txt | cut -c1-260

@@ -12,6 +12,10 @@ from alpha_zero_amd import _lib
 from alpha_zero_amd.core.network import split_weights_f16
 
 b = _lib.load()
+if os.environ.get("AZ_BENCH_LIB"):  # an alternative build of the library (same-box A/B of two kernel versions)
+    from alpha_zero_amd import _abi
+
+    b = _abi.Binding(ctypes.CDLL(os.environ["AZ_BENCH_LIB"]), "A/B build")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 S, C = (int(v) for v in os.environ.get("CONV_BENCH_SHAPE", "9,128").split(","))
 g = torch.Generator().manual_seed(0)
