@@ -96,8 +96,9 @@ def test_gpu_f16_conv3x3_matches_torch(boards):
 def test_gpu_f16_evaluator_vs_fp32_and_bf16():
     """The whole 10 x 128 evaluator on the f16 variants against the fp32 module, with the bf16 kernels beside it on the same
     positions (a sharp random-init network: every path's error is amplified through the 10 blocks).  Measured on MI355X (r03): f16
-    max |dprior| 0.0080, |dvalue| 0.0074, arg-max agreement 100 %; bf16 0.0625 / 0.093 / 98.3 %.  Bound: f16 within 1.5e-2 and at most
-    0.3 x the bf16 distance."""
+    max |dprior| 0.0080, |dvalue| 0.0074, arg-max agreement 100 %; bf16 0.0625 / 0.093 / 98.3 %.  The hand-written kernels pick no
+    algorithm at run time and the checker is the fp32 module on the CPU, so these numbers are the same on every box (two boxes:
+    profiles/r04_bounds_two_boxes.txt).  Bound = measured + 25 %: f16 within 1.0e-2, and at most 0.3 x the bf16 distance."""
     import engine_util as eu
     from alpha_zero_amd import _lib
 
@@ -115,7 +116,7 @@ def test_gpu_f16_evaluator_vs_fp32_and_bf16():
     print(json.dumps(out))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "f16_evaluator_error.json"), "w"))
-    assert out["f16"][0] <= 1.5e-2 and out["f16"][1] <= 1.5e-2, out
+    assert out["f16"][0] <= 1.0e-2 and out["f16"][1] <= 1.0e-2, out
     assert out["f16"][0] <= 0.3 * out["bf16"][0] and out["f16"][1] <= 0.3 * out["bf16"][1], out
 
 

@@ -157,8 +157,10 @@ def test_gpu_split_conv_error_vs_fp64(boards, C):
     """k_conv3x3_sp vs fp64, next to the library's fp32 convolution on the same inputs.  Board counts around one / two boards per
     workgroup slot (128 slots at 128 filters, 256 at 64) exercise the first-board, has-next and last-board paths of the persistent loop;
     the two large counts give every workgroup 17 boards + some an 18th: a full 16-board corner group followed by a partial one.
-    Bound: max |y - y64| <= 2e-6 max|y64| and at most 2x the library's own fp32 error + 5e-7 (measured on MI355X over the 48 cases,
-    profiles/r03_split_conv_error.jsonl: kernel max 6.5e-7 / mean 4.6e-7, library fp32 max 8.8e-7 / mean 5.6e-7)."""
+    Bound: the kernel picks no algorithm at run time, so its error is the same on every box -- measured max 6.49e-7 of max|y64| on the boxes
+    of rounds 3 and 4 (profiles/r03_split_conv_error.jsonl, profiles/r04_bounds_two_boxes.txt) -- and is asserted ABSOLUTELY: <= 8e-7.
+    The library's own fp32 error on the same inputs is recorded beside it (2.7e-7 .. 8.8e-7 depending on the case and on the algorithm
+    MIOpen picks on that box); round 3's bound "<= 2 x library + 5e-7" made the test depend on that choice and is gone."""
     from alpha_zero_amd import _lib
 
     bnd = _lib.load()
@@ -182,7 +184,7 @@ def test_gpu_split_conv_error_vs_fp64(boards, C):
             f.write(json.dumps(o) + "\n")
     for o in out:
         assert o["layout_roundtrip_rel"] <= 2.0 ** -21, o
-        assert o["err"] <= 2e-6 and o["err"] <= 2 * o["library_fp32_err"] + 5e-7, o
+        assert o["err"] <= 8e-7, o
 
 
 @pytest.mark.gpu
@@ -319,8 +321,9 @@ def test_gpu_split_stem_and_heads_vs_fp64(boards):
 def test_gpu_split_conv17_error_vs_fp64(boards):
     """k_conv3x3_sp17 (17x17 planes x 64 filters: the 13x13 Gomoku tower, half-board tiles) vs fp64, next to the library's fp32
     convolution.  Board counts around one / two / four boards per workgroup (256 persistent workgroups) exercise the first-board,
-    has-next and last-board paths of the two-tiles-per-board loop.  Same bound as the 9x9 kernel: max |y - y64| <= 2e-6 max|y64| and
-    at most 2x the library's own fp32 error + 5e-7."""
+    has-next and last-board paths of the two-tiles-per-board loop.  Bound: absolute, like the 9x9 kernel's (the kernel's error does
+    not depend on the box): measured max 4.45e-7 of max|y64| (profiles/r04_split_conv17_error.jsonl), asserted <= 6e-7; the library's own
+    fp32 error (up to 7.1e-7 here) is recorded beside it."""
     from alpha_zero_amd import _lib
 
     bnd = _lib.load()
@@ -346,7 +349,7 @@ def test_gpu_split_conv17_error_vs_fp64(boards):
             f.write(json.dumps(o) + "\n")
     for o in out:
         assert o["layout_roundtrip_rel"] <= 2.0 ** -21, o
-        assert o["err"] <= 2e-6 and o["err"] <= 2 * o["library_fp32_err"] + 5e-7, o
+        assert o["err"] <= 6e-7, o
 
 
 @pytest.mark.gpu
