@@ -223,23 +223,23 @@ k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst,
 //   head planes  hp[pl][pos] = relu(sum_c hw[pl][c] x[c][pos] + hb[pl])      (the two 1x1 convolutions, BatchNorm folded; pl < 3)
 //   priors = softmax(Wp flatten(hp[0 .. npol)) + bp)       value = tanh(w2 . relu(W1 flatten(hp[npol .. 3)) + b1) + b2)
 // BPB boards per 256-thread workgroup (the fully connected weights, stored TRANSPOSED [inputs][outputs] so that neighbouring threads
-// read neighbouring outputs, are streamed from L2 once per BPB boards); plain fp32 FMAs -- HBM-bound (2 x C x P2 x 2 bytes per board).
+// read neighbouring outputs, are streamed from L2 once per BPB boards: BPB = 4 at 9x9, 8 at 17x17 where the policy matrix is 390 KB --
+// rocprofv3, round 4: 1.15 ms per forward at BPB = 4, 4.5 % of a 13x13 Gomoku step); plain fp32 FMAs -- HBM-bound (2 x C x P2 x 2 bytes per board).
 // dynamic LDS: 3 C + BPB (3 P2 + A + F) floats.
-#define SP_HEAD_BPB 4
-__global__ void __launch_bounds__(256)
+template <int BPB> __global__ void __launch_bounds__(256)
 k_head_split(const unsigned char* __restrict__ x, const float* __restrict__ hw, const float* __restrict__ hb, const float* __restrict__ wp_t,
              const float* __restrict__ bp, const float* __restrict__ w1_t, const float* __restrict__ b1, const float* __restrict__ w2, float b2,
              float* __restrict__ priors, float* __restrict__ values, long long boards, int C, int P2, int A, int F, int npol) {
     extern __shared__ float sm[];
     float* ws = sm;                                  // [3][C]
     float* hp = ws + 3 * C;                          // [BPB][3 P2]
-    float* out = hp + SP_HEAD_BPB * 3 * P2;          // [BPB][A + F]
+    float* out = hp + BPB * 3 * P2;                  // [BPB][A + F]
     const int tid = threadIdx.x, nch = C / 8;
-    const long long b0 = (long long)blockIdx.x * SP_HEAD_BPB;
+    const long long b0 = (long long)blockIdx.x * BPB;
     for (int i = tid; i < 3 * C; i += 256) ws[i] = hw[i];
     __syncthreads();
     const size_t plane = (size_t)nch * P2 * 16;
-    for (int it = tid; it < SP_HEAD_BPB * 3 * P2; it += 256) {
+    for (int it = tid; it < BPB * 3 * P2; it += 256) {
         const int b = it / (3 * P2), r = it - b * 3 * P2, pl = r / P2, pos = r - pl * P2;
         float acc = 0.0f;
         if (b0 + b < boards) {
@@ -263,43 +263,44 @@ k_head_split(const unsigned char* __restrict__ x, const float* __restrict__ hw, 
     __syncthreads();
     const int kp = npol * P2, kv = (3 - npol) * P2;
     for (int o = tid; o < A + F; o += 256) {
-        float acc[SP_HEAD_BPB];
+        float acc[BPB];
         const bool pol = o < A;
         const float* wcol = pol ? wp_t + o : w1_t + (o - A);
         const int ld = pol ? A : F, kn = pol ? kp : kv, k0 = pol ? 0 : kp;
         const float bias0 = pol ? bp[o] : b1[o - A];
 #pragma unroll
-        for (int b = 0; b < SP_HEAD_BPB; ++b) acc[b] = bias0;
+        for (int b = 0; b < BPB; ++b) acc[b] = bias0;
         for (int k = 0; k < kn; ++k) {
             const float wv = wcol[(size_t)k * ld];
 #pragma unroll
-            for (int b = 0; b < SP_HEAD_BPB; ++b) acc[b] = fmaf(hp[b * 3 * P2 + k0 + k], wv, acc[b]);
+            for (int b = 0; b < BPB; ++b) acc[b] = fmaf(hp[b * 3 * P2 + k0 + k], wv, acc[b]);
         }
 #pragma unroll
-        for (int b = 0; b < SP_HEAD_BPB; ++b) out[b * (A + F) + o] = pol ? acc[b] : fmaxf(acc[b], 0.0f);
+        for (int b = 0; b < BPB; ++b) out[b * (A + F) + o] = pol ? acc[b] : fmaxf(acc[b], 0.0f);
     }
     __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;  // wave w finishes board b0 + w (4 waves = SP_HEAD_BPB boards)
-    if (b0 + wave >= boards) return;
-    const float* o = out + wave * (A + F);
-    float mx = -__builtin_inff();
-    for (int a = lane; a < A; a += 64) mx = fmaxf(mx, o[a]);
+    const int wave = tid >> 6, lane = tid & 63;  // wave w finishes boards b0 + w, b0 + w + 4, ...
+    for (int bb = wave; bb < BPB; bb += 4) {
+        if (b0 + bb >= boards) break;
+        const float* o = out + bb * (A + F);
+        float mx = -__builtin_inff();
+        for (int a = lane; a < A; a += 64) mx = fmaxf(mx, o[a]);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
-    float sum = 0.0f;
-    for (int a = lane; a < A; a += 64) sum += expf(o[a] - mx);
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+        float sum = 0.0f;
+        for (int a = lane; a < A; a += 64) sum += expf(o[a] - mx);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    const float inv = 1.0f / sum;
-    float* prow = priors + (size_t)(b0 + wave) * A;
-    for (int a = lane; a < A; a += 64) prow[a] = expf(o[a] - mx) * inv;
-    float v = 0.0f;
-    for (int f = lane; f < F; f += 64) v = fmaf(o[A + f], w2[f], v);
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        const float inv = 1.0f / sum;
+        float* prow = priors + (size_t)(b0 + bb) * A;
+        for (int a = lane; a < A; a += 64) prow[a] = expf(o[a] - mx) * inv;
+        float v = 0.0f;
+        for (int f = lane; f < F; f += 64) v = fmaf(o[A + f], w2[f], v);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    if (lane == 0) values[b0 + wave] = tanhf(v + b2);
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0) values[b0 + bb] = tanhf(v + b2);
+    }
 }
-static_assert(SP_HEAD_BPB == 4, "one wave per board in the last phase of k_head_split");
 
 // first MFMA of an accumulator that starts from zero: the C operand is the inline constant 0 (no zeroed registers to keep)
 __device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, const sp_f16x8& b) {

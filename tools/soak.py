@@ -14,7 +14,7 @@ from alpha_zero_amd.core.pipeline import SelfPlayActor
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 game, n, G = (sys.argv[2] if len(sys.argv) > 2 else "go"), int(sys.argv[3]) if len(sys.argv) > 3 else 9, int(sys.argv[4]) if len(sys.argv) > 4 else 4096
-DT = {"bf16": torch.bfloat16, "fp32": torch.float32}[sys.argv[5] if len(sys.argv) > 5 else "bf16"]  # fp32: the split-precision evaluator where the shape has it
+DT = {"bf16": torch.bfloat16, "fp32": torch.float32}[sys.argv[5] if len(sys.argv) > 5 else "fp32"]  # fp32: the split-precision evaluator where the shape has it
 A = n * n + (1 if game == "go" else 0)
 torch.manual_seed(1)
 net = AlphaZeroNet((17, n, n), A, 10 if game == "go" else 6, 128 if game == "go" else 64, 128 if game == "go" else 64, gomoku=(game != "go"))
@@ -47,4 +47,4 @@ cnt = actor.counters()
 dt = time.time() - t0
 print(json.dumps(dict(evaluator=actor.evaluator_path, rounds=rounds, seconds=round(dt, 1), games=games, samples=samples, mean_len=round(float(np.mean(lens)), 1) if lens else None,
                       winners=results, moves=cnt["moves"], moves_per_s=round(cnt["moves"] / dt, 1), sims_per_move=round(cnt["sims"] / max(1, cnt["moves"]), 1),
-                      stalls=cnt["stalls"], dup_leaves=cnt["dup_leaves"], terminal_hits=cnt["terminal_hits"])))
+                      stalls=cnt["stalls"], dup_leaves=cnt["dup_leaves"], terminal_hits=cnt["terminal_hits"], range_events=actor.range_events)))
