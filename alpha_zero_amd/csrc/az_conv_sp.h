@@ -223,57 +223,88 @@ k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst,
 //   head planes  hp[pl][pos] = relu(sum_c hw[pl][c] x[c][pos] + hb[pl])      (the two 1x1 convolutions, BatchNorm folded; pl < 3)
 //   priors = softmax(Wp flatten(hp[0 .. npol)) + bp)       value = tanh(w2 . relu(W1 flatten(hp[npol .. 3)) + b1) + b2)
 // BPB boards per 256-thread workgroup (the fully connected weights, stored TRANSPOSED [inputs][outputs] so that neighbouring threads
-// read neighbouring outputs, are streamed from L2 once per BPB boards: BPB = 4 at 9x9, 8 at 17x17 where the policy matrix is 390 KB --
-// rocprofv3, round 4: 1.15 ms per forward at BPB = 4, 4.5 % of a 13x13 Gomoku step); plain fp32 FMAs -- HBM-bound (2 x C x P2 x 2 bytes per board).
-// dynamic LDS: 3 C + BPB (3 P2 + A + F) floats.
+// read neighbouring outputs, are streamed from L2 once per BPB boards; BPB = 8 was measured SLOWER than 4 at 17x17 (1.77 vs 1.15 ms:
+// fewer, longer workgroups -- the fully connected loop is latency-bound, not traffic-bound); plain fp32 FMAs -- HBM-bound (2 x C x P2 x 2 bytes per board).
+// dynamic LDS: 3 C + BPB (3 ceil4(P2) + A + F) floats.
 template <int BPB> __global__ void __launch_bounds__(256)
 k_head_split(const unsigned char* __restrict__ x, const float* __restrict__ hw, const float* __restrict__ hb, const float* __restrict__ wp_t,
              const float* __restrict__ bp, const float* __restrict__ w1_t, const float* __restrict__ b1, const float* __restrict__ w2, float b2,
              float* __restrict__ priors, float* __restrict__ values, long long boards, int C, int P2, int A, int F, int npol) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int P2P = (P2 + 3) & ~3;                   // a head plane's row in LDS, padded to 16 bytes: the fully connected loop reads float4s
     float* ws = sm;                                  // [3][C]
-    float* hp = ws + 3 * C;                          // [BPB][3 P2]
-    float* out = hp + BPB * 3 * P2;                  // [BPB][A + F]
+    float* hp = ws + 3 * C;                          // [BPB][3][P2P]
+    float* out = hp + BPB * 3 * P2P;                 // [BPB][A + F]
     const int tid = threadIdx.x, nch = C / 8;
     const long long b0 = (long long)blockIdx.x * BPB;
     for (int i = tid; i < 3 * C; i += 256) ws[i] = hw[i];
     __syncthreads();
     const size_t plane = (size_t)nch * P2 * 16;
-    for (int it = tid; it < BPB * 3 * P2; it += 256) {
-        const int b = it / (3 * P2), r = it - b * 3 * P2, pl = r / P2, pos = r - pl * P2;
-        float acc = 0.0f;
+    // head planes: one thread per (board, position) computes all three planes from ONE pass over the position's C channels (the first
+    // version walked (board, plane, position) items and read every activation three times: 1.13 ms per forward at 17x17, rocprofv3 round 4)
+    for (int it = tid; it < BPB * P2; it += 256) {
+        const int b = it / P2, pos = it - b * P2;
+        float acc[3] = {0.0f, 0.0f, 0.0f};
         if (b0 + b < boards) {
-            acc = hb[pl];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) acc[pl] = hb[pl];
             const unsigned char* src = x + (size_t)(b0 + b) * 2 * plane + (size_t)pos * 16;
-            const float* wr = ws + pl * C;
 #pragma unroll 4
             for (int c = 0; c < nch; ++c) {
                 const cv_u32x4 h = *(const cv_u32x4*)(src + (size_t)c * P2 * 16), l = *(const cv_u32x4*)(src + (size_t)c * P2 * 16 + plane);
                 const unsigned hv[4] = {h.x, h.y, h.z, h.w}, lv[4] = {l.x, l.y, l.z, l.w};
+                float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc = fmaf(sp_join(sp_lo16(hv[e]), sp_lo16(lv[e])), wr[c * 8 + 2 * e], acc);
-                    acc = fmaf(sp_join(sp_hi16(hv[e]), sp_hi16(lv[e])), wr[c * 8 + 2 * e + 1], acc);
+                    v[2 * e] = sp_join(sp_lo16(hv[e]), sp_lo16(lv[e]));
+                    v[2 * e + 1] = sp_join(sp_hi16(hv[e]), sp_hi16(lv[e]));
                 }
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[pl] = fmaf(v[e], ws[pl * C + c * 8 + e], acc[pl]);
             }
-            acc = fmaxf(acc, 0.0f);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) acc[pl] = fmaxf(acc[pl], 0.0f);
         }
-        hp[it] = acc;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) hp[(b * 3 + pl) * P2P + pos] = acc[pl];
     }
     __syncthreads();
-    const int kp = npol * P2, kv = (3 - npol) * P2;
+    // Fully connected layers: thread o = one output neuron for the BPB boards.  Inputs in nn.Flatten order k = plane * P2 + position; the
+    // accumulation order of every output is k ascending (as a plain loop over k).  The head planes are read as float4 (one broadcast
+    // ds_read_b128 per board and 4 inputs): with one ds_read_b32 per input the loop was bound by LDS instruction issue (rocprofv3, round 4:
+    // 1.15 ms per forward at 17x17, 0.39 ms at 9x9 -- 2312 / 648 LDS instructions per thread and board group).
     for (int o = tid; o < A + F; o += 256) {
         float acc[BPB];
         const bool pol = o < A;
         const float* wcol = pol ? wp_t + o : w1_t + (o - A);
-        const int ld = pol ? A : F, kn = pol ? kp : kv, k0 = pol ? 0 : kp;
+        const int ld = pol ? A : F, pl0 = pol ? 0 : npol, pl1 = pol ? npol : 3;
         const float bias0 = pol ? bp[o] : b1[o - A];
 #pragma unroll
         for (int b = 0; b < BPB; ++b) acc[b] = bias0;
-        for (int k = 0; k < kn; ++k) {
-            const float wv = wcol[(size_t)k * ld];
+        for (int pl = pl0; pl < pl1; ++pl) {
+            const float* wpl = wcol + (size_t)(pl - pl0) * P2 * ld;
+            const float* hpl = hp + pl * P2P;
+            int pos = 0;
+            for (; pos + 8 <= P2; pos += 8) {
+                float wv[8];
 #pragma unroll
-            for (int b = 0; b < BPB; ++b) acc[b] = fmaf(hp[b * 3 * P2 + k0 + k], wv, acc[b]);
+                for (int u = 0; u < 8; ++u) wv[u] = wpl[(size_t)(pos + u) * ld];
+#pragma unroll
+                for (int b = 0; b < BPB; ++b) {
+                    const c6_f32x4 h0 = *(const c6_f32x4*)(hpl + b * 3 * P2P + pos), h1 = *(const c6_f32x4*)(hpl + b * 3 * P2P + pos + 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[b] = fmaf(h0[u], wv[u], acc[b]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[b] = fmaf(h1[u], wv[4 + u], acc[b]);
+                }
+            }
+            for (; pos < P2; ++pos) {
+                const float wv = wpl[(size_t)pos * ld];
+#pragma unroll
+                for (int b = 0; b < BPB; ++b) acc[b] = fmaf(hpl[b * 3 * P2P + pos], wv, acc[b]);
+            }
         }
 #pragma unroll
         for (int b = 0; b < BPB; ++b) out[b * (A + F) + o] = pol ? acc[b] : fmaxf(acc[b], 0.0f);

@@ -333,7 +333,7 @@ int split_range_status(unsigned out[2], int reset, void* st) {
 }
 template <int BPB> static int launch_head_split_bpb(const HeadSplitArgs& a, void* st) {
     const int P2 = a.S * a.S;
-    const size_t lds = (size_t)(3 * a.C + BPB * (3 * P2 + a.A + a.F)) * sizeof(float);
+    const size_t lds = (size_t)(3 * a.C + BPB * (3 * ((P2 + 3) & ~3) + a.A + a.F)) * sizeof(float);
     if (lds > 64 * 1024) return 1;
     hipLaunchKernelGGL((k_head_split<BPB>), dim3((unsigned)((a.boards + BPB - 1) / BPB)), dim3(256), lds, (hipStream_t)st, (const unsigned char*)a.x, a.hw,
                        a.hb, a.wp_t, a.bp, a.w1_t, a.b1, a.w2, a.b2, a.priors, a.values, a.boards, a.C, P2, a.A, a.F, a.npol);
@@ -341,10 +341,6 @@ template <int BPB> static int launch_head_split_bpb(const HeadSplitArgs& a, void
 }
 int launch_head_split(const HeadSplitArgs& a, void* st) {
     if (a.C % 8 || a.npol < 1 || a.npol > 2) return 1;
-    // boards per workgroup: the fully connected weights are streamed once per workgroup -- 8 boards where the planes are large (17x17:
-    // 390 KB of policy weights) and the LDS budget allows, else 4
-    const int P2 = a.S * a.S;
-    if (P2 > 128 && (size_t)(3 * a.C + 8 * (3 * P2 + a.A + a.F)) * sizeof(float) <= 64 * 1024) return launch_head_split_bpb<8>(a, st);
-    return launch_head_split_bpb<4>(a, st);
+    return launch_head_split_bpb<4>(a, st);  // (8 boards per workgroup: measured slower, see k_head_split)
 }
 }  // namespace azb
