@@ -95,6 +95,29 @@ def widen_network(net: "AlphaZeroNet", num_filters: int) -> "AlphaZeroNet":
 
 F16_MAX = 65504.0
 
+# tower widths with hand-written evaluator kernels per (board size, stem padding); dtype class "fp32" = the split-precision kernels,
+# "lowp" = the bf16 / f16 tiled kernels (see InferenceNet.supports_split_features / supports_tiled_features)
+KERNEL_WIDTHS = {"fp32": {(9, 1): (64, 128), (13, 3): (64,)}, "lowp": {(9, 1): (64, 128), (13, 3): (64,), (19, 1): (256,)}}
+
+
+def widen_for_kernels(net: "AlphaZeroNet", board_size: int, dtype):
+    """The network to hand to InferenceNet so that its evaluation runs on hand-written kernels: `net` itself when its filter count has
+    kernels for this board (or none could help), else a function-preserving widened copy (widen_network: zero-weight extra channels,
+    identity BatchNorm -- exactly the same function) at the next supported width.  This is how the reference's shipped networks of other
+    widths (13x13 Gomoku: 10 x 40, training_gomoku.py:37-38) reach the kernels by default instead of the library fallback; the price is
+    the extra FLOPs of the wider tower (40 -> 64: 2.56x), still 1.7x faster than the library's fp32 convolutions at the true width.
+    Returns (network, note) with note = '' or a description for `evaluator_path`."""
+    cls = "fp32" if dtype == torch.float32 else "lowp"
+    pad = net.conv_block[0].padding[0]
+    widths = KERNEL_WIDTHS[cls].get((board_size, pad), ())
+    f = net.conv_block[0].out_channels
+    if dtype == torch.float16:  # the f16 variants exist for the 9x9 x 128 evaluator with 82 actions and 128 fully connected units only
+        return net, ""
+    if f in widths or not widths or f > max(widths):
+        return net, ""
+    w = min(v for v in widths if v >= f)
+    return widen_network(net, w), f" (network widened {f} -> {w} filters, function-preserving)"
+
 
 def split_weights_f16(w):
     """Convolution weights [Cout,Cin,3,3] fp32 -> the packing of the split-precision kernels (include/azsp.h, azsp_conv3x3_split):

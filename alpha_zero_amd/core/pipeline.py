@@ -45,7 +45,7 @@ import torch  # noqa: E402
 
 from .. import _abi  # noqa: E402
 from .engine import Engine, EngineConfig  # noqa: E402
-from .network import AlphaZeroNet, InferenceNet  # noqa: E402
+from .network import AlphaZeroNet, InferenceNet, widen_for_kernels  # noqa: E402
 from .replay import Transition  # noqa: E402
 
 _FEAT_OF = {torch.float32: _abi.FEAT_F32, torch.bfloat16: _abi.FEAT_BF16, torch.float16: _abi.FEAT_F16}
@@ -74,10 +74,13 @@ class SelfPlayActor:
         self.game, self.komi, self.resign_threshold = game, komi, resign_threshold
         self.net_dtype = net_dtype
         self.use_graph = use_graph and self.device.type == "cuda"
-        probe = InferenceNet(network, dtype=net_dtype, binding=self.binding if self.device.type == "cuda" else None)
+        self.auto_widen = self.device.type == "cuda"  # widths without kernels run function-preservingly widened (network.widen_for_kernels)
+        self.board_size = board_size
+        wnet, self._widen_note = widen_for_kernels(network, board_size, net_dtype) if self.auto_widen else (network, "")
+        probe = InferenceNet(wnet, dtype=net_dtype, binding=self.binding if self.device.type == "cuda" else None)
         self.tiled_features = probe.supports_tiled_features(board_size, self.device) if tiled_features is None else bool(tiled_features)
-        self.evaluator_path = probe.evaluator_path(board_size, self.device) if self.tiled_features or tiled_features is None else \
-            "library stem (tiled features disabled by the caller)"
+        self.evaluator_path = (probe.evaluator_path(board_size, self.device) if self.tiled_features or tiled_features is None else
+                               "library stem (tiled features disabled by the caller)") + self._widen_note
         if self.device.type == "cuda" and "hand-written" not in self.evaluator_path:
             import warnings
 
@@ -106,6 +109,8 @@ class SelfPlayActor:
     # -- weights ---------------------------------------------------------------------------------------
     def set_network(self, network: AlphaZeroNet, training_steps=0):
         """Checkpoint hot-swap (pipeline.py:232-239): new weights take effect at the next round."""
+        if self.auto_widen:
+            network, _ = widen_for_kernels(network, self.board_size, self.net_dtype)
         self.infer = InferenceNet(network, dtype=self.net_dtype, binding=self.binding if self.device.type == "cuda" else None).to(self.device)
         self.training_steps = training_steps
         self.engine.set_actor_state(self.resign_threshold, training_steps)  # games that start from now on carry this tag

@@ -608,6 +608,10 @@ def main(argv=None):
             "speedup_vs_library_fp32": round(total_moves / elapsed_max / fp32_lib["moves_per_s"], 2) if fp32_lib and fp32_lib["moves_per_s"] > 0 else None,
             "fresh_tree_moves_per_s": fresh["moves_per_s"] if fresh else None, "fresh_tree_companion": fresh,
             "speedup_vs_cpu_baseline": round(total_moves / elapsed_max / cpu["value"], 1) if cpu and cpu["value"] > 0 else None,
+            # the same ratio against the REFERENCE's own speed: the CPU baseline is a port (C rules) that runs calibration_ratio x faster than
+            # the imported reference on identical seeded moves (tools/calibrate_baseline.py) -- the raw ratio above is the conservative one
+            "speedup_vs_reference_equivalent_cpu": (round(total_moves / elapsed_max / cpu["reference_equivalent_value"], 1)
+                                                    if cpu and cpu.get("reference_equivalent_value") else None),
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
             "cpu_baseline": cpu, "c1_cpu_reference_path": c1,
         }

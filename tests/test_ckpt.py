@@ -90,3 +90,59 @@ def test_checkpoint_loader_never_unpickles_code_by_default(tmp_path, monkeypatch
     open(trunc, "wb").write(open(good, "rb").read()[:100])
     with pytest.raises(Exception):
         load_checkpoint_state(trunc)
+
+
+def test_widen_for_kernels_picks_the_next_supported_width_and_keeps_the_function():
+    """Networks whose filter count has no hand-written evaluator kernel are widened (function-preserving) to the next width that has:
+    the shipped 10 x 40 Gomoku shape -> 64, a 96-filter 9x9 Go network -> 128; supported widths, widths beyond the largest kernel and
+    boards without kernels are left alone.  The widened copy computes the SAME function (zero-weight channels: exact in fp32)."""
+    from alpha_zero_amd.core.network import widen_for_kernels
+
+    torch.manual_seed(3)
+    net = AlphaZeroNet((17, 13, 13), 169, 2, 40, 80, gomoku=True).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2), m.running_var.uniform_(0.5, 1.5), m.weight.uniform_(0.7, 1.3), m.bias.normal_(0, 0.2)
+    w, note = widen_for_kernels(net, 13, torch.float32)
+    assert w.conv_block[0].out_channels == 64 and "40 -> 64" in note
+    x = (torch.rand(5, 17, 13, 13, generator=torch.Generator().manual_seed(1)) > 0.6).float()
+    with torch.no_grad():
+        (l0, v0), (l1, v1) = net(x), w(x)
+    assert (l0 - l1).abs().max().item() <= 1e-5 and (v0 - v1).abs().max().item() <= 1e-5
+    go96 = AlphaZeroNet((17, 9, 9), 82, 1, 96, 32)
+    assert widen_for_kernels(go96, 9, torch.float32)[0].conv_block[0].out_channels == 128
+    assert widen_for_kernels(go96, 9, torch.bfloat16)[0].conv_block[0].out_channels == 128
+    for f, n, gomoku in ((128, 9, False), (64, 9, False), (64, 13, True), (300, 9, False), (32, 7, False)):
+        same = AlphaZeroNet((17, n, n), n * n + (0 if gomoku else 1), 1, f, 16, gomoku=gomoku)
+        got, note = widen_for_kernels(same, n, torch.float32)
+        assert got is same and note == ""
+    go19 = AlphaZeroNet((17, 19, 19), 362, 1, 192, 16)
+    assert widen_for_kernels(go19, 19, torch.float32)[0] is go19                                   # no fp32-class kernels at 19x19
+    assert widen_for_kernels(go19, 19, torch.bfloat16)[0].conv_block[0].out_channels == 256       # the bf16 kernels exist at 256
+
+
+@pytest.mark.gpu
+def test_gpu_actor_runs_the_shipped_network_width_on_hand_written_kernels_by_default():
+    """SelfPlayActor's defaults with a network of the shipped Gomoku shape (10 x 40, training_gomoku.py:37-38): the reference's precision
+    (fp32 class) on the hand-written split-precision kernels, reached by widening 40 -> 64 filters -- no library fallback, no warning."""
+    import warnings
+
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    torch.manual_seed(2)
+    net = AlphaZeroNet((17, 13, 13), 169, 2, 40, 80, gomoku=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        act = SelfPlayActor(net, game="gomoku", board_size=13, num_games=64, num_simulations=16, num_parallel=4, warm_up_steps=4, device="cuda",
+                            engine_kw={"max_steps": 20})
+        assert "hand-written" in act.evaluator_path and "split-precision" in act.evaluator_path and "widened 40 -> 64" in act.evaluator_path
+        act.run_rounds(120)
+        got = act.harvest()
+    assert len(got) >= 32 and act.range_events == 0
+    # the evaluator the actor built equals the original 40-filter network (fp32 module on the CPU) on real positions
+    x = torch.stack([torch.from_numpy(t.state.astype("float32")) for seq, _ in got[:8] for t in seq[:4]])
+    pri, v = act.infer(x.cuda())
+    with torch.no_grad():
+        lg, vr = net.eval()(x)
+    assert (pri.cpu() - torch.softmax(lg, -1)).abs().max().item() <= 2e-5 and (v.cpu() - vr.squeeze(1)).abs().max().item() <= 2e-5
