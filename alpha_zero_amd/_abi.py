@@ -4,7 +4,7 @@ which only ever loads the HIP build and refuses to run without a GPU."""
 import ctypes as C
 
 GAME_GO, GAME_GOMOKU = 0, 1
-FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16, FEAT_BF16_TILED, FEAT_F16_TILED = 0, 1, 2, 3, 4, 5
+FEAT_I8, FEAT_F32, FEAT_BF16, FEAT_F16, FEAT_BF16_TILED, FEAT_F16_TILED, FEAT_F16_SPLIT = 0, 1, 2, 3, 4, 5, 6
 ST_NEED_ROOT, ST_SEARCH, ST_MOVE_DONE, ST_IDLE, ST_WAIT_BUF = 0, 1, 2, 3, 4
 
 SYMBOLS = [

@@ -97,7 +97,10 @@ class Engine:
         self._ck(self.b.dll.azsp_set_tables(self.h, t_np.ctypes.data, t_py.ctypes.data, sq.ctypes.data, g.table_len), "azsp_set_tables")
         # evaluator-facing tensors (caller-visible; the engine reads / writes them in place)
         self.features_tiled = cfg.feature_dtype in (_abi.FEAT_BF16_TILED, _abi.FEAT_F16_TILED)
-        if self.features_tiled:  # the evaluator's tiled layout (include/azsp.h: AZSP_FEAT_BF16_TILED / _F16_TILED), flat and zero-initialised
+        self.features_split = cfg.feature_dtype == _abi.FEAT_F16_SPLIT
+        if self.features_split:  # the fp32-class stem's input (AZSP_FEAT_F16_SPLIT): [row][hi, lo][4][N*N][8] f16; only hi planes are ever written
+            self.features = torch.zeros((self.b.dll.azsp_split_bytes(self.rows, self.N, 32) // 2,), dtype=torch.float16, device=self.device)
+        elif self.features_tiled:  # the evaluator's tiled layout (include/azsp.h: AZSP_FEAT_BF16_TILED / _F16_TILED), flat and zero-initialised
             n = self.b.dll.azsp_tiled_bytes(self.rows, self.N, 32) // 2
             self.features = torch.zeros((n,), dtype=torch.float16 if cfg.feature_dtype == _abi.FEAT_F16_TILED else torch.bfloat16, device=self.device)
         else:

@@ -268,22 +268,30 @@ class InferenceNet(nn.Module):
         return cache[key]
 
     @torch.no_grad()
-    def forward_split(self, planes, priors_out=None, values_out=None, slot=None):
-        """planes: observation planes [B,17,N,N] fp32, contiguous NCHW (the engine's AZSP_FEAT_F32 features).  The whole evaluator at
-        the reference's precision class (pipeline.py:91-123 evaluates in fp32) on hand-written kernels.  slot: scratch buffers to use
-        (see _split_buffers); None = 0 when the outputs go to caller tensors (the engine's forward), 3 otherwise."""
+    def forward_split(self, planes, priors_out=None, values_out=None, slot=None, split_features=None):
+        """planes: observation planes [B,17,N,N] fp32, contiguous NCHW (the engine's AZSP_FEAT_F32 features) -- or, with
+        split_features = (rows, board_size), the engine's AZSP_FEAT_F16_SPLIT tensor itself (the stem's input layout: no conversion
+        launch).  The whole evaluator at the reference's precision class (pipeline.py:91-123 evaluates in fp32) on hand-written kernels.
+        slot: scratch buffers to use (see _split_buffers); None = 0 when the outputs go to caller tensors (the engine's forward), 3 otherwise."""
         import ctypes
 
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(planes.device).cuda_stream) if planes.is_cuda else None  # (host twin: CPU tensors)
-        B, cin, n, _ = planes.shape
+        if split_features is not None:
+            B, n = split_features
+        else:
+            B, cin, n, _ = planes.shape
         C = self.filters
         S = n + 2 * (self.stem_pad - 1)  # planes of the tower (network.py:101-105: the Gomoku stem pads by 3)
         if slot is None:
             slot = 0 if priors_out is not None else 3
         (a, m, o), feat, pri_buf, v_buf = self._split_buffers(B, S, C, planes.device, slot)
         self._split = (a, m, o, B)  # marks that the split kernels ran (tests); bench.py replays the tower on slot 0's buffers
-        ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, st), "azsp_split_features")
+        if split_features is not None:
+            assert planes.dtype == torch.float16 and planes.numel() >= dll.azsp_split_bytes(B, n, 32) // 2
+            feat = planes
+        else:
+            ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, st), "azsp_split_features")
         ck(dll.azsp_stem_split(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, n, C, self.stem_pad, 1, st),
            "azsp_stem_split")
         a = self._blocks_split(a, m, o, B, S, C, st)

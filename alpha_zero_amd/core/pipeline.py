@@ -60,13 +60,16 @@ class SelfPlayActor:
     def __init__(self, network: AlphaZeroNet, *, game="go", board_size=9, num_games=4096, num_simulations=200, num_parallel=8,
                  c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
                  resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.float32,
-                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None):
+                 use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None,
+                 use_split_evaluator=True):
         """net_dtype: precision class of the leaf evaluator.  The default is the REFERENCE'S: fp32 (pipeline.py:91-123 evaluates in fp32,
         no autocast anywhere) -- on the hand-written split-precision kernels (hi + lo f16 pairs, three MFMA products, fp32 accumulation:
         include/azsp.h azsp_conv3x3_split) for 9x9 x {128, 64} and 13x13 Gomoku x 64 networks, on library fp32 convolutions (announced
         by a RuntimeWarning) for any other shape.  torch.bfloat16 / torch.float16 are the opt-in lower-precision evaluators.
-        tiled_features: None = use the evaluator's tiled input layout whenever the network / board shape has the hand-written bf16 / f16
-        stem / tower / head kernels; False = always NCHW planes + library stem."""
+        tiled_features: None = the engine writes its observation planes in the evaluator's own input layout whenever the network / board
+        shape has hand-written kernels (tiled bf16 / f16, or the fp32-class stem's split layout); False = always NCHW planes.
+        use_split_evaluator: False = an fp32 network is evaluated by the LIBRARY's fp32 convolutions even where the split-precision
+        kernels exist (comparison runs: bench.py's fp32_library_companion, tests/test_precision_parity.py)."""
         from .. import _lib
 
         self.binding = binding or _lib.load(require_gpu=True)
@@ -78,7 +81,11 @@ class SelfPlayActor:
         self.board_size = board_size
         wnet, self._widen_note = widen_for_kernels(network, board_size, net_dtype) if self.auto_widen else (network, "")
         probe = InferenceNet(wnet, dtype=net_dtype, binding=self.binding if self.device.type == "cuda" else None)
+        self.use_split_evaluator = bool(use_split_evaluator)
+        probe.use_split_tower = self.use_split_evaluator
         self.tiled_features = probe.supports_tiled_features(board_size, self.device) if tiled_features is None else bool(tiled_features)
+        # fp32-class evaluator: the engine writes the stem's input layout itself (AZSP_FEAT_F16_SPLIT; 0 / 1 planes are exact f16 values)
+        self.split_features = tiled_features is None and not self.tiled_features and probe.supports_split_features(board_size, self.device)
         self.evaluator_path = (probe.evaluator_path(board_size, self.device) if self.tiled_features or tiled_features is None else
                                "library stem (tiled features disabled by the caller)") + self._widen_note
         if self.device.type == "cuda" and "hand-written" not in self.evaluator_path:
@@ -91,7 +98,8 @@ class SelfPlayActor:
             resign_threshold=resign_threshold, check_resign_after_steps=check_resign_after_steps,
             disable_resign_ratio=disable_resign_ratio, root_noise=root_noise, deterministic=deterministic,
             feature_dtype=((_abi.FEAT_F16_TILED if net_dtype == torch.float16 else _abi.FEAT_BF16_TILED) if self.tiled_features
-                           else _FEAT_OF[net_dtype]), training_steps=training_steps, seed=seed, rank=rank,
+                           else _abi.FEAT_F16_SPLIT if self.split_features else _FEAT_OF[net_dtype]),
+            training_steps=training_steps, seed=seed, rank=rank,
             device_index=self.device.index or 0)
         for k, v in (engine_kw or {}).items():  # further EngineConfig fields (move logs, max_plies, ...: tests and diagnostics)
             if not hasattr(self.cfg, k):
@@ -112,6 +120,7 @@ class SelfPlayActor:
         if self.auto_widen:
             network, _ = widen_for_kernels(network, self.board_size, self.net_dtype)
         self.infer = InferenceNet(network, dtype=self.net_dtype, binding=self.binding if self.device.type == "cuda" else None).to(self.device)
+        self.infer.use_split_tower = self.use_split_evaluator
         self.training_steps = training_steps
         self.engine.set_actor_state(self.resign_threshold, training_steps)  # games that start from now on carry this tag
         self._graph = None
@@ -126,6 +135,11 @@ class SelfPlayActor:
         e = self.engine
         if e.features_tiled:
             self.infer.forward_tiled(e.features, e.rows, e.N, e.priors, e.values)
+        elif e.features_split:
+            if not self.infer.supports_split_features(e.N, self.device):  # (someone switched the split kernels off on the live InferenceNet)
+                raise RuntimeError("the engine writes the split-precision stem's input layout; build the actor with use_split_evaluator=False "
+                                   "to evaluate an fp32 network on the library")
+            self.infer.forward_split(e.features, e.priors, e.values, split_features=(e.rows, e.N))
         else:
             self.infer(e.features, e.priors, e.values)
 

@@ -28,7 +28,7 @@
 
 enum { AZS_NEED_ROOT = 0, AZS_SEARCH = 1, AZS_MOVE_DONE = 2, AZS_IDLE = 3, AZS_WAIT_BUF = 4 };
 enum { AZ_ERR_NODES = 1, AZ_ERR_SAMPLE = 4, AZ_ERR_STAGE = 8 };  // bit 2 (tree depth) retired: deep paths walk parent links
-enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FEAT_BF16_TILED = 4, AZ_FEAT_F16_TILED = 5 };
+enum { AZ_FEAT_I8 = 0, AZ_FEAT_F32 = 1, AZ_FEAT_BF16 = 2, AZ_FEAT_F16 = 3, AZ_FEAT_BF16_TILED = 4, AZ_FEAT_F16_TILED = 5, AZ_FEAT_F16_SPLIT = 6 };
 enum { AZB_FREE = 0, AZB_FILLING = 1, AZB_COMPLETE = 2 };
 // statistics counters (u64 each)
 enum { AZC_SIMS = 0, AZC_NODE_VISITS, AZC_BACKUP_EDGES, AZC_LEAVES, AZC_DUP_LEAVES, AZC_TERMINAL_HITS, AZC_MOVES,
@@ -647,12 +647,13 @@ template <class Wv, int N, int GAME> struct Engine {
     // The evaluator's tiled input layout (include/azsp.h azsp_stem_tiled): [tile = T rows][4 chunks][T NP positions][8] bf16 (or f16) with
     // T = max(1, 256 / NP) boards per tile (3 at 9x9), the 17 planes zero-padded to 32 channels.  Chunks 0..1 = the 16 stone planes, chunk 2 = colour plane + 7 zeros; chunk 3 and
     // the padding are never written (the tensor is zero-initialised by its owner).
-    AZ_HD void emit_tiled(void* feat, int slot, int me) {
-        constexpr int TBF = (256 / NP) > 0 ? 256 / NP : 1;
+    // AZ_FEAT_F16_SPLIT = the input of the fp32-class evaluator's stem (include/azsp.h azsp_stem_split): the split layout
+    // [row][plane: hi, lo][4 chunks][NP positions][8] f16 -- the same chunk strips with ONE board per tile and a second (lo) plane that is
+    // never written: observation planes are 0 / 1, exactly representable in f16, so their lo halves are zero (the owner zero-initialises).
+    template <int TBF, int PLANES> AZ_HD void emit_tiled_t(void* feat, int slot, int me, u32 one) {
         const size_t r = (size_t)g * c.P + slot, tile = r / TBF;
         const int sub = (int)(r - tile * TBF);
-        uint16_t* base = (uint16_t*)feat + tile * (size_t)(4 * TBF * NP * 8) + (size_t)sub * NP * 8;
-        const u32 one = c.feat_dtype == AZ_FEAT_F16_TILED ? 0x3C00u : 0x3F80u;  // 1.0 in f16 / bf16
+        uint16_t* base = (uint16_t*)feat + tile * (size_t)(PLANES * 4 * TBF * NP * 8) + (size_t)sub * NP * 8;
         const u32 black = me == 0 ? one : 0u;
         // One lane per POSITION (81 positions: lanes 0-63, then 0-16): the 16 plane words of its 64-position group are
         // wave-uniform LDS reads (broadcast), a stone is one bit-field extract, two planes make one dword (bf16 1.0 = 0x3F80) with two
@@ -688,7 +689,12 @@ template <class Wv, int N, int GAME> struct Engine {
     }
     AZ_HD void write_features(void* feat, int slot, int me) {
         if (c.feat_dtype == AZ_FEAT_BF16_TILED || c.feat_dtype == AZ_FEAT_F16_TILED) {
-            emit_tiled(feat, slot, me);
+            constexpr int TBF = (256 / NP) > 0 ? 256 / NP : 1;
+            emit_tiled_t<TBF, 1>(feat, slot, me, c.feat_dtype == AZ_FEAT_F16_TILED ? 0x3C00u : 0x3F80u);  // 1.0 in f16 / bf16
+            return;
+        }
+        if (c.feat_dtype == AZ_FEAT_F16_SPLIT) {
+            emit_tiled_t<1, 2>(feat, slot, me, 0x3C00u);
             return;
         }
         const size_t row = ((size_t)g * c.P + slot) * (size_t)(17 * NP);

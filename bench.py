@@ -420,11 +420,11 @@ def main(argv=None):
     DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
     torch.backends.cudnn.benchmark = not args.no_miopen_find
 
-    def make_actor(dtype_name, reuse_tree=True):
+    def make_actor(dtype_name, reuse_tree=True, split=True):
         """Engine + evaluator in the steady state: staggered openings, then the argument-independent pre-roll."""
         act = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
                             warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=DT[dtype_name],
-                            use_graph=not args.no_graph, engine_kw=None if reuse_tree else {"reuse_tree": False})
+                            use_graph=not args.no_graph, engine_kw=None if reuse_tree else {"reuse_tree": False}, use_split_evaluator=split)
         e = act.engine
         if args.stagger > 0:  # mixed game phases from the first round (documented in DESIGN.md "Measurement")
             rng = np.random.Generator(np.random.PCG64(1234 + rank))
@@ -478,7 +478,7 @@ def main(argv=None):
         # select kernel, reference-equivalent dense layout: N, W, P rows of every visited node, the new
         # node's position, virtual loss read-modify-write of W per path edge, the leaf's 17 planes + 8-board history
         # observation planes per leaf: 17 planes in the network dtype, or (tiled evaluator layout) 3 written 8-channel chunks
-        feat_bytes = 3 * n * n * 16 if actor.tiled_features else 17 * n * n * e_bytes
+        feat_bytes = 3 * n * n * 16 if (actor.tiled_features or getattr(actor, "split_features", False)) else 17 * n * n * e_bytes
         alg_bytes = (cnt["node_visits"] * 12 * A + created * 64 + cnt["leaves"] * (cnt["backup_edges"] / max(1, cnt["sims"])) * 8
                      + (cnt["leaves"] + cnt["root_evals"]) * (feat_bytes + 16 * W * 8)) / steps
         # expand/backup kernel: prior + value in, P/N/W rows out, N and W read-modify-write per path edge (+ vloss revert)
@@ -514,10 +514,7 @@ def main(argv=None):
         lowp = fp32_lib = None
         if world == 1 and not args.no_companions:
             def companion(dtype_name, split, steps, pre, label):
-                a = make_actor(dtype_name)
-                if dtype_name == "fp32":
-                    a.infer.use_split_tower = split
-                    a._graph = None
+                a = make_actor(dtype_name, split=split)
                 prer = preroll(a, args, world, dev, min_rounds=pre)
                 el, c, ev, _ = timed(a, args, world, dev, 5, steps)
                 path = a.infer.evaluator_path(n, dev)

@@ -63,6 +63,9 @@ extern "C" {
 #define AZSP_FEAT_F16 3
 #define AZSP_FEAT_BF16_TILED 4 /* bf16 in the evaluator's tiled layout, 17 planes padded to 32 channels (azsp_stem_tiled) */
 #define AZSP_FEAT_F16_TILED 5  /* the same layout with f16 elements (azsp_stem_tiled_f16) */
+#define AZSP_FEAT_F16_SPLIT 6  /* the input of the fp32-class evaluator's stem (azsp_stem_split): split layout [row][plane: hi, lo][4 chunks]
+                                  [N*N][8] f16 with 32 channels, azsp_split_bytes(rows, N, 32) bytes; the planes are 0 / 1 = exact f16 values,
+                                  so only the hi plane is ever written (the caller zero-initialises the tensor once) */
 
 #define AZSP_OK 0
 #define AZSP_EINVAL (-1)   /* bad argument / unsupported configuration */
@@ -286,7 +289,8 @@ int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* 
 
 /* The rest of the fp32-class evaluator on the split layout (core/network.py:101-156):
  * azsp_split_features: observation planes [boards][in_channels <= 32][S][S] fp32 (the engine's AZSP_FEAT_F32 features) -> split
- *   layout with 32 channels (the missing ones zero), azsp_split_bytes(boards, S, 32) bytes.
+ *   layout with 32 channels (the missing ones zero), azsp_split_bytes(boards, S, 32) bytes.  Not needed when the engine writes its
+ *   features with feature_dtype = AZSP_FEAT_F16_SPLIT: that tensor IS the stem's input (what SelfPlayActor does).
  * azsp_stem_split: the stem convolution + BatchNorm + ReLU (network.py:101-110): x from azsp_split_features (board_size x
  *   board_size), w_split [2 planes][9 taps][C out][32 in] f16 (input channels >= the network's zero), y in the tower's split layout
  *   with planes of board_size + 2 (pad - 1): pad = 1 for Go, pad = 3 for Gomoku (network.py:101-105).  On the device: (board 9,

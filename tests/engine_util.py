@@ -125,6 +125,17 @@ def untile_features(flat, rows, n):
     return np.ascontiguousarray((x[:, :, :17] == one).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
 
 
+def unsplit_features(flat, rows, n):
+    """AZSP_FEAT_F16_SPLIT tensor ([row][plane: hi, lo][4][n^2][8] f16, the fp32-class stem's input) -> int8 planes [rows, 17, n, n]; checks
+    the encoding on the way: hi halves only 0.0 / 1.0, padding channels zero, the lo plane never written (all zero)."""
+    NP = n * n
+    t = flat.view(torch.int16).cpu().numpy()[: rows * 2 * 4 * NP * 8].reshape(rows, 2, 4, NP, 8)
+    assert not t[:, 1].any(), "lo plane of 0 / 1 observation planes must stay zero"
+    x = np.ascontiguousarray(t[:, 0].transpose(0, 2, 1, 3)).reshape(rows, NP, 32)
+    assert np.all((x == 0) | (x == 0x3C00)) and not x[:, :, 17:].any()
+    return np.ascontiguousarray((x[:, :, :17] == 0x3C00).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
+
+
 def tile_features(x, dtype=torch.bfloat16):
     """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_BF16_TILED (or, dtype = float16, _F16_TILED) tensor, the inverse of untile_features."""
     rows, _, n, _ = x.shape
@@ -168,7 +179,8 @@ def run_golden_selfplay(kind, G_gold, eval_batch, feature_dtype=_abi.FEAT_I8):
         st, _ = eng.status()
         if not valid.any() and np.all(st[:, 0] == _abi.ST_IDLE):
             break
-        feats = untile_features(eng.features, eng.rows, eng.N) if eng.features_tiled else eng.features.cpu().numpy()
+        feats = (untile_features(eng.features, eng.rows, eng.N) if eng.features_tiled else
+                 unsplit_features(eng.features, eng.rows, eng.N) if eng.features_split else eng.features.cpu().numpy())
         pri = np.zeros((eng.rows, A), dtype=np.float32)
         val = np.zeros(eng.rows, dtype=np.float32)
         rows = np.flatnonzero(valid)

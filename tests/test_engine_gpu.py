@@ -111,12 +111,13 @@ def test_gpu_dihedral():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["bf16_tiled", "f16_split"])
 @pytest.mark.parametrize("name", ["go9_p8_s200", "gomoku13_p8_s200"])
-def test_gpu_tiled_feature_layout_matches_reference(name):
-    """AZSP_FEAT_BF16_TILED observation planes on the device: golden games replay bit-exactly through the un-tiled tensor."""
+def test_gpu_tiled_feature_layout_matches_reference(name, fmt):
+    """AZSP_FEAT_BF16_TILED / AZSP_FEAT_F16_SPLIT observation planes on the device: golden games replay bit-exactly through the decoded tensor."""
     from alpha_zero_amd import _abi
 
-    pc.check_mcts_golden("gpu", name, feature_dtype=_abi.FEAT_BF16_TILED)
+    pc.check_mcts_golden("gpu", name, feature_dtype=_abi.FEAT_BF16_TILED if fmt == "bf16_tiled" else _abi.FEAT_F16_SPLIT)
 
 
 @pytest.mark.gpu

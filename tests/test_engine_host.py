@@ -32,14 +32,15 @@ def test_search_and_actor_match_reference(name):
     pc.check_mcts_golden("host", name)
 
 
-@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+@pytest.mark.parametrize("fmt", ["bf16", "f16", "f16_split"])
 @pytest.mark.parametrize("name", ["go5_p4_s48_resign", "go9_p1_s50", "gomoku7_p8_s64"])
 def test_tiled_feature_layout_matches_reference(name, fmt):
-    """Observation planes written in the evaluator's tiled layout (AZSP_FEAT_BF16_TILED / AZSP_FEAT_F16_TILED) carry exactly the
-    reference's planes: the whole golden game replays bit-exactly when the evaluator sees the un-tiled tensor."""
+    """Observation planes written in the evaluators' own input layouts (AZSP_FEAT_BF16_TILED / AZSP_FEAT_F16_TILED; AZSP_FEAT_F16_SPLIT =
+    the fp32-class stem's split layout, hi plane only) carry exactly the reference's planes: the whole golden game replays bit-exactly
+    when the evaluator sees the decoded tensor (the decoders also check the encoding: only 0 / 1, padding zero, lo plane untouched)."""
     from alpha_zero_amd import _abi
 
-    pc.check_mcts_golden("host", name, feature_dtype=_abi.FEAT_BF16_TILED if fmt == "bf16" else _abi.FEAT_F16_TILED)
+    pc.check_mcts_golden("host", name, feature_dtype={"bf16": _abi.FEAT_BF16_TILED, "f16": _abi.FEAT_F16_TILED, "f16_split": _abi.FEAT_F16_SPLIT}[fmt])
 
 
 @pytest.mark.parametrize("name", ["go5_p8_s64", "go9_p8_s200", "gomoku7_p1_s40"])

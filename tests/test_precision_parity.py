@@ -29,9 +29,8 @@ def _searched_policies(net, game, n, dtype, G, sims, P, stagger, seed=7, split_t
     from alpha_zero_amd.core.pipeline import SelfPlayActor
 
     act = SelfPlayActor(net, game=game, board_size=n, num_games=G, num_simulations=sims, num_parallel=P, warm_up_steps=16, seed=seed, device="cuda",
-                        net_dtype=dtype, use_graph=False, binding=_lib.load(), engine_kw=dict(log_moves=True, log_capacity=1, max_plies=1))
-    if split_tower is not None:  # fp32 evaluator: azsp_conv3x3_split tower (True) or the library's fp32 convolutions (False)
-        act.infer.use_split_tower = split_tower
+                        net_dtype=dtype, use_graph=False, binding=_lib.load(), engine_kw=dict(log_moves=True, log_capacity=1, max_plies=1),
+                        use_split_evaluator=split_tower is not False)  # fp32: the split-precision kernels, or (False) the library's fp32 convolutions
     e = act.engine
     rng = np.random.Generator(np.random.PCG64(4321))
     plies = rng.integers(0, stagger + 1, size=G)
