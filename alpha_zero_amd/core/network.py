@@ -292,8 +292,9 @@ class InferenceNet(nn.Module):
             feat = planes
         else:
             ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, st), "azsp_split_features")
-        ck(dll.azsp_stem_split(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, n, C, self.stem_pad, 1, st),
-           "azsp_stem_split")
+        # engine-written features are 0 / 1 planes (exact f16 values, lo plane never written): the stem skips the lo plane (identical result)
+        stem = dll.azsp_stem_split_exact if split_features is not None else dll.azsp_stem_split
+        ck(stem(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, n, C, self.stem_pad, 1, st), "azsp_stem_split")
         a = self._blocks_split(a, m, o, B, S, C, st)
         pri = priors_out if priors_out is not None else pri_buf
         v = values_out if values_out is not None else v_buf

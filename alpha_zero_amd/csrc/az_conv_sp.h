@@ -340,12 +340,12 @@ __device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, co
 // Vector-memory instructions a wave of k_conv3x3_sp issues between the last LDS-DMA piece of the next board (unit 0, k-step NPIECE) and
 // the board's barrier (unit 1, k-step KS - 2): the stores of the riding epilogues (2 per column tile) and unit 1's residual loads (2 per
 // column tile, first slots of the unit).  Mirrors the kernel's schedule (same constants, same SpSpread arithmetic).
-template <bool RES, int NCH> __host__ __device__ constexpr int sp9_vm_younger() {
-    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (SpGeo9::CELLS + 63) / 64, NPIECE = NP * (2 * NCH / 4);
+template <bool RES, int NCH, bool XLO0 = false> __host__ __device__ constexpr int sp9_vm_younger() {
+    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (SpGeo9::CELLS + 63) / 64, NPIECE = NP * ((XLO0 ? 1 : 2) * NCH / 4);
     constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
     int n = 0;
     for (int i = 0; i < 2; ++i) {
-        const int nj = i == 0 ? 3 : 2, pnj = i == 0 ? 2 : 3, NQ = 3 * nj, P_OPS = pnj * CT_OPS;
+        const int nj = i == 0 ? 3 : 2, pnj = i == 0 ? 2 : 3, NQ = (XLO0 ? 2 : 3) * nj, P_OPS = pnj * CT_OPS;
         const int AVAIL = (i == 1 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
         auto cum = [&](int sl) {
             if (sl < S0) return 0;
@@ -374,7 +374,9 @@ template <bool RES, int NCH> __host__ __device__ constexpr int sp9_vm_younger() 
 // gap from the other set (measured against an exposed per-board epilogue: -4 %); the B-fragment ring (3 k-steps) runs on across units
 // and boards; the next board's LDS-DMA pieces ride in unit 0; ONE barrier per board (unit 1, two k-steps before its end: every
 // read of the current buffer has been issued and each wave's pieces of the next board have landed).
-template <bool RES, int NCH, int NCG> __global__ void __launch_bounds__(CW_THREADS, 1)
+// XLO0: the caller guarantees that the input's lo plane is all zero (exact f16 values: the engine's 0 / 1 observation planes,
+// AZSP_FEAT_F16_SPLIT) -- the lo strips are not loaded, their fragments not read and the w_hi x_lo product is skipped (it is exactly zero).
+template <bool RES, int NCH, int NCG, bool XLO0 = false> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
              const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
     typedef SpGeo9 G;
@@ -385,7 +387,9 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     constexpr int GBLK = G::P2 * 16, XPLANE = NCH * GBLK, XTILE = 2 * XPLANE;
     constexpr int YPLANE = (C / 8) * GBLK, YTILE = 2 * YPLANE;
     constexpr int NP = (G::CELLS + 63) / 64;
-    constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;
+    constexpr int SPW = (XLO0 ? 1 : 2) * NCH / 4, NPIECE = NP * SPW;  // (XLO0: the hi plane's strips only = strips 0 .. NCH - 1)
+    constexpr int NPROD = XLO0 ? 2 : 3;                               // MFMA products per multiply
+    static_assert(!XLO0 || (!RES && NCH == 4), "exact-f16 inputs: the stem");
     constexpr int NF = 2 * KS, NF_A = NF < 64 ? NF : 64;
     // epilogue micro-ops: per element E1 (join, [residual join, add,] ReLU, range record, clamp), per pair of elements 6 more (packed hi
     // convert, 2 scalings, 2 remainders, packed lo convert), per column tile 2 stores
@@ -470,9 +474,11 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
 #pragma unroll
         for (int j = 0; j < NJ0; ++j)
             if (j < nj) bb[rs][0][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off);
+        if constexpr (!XLO0) {
 #pragma unroll
-        for (int j = 0; j < NJ0; ++j)
-            if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off + LPLANE);
+            for (int j = 0; j < NJ0; ++j)
+                if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off + LPLANE);
+        }
     };
 
     {   // first board: all pieces at once, then the first fragments
@@ -564,12 +570,12 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             constexpr int nj = i == 0 ? NJ0 : NJ1, j0 = i == 0 ? 0 : NJ0;          // this unit's column tiles
             constexpr int pnj = i == 0 ? NJ1 : NJ0, pj0 = i == 0 ? NJ0 : 0;        // the previous unit's
             constexpr int nnj = pnj, nj0 = pj0;                                     // the next unit's (= the other one)
-            constexpr int NQ = 3 * nj, P_OPS = pnj * CT_OPS;                        // MFMAs per k-step; micro-ops of the riding epilogue
+            constexpr int NQ = NPROD * nj, P_OPS = pnj * CT_OPS;                    // MFMAs per k-step; micro-ops of the riding epilogue
             // the riders are spread evenly over the unit's MFMA gaps and end 4 slots before the unit does; in unit 1 they end before the
             // barrier (whose counted wait knows exactly which vector-memory instructions are younger than the next board's DMA pieces)
             constexpr int AVAIL = (i == 1 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
             typedef SpSpread<P_OPS, S0, AVAIL> SP;
-            static_assert(SP::MAXPER <= (NCH >= 16 ? 1 : NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
+            static_assert(SP::MAXPER <= (NCH >= 16 ? 1 : NCH >= 8 ? 2 : XLO0 ? 6 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
             unsigned char* pout = i == 0 ? yprev : ybase;
             const bool pstore = i > 0 || have_prev;
             cp_for_each([&](auto TC) __attribute__((always_inline)) {
@@ -579,7 +585,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                     // every read of this buffer has been issued.  This wave's pieces of the next board (unit 0) are older than the
                     // VM_YOUNGER youngest vector-memory instructions it has issued (stores of the riding epilogues, unit 1's residual
                     // loads: counted at compile time, each is issued unconditionally); those may stay in flight
-                    constexpr int VM_YOUNGER = sp9_vm_younger<RES, NCH>();
+                    constexpr int VM_YOUNGER = sp9_vm_younger<RES, NCH, XLO0>();
                     static_assert(VM_YOUNGER < 63, "vmcnt field");
                     if (have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first board: the stores riding in its unit 0 were skipped
@@ -589,7 +595,8 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                 else if constexpr (i == 0) load_step(Xs, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
                 else load_step(Xn, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
                 cp_for_each([&](auto QC) __attribute__((always_inline)) {
-                    constexpr int q = decltype(QC)::value, prod = q / nj, j = q % nj;  // product 0: main, 1: w_hi x_lo, 2: w_lo x_hi
+                    constexpr int q = decltype(QC)::value, j = q % nj;
+                    constexpr int prod = XLO0 ? (q / nj == 0 ? 0 : 2) : q / nj;       // product 0: main, 1: w_hi x_lo (skipped when x_lo = 0), 2: w_lo x_hi
                     constexpr int fa = prod == 2 ? KS + t : t, pl = prod == 1 ? 1 : 0;
                     if constexpr (prod == 0) {
                         if constexpr (t == 0) sp_mfma_ac(accm[set][j], wf[fa], bb[g % R][pl][j], bv);
@@ -597,6 +604,8 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                     } else if constexpr (prod == 1) {
                         if constexpr (t == 0) sp_mfma_a0(accc[set][j], wf[fa], bb[g % R][pl][j]);
                         else sp_mfma_a(accc[set][j], wf[fa], bb[g % R][pl][j]);
+                    } else if constexpr (XLO0 && t == 0) {
+                        sp_mfma_a0(accc[set][j], wf[fa], bb[g % R][pl][j]);  // (the correction accumulator starts here: no w_hi x_lo product)
                     } else {
                         if constexpr (fa < NF_A) sp_mfma_a(accc[set][j], wf[fa], bb[g % R][pl][j]);
                         else sp_mfma_v(accc[set][j], wf[fa], bb[g % R][pl][j]);
@@ -635,15 +644,15 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                 constexpr int u = decltype(TC)::value, tp = u / KSUB, ks = u % KSUB;         // tap = (7 + tp / 2, tp % 2) relative to (8, 0)
                 constexpr int fa = ((tp >> 1) * 3 + 1 + (tp & 1)) * KSUB + ks;              // weight k-step of tap (dy, dx) = (tp / 2 - 1, tp % 2)
                 const sp_f16x8 bh = *(const sp_f16x8*)(sb + ((tp * 2 + 0) * KSUB + ks) * 16);
-                const sp_f16x8 bl = *(const sp_f16x8*)(sb + ((tp * 2 + 1) * KSUB + ks) * 16);
-                if constexpr (u == 0) {
-                    sp_mfma_ac(cm, wf[fa], bh, bv);
-                    sp_mfma_a0(cc, wf[fa], bl);
-                } else {
-                    sp_mfma_a(cm, wf[fa], bh);
-                    sp_mfma_a(cc, wf[fa], bl);
+                if constexpr (u == 0) sp_mfma_ac(cm, wf[fa], bh, bv);
+                else sp_mfma_a(cm, wf[fa], bh);
+                if constexpr (!XLO0) {
+                    const sp_f16x8 bl = *(const sp_f16x8*)(sb + ((tp * 2 + 1) * KSUB + ks) * 16);
+                    if constexpr (u == 0) sp_mfma_a0(cc, wf[fa], bl);
+                    else sp_mfma_a(cc, wf[fa], bl);
                 }
-                if constexpr (KS + fa < NF_A) sp_mfma_a(cc, wf[KS + fa], bh);
+                if constexpr (XLO0 && u == 0) sp_mfma_a0(cc, wf[KS + fa], bh);
+                else if constexpr (KS + fa < NF_A) sp_mfma_a(cc, wf[KS + fa], bh);
                 else sp_mfma_v(cc, wf[KS + fa], bh);
             }, typename CpMakeSeq<4 * KSUB>::type{});
             asm volatile("s_nop 15\n\ts_nop 15" : "+v"(cm), "+v"(cc));

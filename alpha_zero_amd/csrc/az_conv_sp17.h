@@ -124,12 +124,12 @@ static_assert(sp17_uj0(0, 3) + sp17_unj(0, 3) == Sp17Geo::NCT0 && sp17_uj0(1, 3)
 // Vector-memory instructions a wave issues between the last LDS-DMA piece of the next tile (unit 0, k-step NPIECE) and the barrier of
 // the tile (unit 3, k-step KS - 2) of half h: the stores of the riding epilogues (2 per column tile) and the residual loads (2 per
 // column tile, first slots of a unit).  Mirrors the schedule of k_conv3x3_sp17 below (same constants, same SpSpread).
-template <bool RES, int NCH> __host__ __device__ constexpr int sp17_vm_younger(int h) {
-    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (Sp17Geo::CELLS + 63) / 64, NPIECE = NP * (2 * NCH / 4);
+template <bool RES, int NCH, bool XLO0 = false> __host__ __device__ constexpr int sp17_vm_younger(int h) {
+    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (Sp17Geo::CELLS + 63) / 64, NPIECE = NP * ((XLO0 ? 1 : 2) * NCH / 4);
     constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
     int n = 0;
     for (int u = 0; u < 4; ++u) {
-        const int nj = sp17_unj(h, u), NQ = 3 * nj;
+        const int nj = sp17_unj(h, u), NQ = (XLO0 ? 2 : 3) * nj;
         const int ph = u == 0 ? h ^ 1 : h, pu = (u + 3) & 3, pnj = sp17_unj(ph, pu), P_OPS = pnj * CT_OPS;
         const int AVAIL = (u == 3 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
         // slot -> cumulative micro-ops (SpSpread::cum with run-time arguments)
@@ -152,7 +152,9 @@ template <bool RES, int NCH> __host__ __device__ constexpr int sp17_vm_younger(i
 
 // NCH = input-channel chunks of 8: 8 = tower layer (64 -> 64), 4 = stem (17 planes padded to 32 -> 64, 13x13 input board at (2, 2)).
 // w: [plane: hi, lo][9 taps][64 couts][8 NCH cin] f16 with lo = (w - hi) * 2^11; bias fp32 [64].
-template <bool RES, int NCH> __global__ void __launch_bounds__(CW_THREADS, 1)
+// XLO0: the input's lo plane is all zero (exact f16 values: AZSP_FEAT_F16_SPLIT features) -- its strips, fragments and the w_hi x_lo
+// product are skipped (see k_conv3x3_sp).
+template <bool RES, int NCH, bool XLO0 = false> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
                const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int nboards, int relu) {
     typedef Sp17Geo G;
@@ -164,7 +166,9 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
     constexpr int GBLK_IN = IN_S * IN_S * 16, XPLANE = NCH * GBLK_IN, XTILE = 2 * XPLANE;
     constexpr int GBLK = G::P2 * 16, YPLANE = (C / 8) * GBLK, YTILE = 2 * YPLANE;
     constexpr int NP = (G::CELLS + 63) / 64;                 // DMA pieces of 64 cells per strip
-    constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips and DMA pieces per wave and tile
+    constexpr int SPW = (XLO0 ? 1 : 2) * NCH / 4, NPIECE = NP * SPW;  // strips and DMA pieces per wave and tile (XLO0: hi strips only)
+    constexpr int NPROD = XLO0 ? 2 : 3;
+    static_assert(!XLO0 || (!RES && NCH == 4), "exact-f16 inputs: the stem");
     constexpr int NF = 2 * KS;
     // epilogue micro-ops: per element E1 (join, [residual join, add,] ReLU, range record, clamp), per pair of elements 6 more (packed hi
     // convert, 2 scalings, 2 remainders, packed lo convert), per column tile 2 stores
@@ -235,9 +239,11 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
 #pragma unroll
         for (int j = 0; j < NJM; ++j)
             if (j < nj) bb[rs][0][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off);
+        if constexpr (!XLO0) {
 #pragma unroll
-        for (int j = 0; j < NJM; ++j)
-            if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off + LPLANE);
+            for (int j = 0; j < NJM; ++j)
+                if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off + LPLANE);
+        }
     };
 
     {   // first tile (upper half of the first board): all pieces at once, then the first fragments
@@ -314,12 +320,12 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
             constexpr int pnj = sp17_unj(PH, PU), pj0 = sp17_uj0(PH, PU);
             constexpr int NH = U == 3 ? H ^ 1 : H, NU = (U + 1) & 3;                 // the next unit (the ring runs on into it)
             constexpr int nnj = sp17_unj(NH, NU), nj0 = sp17_uj0(NH, NU);
-            constexpr int NQ = 3 * nj, P_OPS = pnj * CT_OPS;                         // MFMAs per k-step; micro-ops of the riding epilogue
+            constexpr int NQ = NPROD * nj, P_OPS = pnj * CT_OPS;                     // MFMAs per k-step; micro-ops of the riding epilogue
             // the riders end 4 slots before the unit does; in the tile's last unit they end before the barrier (whose counted wait
             // knows exactly which vector-memory instructions are younger than the next tile's DMA pieces)
             constexpr int AVAIL = (U == 3 ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;
             typedef SpSpread<P_OPS, S0, AVAIL> SP;
-            static_assert(SP::MAXPER <= (NCH >= 8 ? 2 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
+            static_assert(SP::MAXPER <= (NCH >= 8 ? 2 : XLO0 ? 6 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
             const unsigned char* Xs = lds + H * LBUF;
             const unsigned char* Xn = lds + (H ^ 1) * LBUF;
             // previous unit's output: the first unit of a board finishes the previous board's lower half
@@ -336,7 +342,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                     // every read of this buffer has been issued.  This wave's pieces of the next tile (unit 0) are older than the
                     // VM_YOUNGER youngest vector-memory instructions it has issued (residual loads and stores of units 0-3, counted at
                     // compile time: each is issued unconditionally); those may stay in flight
-                    constexpr int VM_YOUNGER = sp17_vm_younger<RES, NCH>(H);
+                    constexpr int VM_YOUNGER = sp17_vm_younger<RES, NCH, XLO0>(H);
                     static_assert(VM_YOUNGER < 63, "vmcnt field");
                     if (H == 0 && !have_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: the stores riding in its unit 0 were skipped
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");
@@ -346,7 +352,8 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                 else if constexpr (U < 3) load_step(Xs, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
                 else load_step(Xn, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
                 cp_for_each([&](auto QC) __attribute__((always_inline)) {
-                    constexpr int q = decltype(QC)::value, prod = q / nj, j = q % nj;  // product 0: main, 1: w_hi x_lo, 2: w_lo x_hi
+                    constexpr int q = decltype(QC)::value, j = q % nj;
+                    constexpr int prod = XLO0 ? (q / nj == 0 ? 0 : 2) : q / nj;       // product 0: main, 1: w_hi x_lo (skipped when x_lo = 0), 2: w_lo x_hi
                     constexpr int fa = prod == 2 ? KS + t : t, pl = prod == 1 ? 1 : 0;
                     if constexpr (prod == 0) {
                         if constexpr (t == 0) sp_mfma_ac(accm[set][j], wf[fa], bb[g % R][pl][j], bv);
@@ -354,6 +361,8 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                     } else if constexpr (prod == 1) {
                         if constexpr (t == 0) sp_mfma_a0(accc[set][j], wf[fa], bb[g % R][pl][j]);
                         else sp_mfma_a(accc[set][j], wf[fa], bb[g % R][pl][j]);
+                    } else if constexpr (XLO0 && t == 0) {
+                        sp_mfma_a0(accc[set][j], wf[fa], bb[g % R][pl][j]);  // (the correction accumulator starts here: no w_hi x_lo product)
                     } else {
                         sp_mfma_a(accc[set][j], wf[fa], bb[g % R][pl][j]);
                     }

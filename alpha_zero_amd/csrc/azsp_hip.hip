@@ -284,22 +284,22 @@ int launch_split_layout(const void* src, void* dst, long long boards, int S, int
                        (unsigned char*)dst, nchunks, to_split, C / 8, S * S);
     return AZ_HIP(hipGetLastError());
 }
-template <bool RES, int NCH, int NCG>
+template <bool RES, int NCH, int NCG, bool XLO0 = false>
 static int launch_sp(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
     long long nslot = n_cu / NCG > 0 ? n_cu / NCG : 1;  // one persistent workgroup per CU; the cout groups of a board run side by side
     if (boards < nslot) nslot = boards;
-    hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG>), dim3((unsigned)(nslot * NCG)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+    hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG, XLO0>), dim3((unsigned)(nslot * NCG)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
                        (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
     return AZ_HIP(hipGetLastError());
 }
-template <bool RES, int NCH>
+template <bool RES, int NCH, bool XLO0 = false>
 static int launch_sp17(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
     const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles
-    hipLaunchKernelGGL((k_conv3x3_sp17<RES, NCH>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
+    hipLaunchKernelGGL((k_conv3x3_sp17<RES, NCH, XLO0>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
                        (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
     return AZ_HIP(hipGetLastError());
 }
@@ -318,9 +318,13 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
                        S * S);
     return AZ_HIP(hipGetLastError());
 }
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st) {
-    if (S == 13 && C == 64 && pad == 3) return launch_sp17<false, 4>(x, w, bias, nullptr, y, boards, relu, st);  // 13x13 boards -> 17x17 planes
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st,
+                      int x_lo_zero) {
+    if (S == 13 && C == 64 && pad == 3)  // 13x13 boards -> 17x17 planes
+        return x_lo_zero ? launch_sp17<false, 4, true>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp17<false, 4>(x, w, bias, nullptr, y, boards, relu, st);
     if (S != SpGeo9::S || (C != 128 && C != 64) || pad != 1) return 1;
+    if (x_lo_zero)
+        return C == 128 ? launch_sp<false, 4, 2, true>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp<false, 4, 1, true>(x, w, bias, nullptr, y, boards, relu, st);
     return C == 128 ? launch_sp<false, 4, 2>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp<false, 4, 1>(x, w, bias, nullptr, y, boards, relu, st);
 }
 int split_range_status(unsigned out[2], int reset, void* st) {

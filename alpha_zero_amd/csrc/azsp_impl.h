@@ -559,7 +559,8 @@ struct HeadSplitArgs {
     int S, C, A, F, npol;
 };
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* stream);
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream);
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
+                      int x_lo_zero = 0);
 int split_range_status(unsigned out[2], int reset, void* stream);  // synchronises the stream
 int launch_head_split(const HeadSplitArgs& a, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
@@ -1075,6 +1076,14 @@ int azsp_stem_split(const void* x, const void* w, const float* bias, void* y, in
     if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_stem_split_exact(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
+                          void* stream) {
+    if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream, 1);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

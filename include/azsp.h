@@ -302,6 +302,10 @@ int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* 
 int azsp_split_features(const float* planes_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t in_channels, void* stream);
 int azsp_stem_split(const void* x_split32_dev, const void* w_split_dev, const float* bias_dev, void* y_dev, int64_t boards, int32_t board_size,
                     int32_t channels, int32_t pad, int32_t relu, void* stream);
+/* azsp_stem_split for inputs whose lo plane is all zero -- values that are exact in f16, i.e. the engine's AZSP_FEAT_F16_SPLIT features (0 / 1
+ * observation planes): the lo plane is neither loaded nor multiplied (its product is exactly zero), the result is identical to azsp_stem_split's. */
+int azsp_stem_split_exact(const void* x_split32_dev, const void* w_split_dev, const float* bias_dev, void* y_dev, int64_t boards, int32_t board_size,
+                          int32_t channels, int32_t pad, int32_t relu, void* stream);
 int azsp_head_split(const void* x_dev, const float* head_w_dev, const float* head_b_dev, const float* pol_fc_wt_dev, const float* pol_fc_b_dev,
                     const float* val_fc1_wt_dev, const float* val_fc1_b_dev, const float* val_fc2_w_dev, float val_fc2_b, float* priors_dev,
                     float* values_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t num_actions, int32_t fc_units, int32_t npol,

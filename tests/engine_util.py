@@ -136,6 +136,17 @@ def unsplit_features(flat, rows, n):
     return np.ascontiguousarray((x[:, :, :17] == 0x3C00).astype(np.int8).transpose(0, 2, 1)).reshape(rows, 17, n, n)
 
 
+def split_features(x):
+    """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_F16_SPLIT tensor (hi plane written, lo plane zero), the inverse of unsplit_features."""
+    rows, _, n, _ = x.shape
+    NP = n * n
+    full = torch.zeros(rows, 2, 4, NP, 8, dtype=torch.float16)
+    hi = torch.zeros(rows, NP, 32, dtype=torch.float16)
+    hi[:, :, :17] = x.reshape(rows, 17, NP).permute(0, 2, 1).to(torch.float16)
+    full[:, 0] = hi.view(rows, NP, 4, 8).permute(0, 2, 1, 3)
+    return full.reshape(-1)
+
+
 def tile_features(x, dtype=torch.bfloat16):
     """[rows, 17, n, n] 0/1 planes -> the AZSP_FEAT_BF16_TILED (or, dtype = float16, _F16_TILED) tensor, the inverse of untile_features."""
     rows, _, n, _ = x.shape

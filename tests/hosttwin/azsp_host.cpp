@@ -177,7 +177,7 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
             }
     return 0;
 }
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*) {
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*, int) {
     if (!((S == 9 && (C == 128 || C == 64) && pad == 1) || (S == 13 && C == 64 && pad == 3))) return 1;
     if (pad == 1) return host_conv_split(x, w, bias, nullptr, y, boards, S, 32, C, relu);
     // embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1): the pad-3 convolution of the board is the pad-1 convolution of that plane

@@ -448,3 +448,35 @@ def test_gpu_split_range_record_trips_and_resets(S, C):
     xs = torch.zeros(dll.azsp_split_bytes(5, S, C) // 2, dtype=torch.float16, device="cuda")
     assert dll.azsp_split_layout(x3.cuda().contiguous(memory_format=torch.channels_last).data_ptr(), xs.data_ptr(), 5, S, C, 1, None) == 0
     assert status(1) == (1, 1e6)
+
+
+def test_split_feature_tensor_round_trip_host():
+    """engine_util.split_features builds the AZSP_FEAT_F16_SPLIT tensor the engine writes (checked by unsplit_features' own assertions), and
+    the host twin's forward on it equals its forward on the fp32 planes (azsp_stem_split_exact == azsp_split_features + azsp_stem_split)."""
+    import engine_util as eu
+
+    x = (torch.rand(3, 17, 9, 9, generator=torch.Generator().manual_seed(5)) > 0.6).float()
+    t = eu.split_features(x)
+    assert (torch.from_numpy(eu.unsplit_features(t, 3, 9)).float() == x).all()
+    net = _trained_like_net(64, 1)
+    inf = InferenceNet(net, dtype=torch.float32, binding=eu.hosttwin_binding())
+    p0, v0 = inf.forward_split(x)
+    p1, v1 = inf.forward_split(t, split_features=(3, 9))
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("game,n,filters", [("go", 9, 128), ("go", 9, 64), ("gomoku", 13, 64)])
+def test_gpu_stem_on_engine_written_features_equals_the_general_stem(game, n, filters):
+    """azsp_stem_split_exact on the engine's AZSP_FEAT_F16_SPLIT features (hi plane only: the lo plane of 0 / 1 planes is zero, so its
+    loads and its product are skipped) gives bit for bit the network outputs of azsp_split_features + azsp_stem_split on the same planes."""
+    import engine_util as eu
+    from alpha_zero_amd import _lib
+
+    net = _trained_like_net(filters, 2) if game == "go" else _trained_like_gomoku_net(filters, 2)
+    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    for rows in (1, 5, 300, 1031):
+        x = (torch.rand(rows, 17, n, n, generator=torch.Generator().manual_seed(rows)) > 0.6).float()
+        p0, v0 = inf.forward_split(x.cuda().contiguous())
+        p1, v1 = inf.forward_split(eu.split_features(x).cuda(), split_features=(rows, n))
+        assert torch.equal(p0, p1) and torch.equal(v0, v1), (game, n, filters, rows, float((p0 - p1).abs().max()))
