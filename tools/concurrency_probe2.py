@@ -47,6 +47,46 @@ def snapshot(k):
             "pri": e.priors[g0 * e.P:g1 * e.P].clone(), "v": e.values[g0 * e.P:g1 * e.P].clone()}
 
 
+# PROBE_B_KERNELS = stem | tower | head: the second stream does not run a whole forward but only that kernel family, again and again
+# (bisects which neighbour it takes); its results are then not compared (half 1 is skipped below)
+B_KIND = os.environ.get("PROBE_B_KERNELS", "all")
+if B_KIND != "all":
+    import ctypes
+
+    _orig_half = act._forward_half
+
+    def _forward_half(k):
+        if k == 0:
+            return _orig_half(0)
+        dll, st = act.binding.dll, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        g0, g1 = act._halves[1]
+        r0, rows = g0 * e.P, (g1 - g0) * e.P
+        tb = 3
+        feat = e.features[(r0 // tb) * (32 * tb * 81):]
+        a, m, o = inf._tiled_buffers(rows, 9, 128, feat.device, 2)
+        k1, k2 = inf.fc_wp.shape[1], inf.fc_w1.shape[1]
+        pol, val, _, _ = inf._head_buffers(rows, k1, k2, feat.device, 2)
+        pri_b, v_b = e.priors[r0:r0 + rows], e.values[r0:r0 + rows]
+        seq = B_KIND.split("+")  # e.g. "tower+head": the listed kernels one after the other, the whole list PROBE_B_REPS times
+        for _ in range(int(os.environ.get("PROBE_B_REPS", "8"))):
+            for kname in seq:
+                if kname == "stem":
+                    assert dll.azsp_stem_tiled(feat.data_ptr(), inf.stem_wp.data_ptr(), inf.stem_b32.data_ptr(), a.data_ptr(), rows, 9, 128, 1, 1, st) == 0
+                elif kname == "tower":
+                    assert dll.azsp_conv3x3_tiled(a.data_ptr(), inf.wp[0].data_ptr(), inf.b32[0].data_ptr(), None, m.data_ptr(), rows, 9, 128, 1, st) == 0
+                elif kname == "towerres":
+                    assert dll.azsp_conv3x3_tiled(m.data_ptr(), inf.wp[1].data_ptr(), inf.b32[1].data_ptr(), a.data_ptr(), o.data_ptr(), rows, 9, 128, 1, st) == 0
+                elif kname == "head":
+                    assert dll.azsp_head_tiled(a.data_ptr(), inf.head_w32.data_ptr(), inf.head_b32.data_ptr(), pol.data_ptr(), val.data_ptr(), rows, 9, 128,
+                                               inf.npol, inf.nval, k1, k2, st) == 0
+                elif kname == "fc":
+                    assert dll.azsp_fc_heads(pol.data_ptr(), val.data_ptr(), inf.fc_wp.data_ptr(), inf.fc_bp.data_ptr(), k1 // 16, inf.fc_w1.data_ptr(),
+                                             inf.fc_b1.data_ptr(), k2 // 16, inf.fc_w2.data_ptr(), ctypes.c_float(inf.fc_b2), pri_b.data_ptr(), v_b.data_ptr(),
+                                             rows, inf.num_actions, inf.fc_width, st) == 0
+                else:
+                    raise SystemExit("unknown kernel " + kname)
+
+    act._forward_half = _forward_half
 main = torch.cuda.current_stream()
 found = {}
 for r in range(40):
@@ -60,19 +100,21 @@ for r in range(40):
     for s in act._streams:
         main.wait_stream(s)
     torch.cuda.synchronize()
-    conc = [snapshot(k) for k in range(2)]
+    halves = (0, 1) if B_KIND == "all" else (0,)
+    conc = [snapshot(k) for k in halves]
     ser = []
-    for k in range(2):
-        act._forward_half(k)
+    for k in halves:
+        (act._forward_half if B_KIND == "all" else _orig_half)(k)
         torch.cuda.synchronize()
         ser.append(snapshot(k))
-    for k in range(2):
+    for k in halves:
         for name in ("stem", "tower", "pol", "val", "pri", "v"):
             if not torch.equal(conc[k][name], ser[k][name]):
                 d = (conc[k][name].float() - ser[k][name].float()).abs()
                 nz = torch.nonzero(d.flatten() > 0).flatten()
                 found.setdefault((k, name), []).append((r, int(nz.numel()), nz[:8].tolist(), float(d.max())))
                 break
+print("second stream runs:", B_KIND)
 print("first differing stage per (half, stage) over 40 rounds:", {k: (len(v), v[:3]) for k, v in found.items()} or "none", flush=True)
 # where the differing head-plane elements sit: (row of the head buffer = board, column = plane * P2 + position) -> head workgroup = flat position // 256
 for (k, name), v in found.items():

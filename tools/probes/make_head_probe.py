@@ -8,6 +8,7 @@ AZ_PROBE_LIB:
   CHECK    LDSTABLE + at its end the kernel verifies that (a) the table still equals the global weights and (b) recomputing the planes from
            a second read of the input with weights from global memory gives the same result; counted in a device record read by
            azsp_probe_head_dbg (probe-only export)
+  PAD512   LDSTABLE + 512 B of static LDS (2048 B per head workgroup: two of them no longer fit beside a tower workgroup)
   PAD      LDSTABLE with 96 KB of extra static LDS (one head workgroup per CU): the round-3 observation that this hides the effect
 The product build itself is the fourth variant (no AZ_PROBE_LIB)."""
 import os
@@ -78,6 +79,10 @@ def build(variant):
         marker = "    extern __shared__ float ws[];  // [NPL][C]\n"
         assert body.count(marker) == 1
         body = body.replace(marker, marker + "    __shared__ float pad_lds[24 * 1024];\n    if (C < 0) pad_lds[threadIdx.x] = 0.0f, ws[0] = pad_lds[threadIdx.x + 1];\n")
+    elif variant == "PAD512":  # table + 512 B: two head workgroups no longer fit beside a 160 768-byte tower workgroup (LDS exactly full with 1536 B each)
+        marker = "    extern __shared__ float ws[];  // [NPL][C]\n"
+        assert body.count(marker) == 1
+        body = body.replace(marker, marker + "    __shared__ float pad_lds[128];\n    if (C < 0) pad_lds[threadIdx.x & 127] = 0.0f, ws[0] = pad_lds[(threadIdx.x + 1) & 127];\n")
     else:
         assert variant == "LDSTABLE"
     open(p, "w").write(t[:head0] + body + t[head1:])
