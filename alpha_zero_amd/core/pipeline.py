@@ -196,9 +196,10 @@ class SelfPlayActor:
         """fp32-class evaluator: its kernels carry values as f16 pairs and clamp what exceeds +-65504 -- the reference's fp32 network
         would carry such a value on.  The kernels record every such event (azsp_split_range_status); it is polled here, once per
         harvest (the harvest has synchronised the stream already), counted in `range_events` and announced: never silent."""
-        if self.device.type != "cuda" or self.net_dtype != torch.float32 or "split-precision" not in self.evaluator_path:
+        if self.device.type != "cuda" or self.net_dtype != torch.float32 or not self.infer.supports_split_features(self.board_size, self.device):
             return
-        ev, mx = self.infer.split_range_status(reset=True)
+        with torch.cuda.device(self.device):  # the record is a per-device symbol: read the one of THIS actor's device
+            ev, mx = self.infer.split_range_status(reset=True)
         if ev:
             import warnings
 
