@@ -640,30 +640,48 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             const int n_ok = (it & 15) + 1, it0 = it - (it & 15);
             c6_f32x4 cm, cc;
             const unsigned char* sb = lds + SIDE0 + l15 * SIDE_BOARD + kg * (8 * KSUB * 16);
+            // D layout: column = board l15 of the group, rows = couts 4 kg + e of the wave's 16
+            const int nb = l15 < n_ok ? l15 : 0;
+            const size_t co = (size_t)(slot + (size_t)(it0 + nb) * nslot) * YTILE + (size_t)(cg * 8 + wave * 2 + (kg >> 1)) * GBLK + G::CORNER * 16 + (kg & 1) * 8;
+            // The phase is exposed (nothing rides behind it): the residual of the 16 corners is requested first and arrives under the MFMAs (in
+            // unit 0's residual registers, free here: its epilogue has run, the next board reloads them), and the side-buffer fragments of step
+            // u + 1 are read before the MFMAs of step u.  (Ablation, round 4, profiles/r04_split_ablation.txt: the whole phase costs 1.4 % of a plain
+            // and 2.4 % of a residual launch, three times its 48 MFMAs; overlapping these latencies recovered only 0.2 % -- the rest is the break in
+            // the software pipeline around the phase and its barrier.)
+            if (RES) {
+                rr[0][0][0] = *(const cv_u32x2*)(res + co);
+                rr[0][0][1] = *(const cv_u32x2*)(res + co + YPLANE);
+            }
+            sp_f16x8 fb[2][2];  // [step parity][plane]
+            fb[0][0] = *(const sp_f16x8*)(sb);
+            if constexpr (!XLO0) fb[0][1] = *(const sp_f16x8*)(sb + KSUB * 16);
             cp_for_each([&](auto TC) __attribute__((always_inline)) {
                 constexpr int u = decltype(TC)::value, tp = u / KSUB, ks = u % KSUB;         // tap = (7 + tp / 2, tp % 2) relative to (8, 0)
                 constexpr int fa = ((tp >> 1) * 3 + 1 + (tp & 1)) * KSUB + ks;              // weight k-step of tap (dy, dx) = (tp / 2 - 1, tp % 2)
-                const sp_f16x8 bh = *(const sp_f16x8*)(sb + ((tp * 2 + 0) * KSUB + ks) * 16);
+                if constexpr (u + 1 < 4 * KSUB) {
+                    constexpr int tn = (u + 1) / KSUB, kn = (u + 1) % KSUB;
+                    fb[(u + 1) & 1][0] = *(const sp_f16x8*)(sb + ((tn * 2 + 0) * KSUB + kn) * 16);
+                    if constexpr (!XLO0) fb[(u + 1) & 1][1] = *(const sp_f16x8*)(sb + ((tn * 2 + 1) * KSUB + kn) * 16);
+                }
+                const sp_f16x8& bh = fb[u & 1][0];
                 if constexpr (u == 0) sp_mfma_ac(cm, wf[fa], bh, bv);
                 else sp_mfma_a(cm, wf[fa], bh);
                 if constexpr (!XLO0) {
-                    const sp_f16x8 bl = *(const sp_f16x8*)(sb + ((tp * 2 + 1) * KSUB + ks) * 16);
+                    const sp_f16x8& bl = fb[u & 1][1];
                     if constexpr (u == 0) sp_mfma_a0(cc, wf[fa], bl);
                     else sp_mfma_a(cc, wf[fa], bl);
                 }
                 if constexpr (XLO0 && u == 0) sp_mfma_a0(cc, wf[KS + fa], bh);
                 else if constexpr (KS + fa < NF_A) sp_mfma_a(cc, wf[KS + fa], bh);
                 else sp_mfma_v(cc, wf[KS + fa], bh);
+                __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<4 * KSUB>::type{});
             asm volatile("s_nop 15\n\ts_nop 15" : "+v"(cm), "+v"(cc));
-            // D layout: column = board l15 of the group, rows = couts 4 kg + e of the wave's 16
-            const int nb = l15 < n_ok ? l15 : 0;
-            const size_t co = (size_t)(slot + (size_t)(it0 + nb) * nslot) * YTILE + (size_t)(cg * 8 + wave * 2 + (kg >> 1)) * GBLK + G::CORNER * 16 + (kg & 1) * 8;
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(cc[e], SP_INV_SCALE, cm[e]);
             if (RES) {
-                const cv_u32x2 rh = *(const cv_u32x2*)(res + co), rl = *(const cv_u32x2*)(res + co + YPLANE);
+                const cv_u32x2 rh = rr[0][0][0], rl = rr[0][0][1];
                 v[0] += sp_join(sp_lo16(rh.x), sp_lo16(rl.x));
                 v[1] += sp_join(sp_hi16(rh.x), sp_hi16(rl.x));
                 v[2] += sp_join(sp_lo16(rh.y), sp_lo16(rl.y));

@@ -3,7 +3,7 @@ the kernels removed per build (results are wrong, timings tell what each part co
 script patches copies under a build directory and compiles them to tools/probes/libazsp_abl_<VARIANT>.so, which tools/split_bench.py
 times through AZ_BENCH_LIB.  Variants: FULL (unpatched), HALF_FRAG (B fragments of every second k-step are not read from LDS: the ring
 slot keeps its old contents), NO_FRAG (no fragment reads after the first k-steps), NO_DMA (the next tile's LDS-DMA pieces are not
-issued), NO_STORE (no output stores and no residual loads; the compiler then drops the whole epilogue arithmetic as dead code)."""
+issued), NO_CORNER (9x9: no corner phase), NO_STORE (no output stores and no residual loads; the compiler then drops the whole epilogue arithmetic as dead code)."""
 import os
 import shutil
 import subprocess
@@ -36,6 +36,9 @@ def patch(text, variant, name):
             rep("                if constexpr (U == 0 && t >= 1 && t - 1 < NPIECE) dma_piece(nsrc, ndst, nlive, H ^ 1, t - 1);",
                 "                if constexpr (g >= 1 && (g - 1) %% %d == 0 && (g - 1) / %d < NPIECE) dma_piece(nsrc, ndst, nlive, H ^ 1, (g - 1) / %d);" % (STR, STR, STR))
             rep('if (H == 0 && !have_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', 'if (true) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+    elif variant == "NO_CORNER":  # 9x9 kernel only: the corner phase (position (8, 0) of the last <= 16 boards) is skipped
+        if name == "az_conv_sp.h":
+            rep("        if ((it & 15) == 15 || !has_next) {", "        if (false) {")
     elif variant == "NO_STORE":
         rep("if (store_ok) *(cv_u32x2*)", "if (false) *(cv_u32x2*)", 0)
         rep("                        rr[set][rj][rp] = *(const cv_u32x2*)", "                        if (false) rr[set][rj][rp] = *(const cv_u32x2*)")
