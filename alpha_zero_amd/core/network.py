@@ -11,6 +11,8 @@ engine's priors/values tensors.  MFMA is used here and only here (MIOpen / hipBL
 """
 from typing import Tuple
 
+from contextlib import nullcontext as _nullcontext
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -171,6 +173,13 @@ class InferenceNet(nn.Module):
             self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
             if dtype == torch.float32:  # split-precision tower (azsp_conv3x3_split)
                 self.wsp = nn.ParameterList([nn.Parameter(split_weights_f16(w), requires_grad=False) for w, _ in convs[1:]])
+                # tower biases as the split kernels see them: b * 2^-act_shift (set_act_shift); b32 keeps the unscaled values
+                self.b_sp = nn.ParameterList([nn.Parameter(b.float().clone().contiguous(), requires_grad=False) for _, b in convs[1:]])
+                # this network's own range record (include/azsp.h: range_rec_dev): [events, bits of the largest |v|]
+                self.register_buffer("range_rec", torch.zeros(2, dtype=torch.int32), persistent=False)
+            # fp32-class path: every activation is carried as v * 2^-act_shift (an exact rescaling of a ReLU + skip tower, see set_act_shift)
+            self.act_shift, self.act_calibrated, self.act_max_abs = 0, False, 0.0
+            self.split_fallback_reason = ""  # set when calibration gave the fp32-class kernels up for this network (library fp32 instead)
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
@@ -184,11 +193,15 @@ class InferenceNet(nn.Module):
                 if dtype == torch.float32:  # azsp_stem_split: [plane][tap][cout][32 in] f16, input channels 17.. zero
                     sw32 = torch.zeros(sw.shape[0], 32, 3, 3)
                     sw32[:, : sw.shape[1]] = sw
+                    self.register_buffer("stem_w32", sw32.float().contiguous(), persistent=False)  # unscaled source of stem_wsp
                     self.stem_wsp = nn.Parameter(split_weights_f16(sw32), requires_grad=False)
+                    self.stem_b_sp = nn.Parameter(convs[0][1].float().clone().contiguous(), requires_grad=False)
             pw, pb = _fold(net.policy_head[0], net.policy_head[1])
             vw, vb = _fold(net.value_head[0], net.value_head[1])
             self.npol, self.nval = pw.shape[0], vw.shape[0]
             self.head_w32 = nn.Parameter(torch.cat([pw, vw], 0).reshape(pw.shape[0] + vw.shape[0], -1).float().contiguous(), requires_grad=False)
+            if dtype == torch.float32:  # azsp_head_split reads head_w32 * 2^act_shift (undoes the activation scale exactly)
+                self.head_w_sp = nn.Parameter(self.head_w32.detach().clone(), requires_grad=False)
             self.head_b32 = nn.Parameter(torch.cat([pb, vb], 0).float().contiguous(), requires_grad=False)
             # both 1x1 heads share one convolution (2 policy planes + 1 value plane)
             self.head_w = nn.Parameter(torch.cat([pw, vw], 0).to(dtype).contiguous(memory_format=self.mf), requires_grad=False)
@@ -239,7 +252,7 @@ class InferenceNet(nn.Module):
         MFMA rate."""
         return (self.binding is not None and self.use_fused_conv and self.use_split_tower and x.is_cuda and x.dtype == torch.float32
                 and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in self.SPLIT_TOWER_SHAPES
-                and x.is_contiguous(memory_format=torch.channels_last))
+                and not self.split_fallback_reason and x.is_contiguous(memory_format=torch.channels_last))
 
     def supports_split_features(self, board_size, device):
         """True when the WHOLE fp32 evaluator runs on the split-precision kernels (azsp_split_features -> azsp_stem_split ->
@@ -247,34 +260,43 @@ class InferenceNet(nn.Module):
         filters (pad-3 stem, 17x17 planes)."""
         return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.use_fused_conv
                 and self.use_split_tower and self.use_split_heads and self.stem_ok and self.npol + self.nval == 3
-                and (self.filters, board_size, self.stem_pad) in self.SPLIT_EVAL_SHAPES)
+                and not self.split_fallback_reason and (self.filters, board_size, self.stem_pad) in self.SPLIT_EVAL_SHAPES)
 
-    def _split_buffers(self, B, S, C, device, slot=0):
-        """Scratch of the split-precision evaluator per `slot` (the scheme of _tiled_buffers): three rotating tower buffers, the stem's
-        feature buffer and the output rows.  A slot holds one batch size at a time; slot 0 is the engine-facing forward (the one
-        SelfPlayActor captures in a hipGraph -- its buffers must never be freed by another caller of the same InferenceNet), slot 3
-        every other call (evaluation games, drop-in eval_func wrappers, tests)."""
+    def _split_buffers(self, B, S, C, device, slot=0, board_size=None):
+        """Scratch of the split-precision evaluator per `slot` (the scheme of _tiled_buffers): three rotating tower buffers, the output
+        rows and -- only for callers that hand over fp32 planes (board_size given) -- the stem's feature buffer, sized with the BOARD
+        (13 at Gomoku, not the 17 of the tower planes); the engine-facing forward passes the engine's own AZSP_FEAT_F16_SPLIT tensor and
+        never allocates it.  A slot holds one batch size at a time; slot 0 is the engine-facing forward (the one SelfPlayActor captures
+        in a hipGraph -- its buffers must never be freed by another caller of the same InferenceNet), slot 3 every other call
+        (evaluation games, drop-in eval_func wrappers, tests)."""
         dll = self.binding.dll
-        nb, nf = dll.azsp_split_bytes(B, S, C) // 2, dll.azsp_split_bytes(B, S, 32) // 2
+        nb = dll.azsp_split_bytes(B, S, C) // 2
         cache = self.__dict__.setdefault("_split_cache", {})
         key = (slot, B, S, str(device))
         if key not in cache:
             for k in [k for k in cache if k[0] == slot]:
                 del cache[k]
-            cache[key] = ([torch.zeros(nb, dtype=torch.float16, device=device) for _ in range(3)],
-                          torch.zeros(nf, dtype=torch.float16, device=device),
+            cache[key] = [[torch.zeros(nb, dtype=torch.float16, device=device) for _ in range(3)], None,
                           torch.empty((B, self.num_actions), dtype=torch.float32, device=device),
-                          torch.empty((B,), dtype=torch.float32, device=device))
-        return cache[key]
+                          torch.empty((B,), dtype=torch.float32, device=device)]
+        ent = cache[key]
+        if board_size is not None and ent[1] is None:
+            ent[1] = torch.zeros(dll.azsp_split_bytes(B, board_size, 32) // 2, dtype=torch.float16, device=device)
+        return ent
 
     @torch.no_grad()
-    def forward_split(self, planes, priors_out=None, values_out=None, slot=None, split_features=None):
+    def forward_split(self, planes, priors_out=None, values_out=None, slot=None, split_features=None, probe=None):
         """planes: observation planes [B,17,N,N] fp32, contiguous NCHW (the engine's AZSP_FEAT_F32 features) -- or, with
         split_features = (rows, board_size), the engine's AZSP_FEAT_F16_SPLIT tensor itself (the stem's input layout: no conversion
         launch).  The whole evaluator at the reference's precision class (pipeline.py:91-123 evaluates in fp32) on hand-written kernels.
-        slot: scratch buffers to use (see _split_buffers); None = 0 when the outputs go to caller tensors (the engine's forward), 3 otherwise."""
+        slot: scratch buffers to use (see _split_buffers); None = 0 when the outputs go to caller tensors (the engine's forward), 3 otherwise.
+        probe: optional callback(buffer, B) after the stem and after every tower convolution (calibrate_activation_scale)."""
         import ctypes
 
+        if not self.act_calibrated and probe is None and planes.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.calibrate_activation_scale(planes, split_features=split_features, slot=slot if slot is not None else (0 if priors_out is not None else 3))
+            if self.split_fallback_reason:  # the calibration gave the fp32-class kernels up for this network: library fp32 convolutions
+                return self._forward_after_split_fallback(planes, priors_out, values_out, split_features)
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(planes.device).cuda_stream) if planes.is_cuda else None  # (host twin: CPU tensors)
         if split_features is not None:
@@ -285,42 +307,143 @@ class InferenceNet(nn.Module):
         S = n + 2 * (self.stem_pad - 1)  # planes of the tower (network.py:101-105: the Gomoku stem pads by 3)
         if slot is None:
             slot = 0 if priors_out is not None else 3
-        (a, m, o), feat, pri_buf, v_buf = self._split_buffers(B, S, C, planes.device, slot)
+        (a, m, o), feat, pri_buf, v_buf = self._split_buffers(B, S, C, planes.device, slot, board_size=None if split_features is not None else n)
         self._split = (a, m, o, B)  # marks that the split kernels ran (tests); bench.py replays the tower on slot 0's buffers
+        rr = self._range_ptr(planes.device)
         if split_features is not None:
             assert planes.dtype == torch.float16 and planes.numel() >= dll.azsp_split_bytes(B, n, 32) // 2
             feat = planes
         else:
-            ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, st), "azsp_split_features")
+            ck(dll.azsp_split_features(planes.data_ptr(), feat.data_ptr(), B, n, cin, rr, st), "azsp_split_features")
         # engine-written features are 0 / 1 planes (exact f16 values, lo plane never written): the stem skips the lo plane (identical result)
         stem = dll.azsp_stem_split_exact if split_features is not None else dll.azsp_stem_split
-        ck(stem(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b32.data_ptr(), a.data_ptr(), B, n, C, self.stem_pad, 1, st), "azsp_stem_split")
-        a = self._blocks_split(a, m, o, B, S, C, st)
+        ck(stem(feat.data_ptr(), self.stem_wsp.data_ptr(), self.stem_b_sp.data_ptr(), a.data_ptr(), B, n, C, self.stem_pad, 1, rr, st), "azsp_stem_split")
+        if probe is not None:
+            probe(a, B)
+        a = self._blocks_split(a, m, o, B, S, C, st, rr, probe)
+        if probe is not None:
+            return None
         pri = priors_out if priors_out is not None else pri_buf
         v = values_out if values_out is not None else v_buf
-        ck(dll.azsp_head_split(a.data_ptr(), self.head_w32.data_ptr(), self.head_b32.data_ptr(), self.pol_fc_wt.data_ptr(), self.pol_fc_b32.data_ptr(),
+        ck(dll.azsp_head_split(a.data_ptr(), self.head_w_sp.data_ptr(), self.head_b32.data_ptr(), self.pol_fc_wt.data_ptr(), self.pol_fc_b32.data_ptr(),
                                self.val_fc1_wt.data_ptr(), self.val_fc1_b32.data_ptr(), self.val_fc2_w32.data_ptr(), ctypes.c_float(self.fc_b2),
                                pri.data_ptr(), v.data_ptr(), B, S, C, self.num_actions, self.fc_width, self.npol, st), "azsp_head_split")
         return (pri, v) if priors_out is not None else (pri.clone(), v.clone())  # the cached output buffers are reused by the next call
 
+    def _range_ptr(self, device):
+        """Device pointer of this network's range record (None on the host twin's CPU tensors: the twin's default record)."""
+        if torch.device(device).type != "cuda":
+            return None
+        if self.range_rec.device != torch.device(device):
+            raise RuntimeError(f"InferenceNet lives on {self.range_rec.device}, its input on {device}")
+        return self.range_rec.data_ptr()
+
     def split_range_status(self, reset=False, stream=None):
-        """(events, max_abs) of the split-precision evaluator's sticky range record (include/azsp.h azsp_split_range_status): how many
-        kernel lanes met a value beyond f16's finite range (clamped to +-65504 where the reference's fp32 network would carry it) since
-        the last reset, and the largest such |v|.  Synchronises the stream."""
+        """(events, max_abs) of THIS network's sticky range record (include/azsp.h azsp_split_range_read): how many kernel lanes met a
+        value beyond f16's finite range (clamped to +-65504 where the reference's fp32 network would carry it) since the last reset,
+        and the largest such |v| in the kernels' own (scaled) units: multiply by 2^act_shift for the network's units.  Synchronises
+        the stream.  Another InferenceNet in the same process has its own record."""
         import ctypes
 
         ev, mx = ctypes.c_uint32(0), ctypes.c_float(0.0)
-        self._ck(self.binding.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), int(bool(reset)), stream), "azsp_split_range_status")
+        rec = self.range_rec.data_ptr() if self.range_rec.is_cuda else None
+        if rec is not None and stream is None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.range_rec.device).cuda_stream)
+        with torch.cuda.device(self.range_rec.device) if rec is not None else _nullcontext():
+            self._ck(self.binding.dll.azsp_split_range_read(rec, ctypes.byref(ev), ctypes.byref(mx), int(bool(reset)), stream), "azsp_split_range_read")
         return int(ev.value), float(mx.value)
 
-    def _blocks_split(self, a, m, o, B, S, C, st):
+    # -- range safety: exact power-of-two activation scale -------------------------------------------------------------------
+    MAX_ACT_SHIFT = 9   # beyond 2^-9 the scaled stem weights lose fp32-class accuracy (their hi halves become f16 subnormals)
+    ACT_HEADROOM = 16.0  # calibration leaves this factor between the largest activation it saw and f16's limit
+
+    @torch.no_grad()
+    def set_act_shift(self, k):
+        """Carry every activation of the fp32-class path as v * 2^-k: the stem's weights and bias and every tower bias are multiplied
+        by 2^-k, the 1x1 head weights by 2^k.  ReLU and the skip addition are positively homogeneous, a power of two multiplies fp32
+        and f16 values exactly: the evaluator computes the same function (network.py:42-82, :118-156) while its activations stay
+        2^k further inside f16's range.  All updates are in place (a captured hipGraph keeps pointing at the right tensors)."""
+        if self.dtype != torch.float32 or not hasattr(self, "b_sp"):
+            raise RuntimeError("set_act_shift: fp32 networks only")
+        k = int(k)
+        if k < 0 or k > 24:
+            raise ValueError(f"act_shift {k} out of range")
+        dn, up = 2.0 ** -k, 2.0 ** k
+        if self.stem_ok:
+            self.stem_wsp.copy_(split_weights_f16(self.stem_w32 * dn))
+            self.stem_b_sp.copy_(self.stem_b32 * dn)
+        for d, b in zip(self.b_sp, self.b32):
+            d.copy_(b * dn)
+        self.head_w_sp.copy_(self.head_w32 * up)
+        self.act_shift = k
+
+    @torch.no_grad()
+    def calibrate_activation_scale(self, planes, split_features=None, slot=3):
+        """One calibration pass of the fp32-class evaluator on a real batch: runs the stem and the tower launch by launch, takes the
+        largest |activation| of every layer's output and raises act_shift until that maximum sits ACT_HEADROOM below f16's limit
+        (never lowers it).  If that needs more than MAX_ACT_SHIFT the fp32-class kernels are given up for this network
+        (split_fallback_reason; the caller's forward then runs the library's fp32 convolutions and `evaluator_path` says so).
+        Returns (act_shift, largest |activation| in the network's own units).  Leaves the range record clean.  Not capturable."""
+        import math
+
+        if planes.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("calibrate_activation_scale cannot run inside a hipGraph capture")
+        self.act_calibrated = True  # (set first: forward_split below must not recurse)
+        shift, worst = self.act_shift, 0.0
+        for _ in range(8):
+            if shift != self.act_shift:
+                self.set_act_shift(shift)
+            peak = torch.zeros((), dtype=torch.float32, device=planes.device)
+
+            def probe(buf, B, peak=peak):
+                peak.copy_(torch.maximum(peak, buf.view(B, 2, -1)[:, 0].abs().max().float()))
+
+            self.forward_split(planes, slot=slot, split_features=split_features, probe=probe)
+            mx = float(peak.item())
+            if not math.isfinite(mx):
+                self.split_fallback_reason = "non-finite activations in the calibration pass"
+                break
+            if mx >= F16_MAX:  # saturated somewhere: the true maximum is unknown -- take a big step and look again
+                worst = max(worst, mx * 2.0 ** shift)
+                shift += 6
+            else:
+                worst = mx * 2.0 ** shift
+                need = math.ceil(math.log2(mx * self.ACT_HEADROOM / F16_MAX)) if mx > 0.0 else 0
+                if need <= 0:
+                    break
+                shift += need
+            if shift > self.MAX_ACT_SHIFT:
+                self.split_fallback_reason = (f"activations reach {worst:.3g}: beyond what the f16-pair format carries even scaled by "
+                                              f"2^-{self.MAX_ACT_SHIFT}")
+                break
+        if self.split_fallback_reason and self.act_shift != 0:
+            self.set_act_shift(0)
+        self.act_max_abs = max(self.act_max_abs, worst)
+        if self.range_rec.is_cuda:
+            self.split_range_status(reset=True)  # the passes above may have clamped: that is what they were looking for
+        return self.act_shift, worst
+
+    def _forward_after_split_fallback(self, planes, priors_out, values_out, split_features):
+        """The forward of a network whose fp32-class kernels were given up (split_fallback_reason): library fp32 convolutions.  The
+        engine's AZSP_FEAT_F16_SPLIT tensor is unpacked to NCHW fp32 planes first (its hi plane holds the 0 / 1 observation planes)."""
+        if split_features is not None:
+            B, n = split_features
+            cin = self.w[0].shape[1]
+            planes = planes[: B * 2 * 32 * n * n].view(B, 2, 4, n * n, 8)[:, 0].permute(0, 1, 3, 2).reshape(B, 32, n, n)[:, :cin].float()
+        return self.forward(planes, priors_out, values_out)
+
+    def _blocks_split(self, a, m, o, B, S, C, st, rr=None, probe=None):
         """All residual blocks on split-layout buffers; returns the buffer holding the tower output."""
         dll, ck = self.binding.dll, self._ck
         for i in range(self.n_blocks):
-            ck(dll.azsp_conv3x3_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b32[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, st),
+            ck(dll.azsp_conv3x3_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b_sp[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, rr, st),
                "azsp_conv3x3_split")
-            ck(dll.azsp_conv3x3_split(m.data_ptr(), self.wsp[2 * i + 1].data_ptr(), self.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
-                                      B, S, C, 1, st), "azsp_conv3x3_split")
+            if probe is not None:
+                probe(m, B)
+            ck(dll.azsp_conv3x3_split(m.data_ptr(), self.wsp[2 * i + 1].data_ptr(), self.b_sp[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(),
+                                      B, S, C, 1, rr, st), "azsp_conv3x3_split")
+            if probe is not None:
+                probe(o, B)
             a, o = o, a
         return a
 
@@ -410,6 +533,8 @@ class InferenceNet(nn.Module):
             if (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_TOWER_SHAPES:
                 return ("fp32 class: hand-written split-precision tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 "
                         "accumulation) behind a library fp32 stem and heads")
+        if self.split_fallback_reason:
+            return f"library fp32 convolutions + azsp_bias_act epilogue (fp32-class kernels given up for this network: {self.split_fallback_reason})"
         return f"library convolutions + azsp_bias_act epilogue (no hand-written kernel for {self.filters} filters on {board_size}x{board_size}, {self.dtype})"
 
     def supports_tiled_features(self, board_size, device):
@@ -500,17 +625,23 @@ class InferenceNet(nn.Module):
 
     def _tower_split(self, x, slot=3):
         """The whole residual tower of an fp32 network on the split layout (azsp_split_layout / azsp_conv3x3_split): activations are
-        converted once on entry and once on exit; x is channels-last fp32 [B,C,S,S] and is overwritten with the tower's output."""
+        converted once on entry and once on exit; x is channels-last fp32 [B,C,S,S] and is overwritten with the tower's output.
+        (The evaluator of shapes whose stem or heads have no split kernel: a library stem and heads around the hand-written tower.)"""
         import ctypes
 
         dll, ck = self.binding.dll, self._ck
         st = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rr = self._range_ptr(x.device)
         B, C, S = x.shape[0], x.shape[1], x.shape[2]
         (a, m, o), _, _, _ = self._split_buffers(B, S, C, x.device, slot)
         self._split = (a, m, o, B)
-        ck(dll.azsp_split_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, st), "azsp_split_layout")
-        a = self._blocks_split(a, m, o, B, S, C, st)
-        ck(dll.azsp_split_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, st), "azsp_split_layout")
+        if self.act_shift:
+            x.mul_(2.0 ** -self.act_shift)  # exact; the tower biases b_sp carry the same factor
+        ck(dll.azsp_split_layout(x.data_ptr(), a.data_ptr(), B, S, C, 1, rr, st), "azsp_split_layout")
+        a = self._blocks_split(a, m, o, B, S, C, st, rr)
+        ck(dll.azsp_split_layout(a.data_ptr(), x.data_ptr(), B, S, C, 0, rr, st), "azsp_split_layout")
+        if self.act_shift:
+            x.mul_(2.0 ** self.act_shift)
         return x
 
     @torch.no_grad()

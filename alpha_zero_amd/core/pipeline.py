@@ -61,7 +61,7 @@ class SelfPlayActor:
                  c_puct_base=19652.0, c_puct_init=1.25, warm_up_steps=16, check_resign_after_steps=40, disable_resign_ratio=0.1,
                  resign_threshold=-1.0, komi=7.5, num_to_win=5, seed=1, rank=0, device="cuda", net_dtype=torch.float32,
                  use_graph=True, training_steps=0, binding=None, root_noise=True, deterministic=False, tiled_features=None, engine_kw=None,
-                 use_split_evaluator=True):
+                 use_split_evaluator=True, auto_widen=None):
         """net_dtype: precision class of the leaf evaluator.  The default is the REFERENCE'S: fp32 (pipeline.py:91-123 evaluates in fp32,
         no autocast anywhere) -- on the hand-written split-precision kernels (hi + lo f16 pairs, three MFMA products, fp32 accumulation:
         include/azsp.h azsp_conv3x3_split) for 9x9 x {128, 64} and 13x13 Gomoku x 64 networks, on library fp32 convolutions (announced
@@ -69,7 +69,10 @@ class SelfPlayActor:
         tiled_features: None = the engine writes its observation planes in the evaluator's own input layout whenever the network / board
         shape has hand-written kernels (tiled bf16 / f16, or the fp32-class stem's split layout); False = always NCHW planes.
         use_split_evaluator: False = an fp32 network is evaluated by the LIBRARY's fp32 convolutions even where the split-precision
-        kernels exist (comparison runs: bench.py's fp32_library_companion, tests/test_precision_parity.py)."""
+        kernels exist (comparison runs: bench.py's fp32_library_companion, tests/test_precision_parity.py).
+        auto_widen: networks of a width without hand-written kernels run as a function-preserving widened copy (network.widen_for_kernels).
+        None = on the GPU whenever the widened network actually reaches hand-written kernels (not for library comparison runs, not when
+        the caller disabled the kernels' feature layouts); True / False force it."""
         from .. import _lib
 
         self.binding = binding or _lib.load(require_gpu=True)
@@ -77,11 +80,14 @@ class SelfPlayActor:
         self.game, self.komi, self.resign_threshold = game, komi, resign_threshold
         self.net_dtype = net_dtype
         self.use_graph = use_graph and self.device.type == "cuda"
-        self.auto_widen = self.device.type == "cuda"  # widths without kernels run function-preservingly widened (network.widen_for_kernels)
+        self.use_split_evaluator = bool(use_split_evaluator)
+        if auto_widen is None:  # widening only pays when the wider network lands on hand-written kernels
+            auto_widen = (self.device.type == "cuda" and tiled_features is not False
+                          and (net_dtype != torch.float32 or self.use_split_evaluator))
+        self.auto_widen = bool(auto_widen)
         self.board_size = board_size
         wnet, self._widen_note = widen_for_kernels(network, board_size, net_dtype) if self.auto_widen else (network, "")
         probe = InferenceNet(wnet, dtype=net_dtype, binding=self.binding if self.device.type == "cuda" else None)
-        self.use_split_evaluator = bool(use_split_evaluator)
         probe.use_split_tower = self.use_split_evaluator
         self.tiled_features = probe.supports_tiled_features(board_size, self.device) if tiled_features is None else bool(tiled_features)
         # fp32-class evaluator: the engine writes the stem's input layout itself (AZSP_FEAT_F16_SPLIT; 0 / 1 planes are exact f16 values)
@@ -110,7 +116,8 @@ class SelfPlayActor:
         self._graph = None
         self.rounds = 0
         self.straddled_games = 0  # harvested games that were in progress across a weight hot-swap (see harvest())
-        self.range_events, self.range_max_abs = 0, 0.0  # fp32-class evaluator: clamped out-of-range activations seen so far (_check_evaluator_range)
+        # fp32-class evaluator: clamped out-of-range activations seen so far and the rescalings they triggered (_check_evaluator_range)
+        self.range_events, self.range_max_abs, self.range_rescales = 0, 0.0, 0
         self.drop_straddling_games = False
         self.set_network(network, training_steps)
 
@@ -136,12 +143,35 @@ class SelfPlayActor:
         if e.features_tiled:
             self.infer.forward_tiled(e.features, e.rows, e.N, e.priors, e.values)
         elif e.features_split:
+            if self.infer.split_fallback_reason:  # calibration gave the fp32-class kernels up for this network: library fp32 convolutions
+                self.infer._forward_after_split_fallback(e.features, e.priors, e.values, (e.rows, e.N))
+                return
             if not self.infer.supports_split_features(e.N, self.device):  # (someone switched the split kernels off on the live InferenceNet)
                 raise RuntimeError("the engine writes the split-precision stem's input layout; build the actor with use_split_evaluator=False "
                                    "to evaluate an fp32 network on the library")
             self.infer.forward_split(e.features, e.priors, e.values, split_features=(e.rows, e.N))
         else:
             self.infer(e.features, e.priors, e.values)
+
+    def _calibrate(self):
+        """fp32-class evaluator: one calibration pass on the leaf batch the engine has just written (InferenceNet.calibrate_activation_scale)
+        fixes the power-of-two activation scale of this network BEFORE its first forward is used (and before a hipGraph is captured)."""
+        e, inf = self.engine, self.infer
+        if not (e.features_split and not inf.act_calibrated and inf.supports_split_features(e.N, self.device)):
+            return
+        inf.calibrate_activation_scale(e.features, split_features=(e.rows, e.N), slot=0)
+        self._note_evaluator_path()
+
+    def _note_evaluator_path(self):
+        inf = self.infer
+        if inf.split_fallback_reason:
+            import warnings
+
+            self.evaluator_path = inf.evaluator_path(self.board_size, self.device) + self._widen_note
+            warnings.warn(f"alpha_zero_amd: evaluator falls back to {self.evaluator_path}", RuntimeWarning, stacklevel=3)
+            self._graph = None
+        elif inf.act_shift and "activations carried" not in self.evaluator_path:
+            self.evaluator_path += f"; activations carried x 2^-{inf.act_shift} (exact rescaling, calibrated max |v| = {inf.act_max_abs:.4g})"
 
     def _capture(self):
         e = self.engine
@@ -169,6 +199,8 @@ class SelfPlayActor:
         e.select()
         if evs is not None:
             evs[2].record()
+        if not self.infer.act_calibrated:
+            self._calibrate()
         if self.use_graph:
             if self._graph is None:
                 self._capture()
@@ -193,21 +225,38 @@ class SelfPlayActor:
         return (st.clone(), pi.clone(), z.clone(), games) if clone else (st, pi, z, games)
 
     def _check_evaluator_range(self):
-        """fp32-class evaluator: its kernels carry values as f16 pairs and clamp what exceeds +-65504 -- the reference's fp32 network
-        would carry such a value on.  The kernels record every such event (azsp_split_range_status); it is polled here, once per
-        harvest (the harvest has synchronised the stream already), counted in `range_events` and announced: never silent."""
-        if self.device.type != "cuda" or self.net_dtype != torch.float32 or not self.infer.supports_split_features(self.board_size, self.device):
+        """fp32-class evaluator: its kernels carry values as f16 pairs and clamp what exceeds +-65504 (in units of 2^act_shift) -- the
+        reference's fp32 network would carry such a value on.  The kernels record every such event in THIS network's range record
+        (InferenceNet.range_rec; another actor or evaluator in the same process has its own); it is polled here, once per harvest (the
+        harvest has synchronised the stream already).  An event is counted, announced and ACTED on: the network is re-calibrated on
+        the current leaf batch (a larger exact power-of-two activation scale), or, if the format cannot carry it, handed to the
+        library's fp32 convolutions -- the actor never keeps playing on a clamping evaluator."""
+        inf = self.infer
+        if (self.device.type != "cuda" or self.net_dtype != torch.float32 or inf.binding is None or not inf.use_split_tower
+                or inf.split_fallback_reason or not hasattr(inf, "range_rec")):
             return
-        with torch.cuda.device(self.device):  # the record is a per-device symbol: read the one of THIS actor's device
-            ev, mx = self.infer.split_range_status(reset=True)
-        if ev:
-            import warnings
+        ev, mx = inf.split_range_status(reset=True)
+        if not ev:
+            return
+        import warnings
 
-            self.range_events += ev
-            self.range_max_abs = max(self.range_max_abs, mx)
-            warnings.warn(f"alpha_zero_amd: the fp32-class evaluator clamped {ev} activation lanes beyond f16's range (largest |v| = {mx:.6g}); "
-                          "the reference's fp32 network would have carried them -- evaluate this network with use_split_tower = False",
-                          RuntimeWarning, stacklevel=3)
+        self.range_events += ev
+        self.range_max_abs = max(self.range_max_abs, mx * 2.0 ** inf.act_shift)
+        old_shift = inf.act_shift
+        e = self.engine
+        if e.features_split and inf.supports_split_features(e.N, self.device):
+            inf.act_calibrated = False
+            inf.set_act_shift(min(inf.MAX_ACT_SHIFT, old_shift + 2))  # at least 4x more room, then whatever the calibration asks for
+            inf.calibrate_activation_scale(e.features, split_features=(e.rows, e.N), slot=0)
+            self.range_rescales += 1
+            self._note_evaluator_path()
+            what = (f"falls back to the library's fp32 convolutions ({inf.split_fallback_reason})" if inf.split_fallback_reason
+                    else f"activation scale raised 2^-{old_shift} -> 2^-{inf.act_shift}")
+        else:
+            what = "evaluate this network with use_split_tower = False"
+        warnings.warn(f"alpha_zero_amd: the fp32-class evaluator clamped {ev} activation lanes beyond f16's range (largest |v| = "
+                      f"{mx * 2.0 ** old_shift:.6g}); the reference's fp32 network would have carried them -- {what}",
+                      RuntimeWarning, stacklevel=3)
 
     def harvest(self, with_moves=False):
         """Finished games as the reference actor emits them: [(game_seq: list[Transition], stats: dict)]

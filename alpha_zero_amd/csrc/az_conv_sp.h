@@ -106,17 +106,24 @@ __device__ __forceinline__ void sp_split(float v, _Float16& h, _Float16& l) {
     l = (_Float16)((v - (float)h) * SP_SCALE);     // the difference is exact in fp32
 }
 __device__ __forceinline__ float sp_join(_Float16 h, _Float16 l) { return fmaf((float)l, SP_INV_SCALE, (float)h); }
-// Sticky range record of the split-precision evaluator (read and reset by azsp_split_range_status): [0] = number of lanes that met a
-// value beyond f16's finite range while splitting it (the value was clamped to +-65504 where the reference's fp32 network would carry
-// it on), [1] = the bits of the largest such |v| (positive floats order like unsigned integers).  Every kernel that splits values
-// keeps the largest |v| it produced in a register (one v_max_f32 per element) and reports once, at its end, if that exceeded the range.
+// Sticky range record of the split-precision evaluator: two device words, [0] = number of lanes that met a value beyond f16's
+// finite range while splitting it (the value was clamped to +-65504 where the reference's fp32 network would carry it on), [1] = the
+// bits of the largest such |v| (positive floats order like unsigned integers).  Every kernel that splits values keeps the largest |v|
+// it produced in a register (one v_max_f32 per element) and reports once, at its end, if that exceeded the range.  The record is the
+// CALLER'S (the `range_rec` argument of the azsp_*_split entries: one per network, so that two evaluators in one process never see
+// each other's events; read / reset with azsp_split_range_read); a null pointer selects the library's per-device default record
+// g_sp_range (azsp_split_range_status).
 __device__ unsigned g_sp_range[2];
-__device__ __forceinline__ void sp_range_report(float mx) {
-    if (mx > SP_F16_MAX) {  // (rare: one atomic pair per lane that saw an overflow; NaN compares false and is not a range event)
-        atomicAdd(&g_sp_range[0], 1u);
-        atomicMax(&g_sp_range[1], __float_as_uint(mx));
+__device__ __forceinline__ void sp_range_report(float mx, unsigned* rec) {
+    if (mx > SP_F16_MAX) {  // (rare: one atomic pair per lane that saw an overflow; +inf counts -- the callers map NaN inputs to +inf)
+        unsigned* r = rec ? rec : g_sp_range;
+        atomicAdd(&r[0], 1u);
+        atomicMax(&r[1], __float_as_uint(mx));
     }
 }
+// |v| for the range record of values that arrive from OUTSIDE the evaluator (azsp_split_layout / azsp_split_features): a NaN is an
+// event too (v_max_f32 would drop it; the clamp of sp_split turns it into -65504)
+__device__ __forceinline__ float sp_range_abs(float v) { return v != v ? __builtin_inff() : fabsf(v); }
 __device__ __forceinline__ unsigned sp_pack(_Float16 a, _Float16 b) { return __builtin_bit_cast(unsigned, (sp_f16x2){a, b}); }
 __device__ __forceinline__ _Float16 sp_lo16(unsigned v) { return __builtin_bit_cast(sp_f16x2, v)[0]; }
 __device__ __forceinline__ _Float16 sp_hi16(unsigned v) { return __builtin_bit_cast(sp_f16x2, v)[1]; }
@@ -161,7 +168,8 @@ template <int P_OPS, int S0, int AVAIL> struct SpSpread {
 // fp32 channels-last rows [boards * P2][C] <-> split layout; one thread per (board, chunk, position), positions fastest
 // (the 16-byte accesses of the split side are contiguous per chunk strip)
 __global__ void __launch_bounds__(256)
-k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long nchunks, int to_split, int nch, int p2) {
+k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long nchunks, int to_split, int nch, int p2,
+               unsigned* range) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nchunks) return;
     const long long b = i / ((long long)nch * p2);
@@ -176,10 +184,10 @@ k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict_
         float mx = 0.0f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            mx = fmaxf(mx, fabsf(f[e]));
+            mx = fmaxf(mx, sp_range_abs(f[e]));
             sp_split(f[e], h[e], l[e]);
         }
-        sp_range_report(mx);
+        sp_range_report(mx, range);
         *(cv_u32x4*)(dst + so) = (cv_u32x4){sp_pack(h[0], h[1]), sp_pack(h[2], h[3]), sp_pack(h[4], h[5]), sp_pack(h[6], h[7])};
         *(cv_u32x4*)(dst + so + plane) = (cv_u32x4){sp_pack(l[0], l[1]), sp_pack(l[2], l[3]), sp_pack(l[4], l[5]), sp_pack(l[6], l[7])};
     } else {
@@ -199,7 +207,7 @@ k_split_layout(const unsigned char* __restrict__ src, unsigned char* __restrict_
 // Observation planes [boards][Cin][P2] fp32 (NCHW, what the engine's AZSP_FEAT_F32 features are) -> split layout with 32 channels
 // (4 chunks; channels >= Cin zero) = the stem's input.  One thread per (board, chunk, position), positions fastest.
 __global__ void __launch_bounds__(256)
-k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst, long long nitems, int cin, int p2) {
+k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst, long long nitems, int cin, int p2, unsigned* range) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nitems) return;
     const long long b = i / (4 * p2);
@@ -210,10 +218,10 @@ k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst,
     for (int e = 0; e < 8; ++e) {
         const int ch = 8 * c + e;
         const float v = ch < cin ? src[((size_t)b * cin + ch) * p2 + p] : 0.0f;
-        mx = fmaxf(mx, fabsf(v));
+        mx = fmaxf(mx, sp_range_abs(v));
         sp_split(v, h[e], l[e]);
     }
-    sp_range_report(mx);
+    sp_range_report(mx, range);
     const size_t plane = (size_t)4 * p2 * 16, so = (size_t)b * 2 * plane + ((size_t)c * p2 + p) * 16;
     *(cv_u32x4*)(dst + so) = (cv_u32x4){sp_pack(h[0], h[1]), sp_pack(h[2], h[3]), sp_pack(h[4], h[5]), sp_pack(h[6], h[7])};
     *(cv_u32x4*)(dst + so + plane) = (cv_u32x4){sp_pack(l[0], l[1]), sp_pack(l[2], l[3]), sp_pack(l[4], l[5]), sp_pack(l[6], l[7])};
@@ -225,20 +233,20 @@ k_split_features(const float* __restrict__ src, unsigned char* __restrict__ dst,
 // BPB boards per 256-thread workgroup (the fully connected weights, stored TRANSPOSED [inputs][outputs] so that neighbouring threads
 // read neighbouring outputs, are streamed from L2 once per BPB boards; BPB = 8 was measured SLOWER than 4 at 17x17 (1.77 vs 1.15 ms:
 // fewer, longer workgroups -- the fully connected loop is latency-bound, not traffic-bound); plain fp32 FMAs -- HBM-bound (2 x C x P2 x 2 bytes per board).
-// dynamic LDS: 3 C + BPB (3 ceil4(P2) + A + F) floats.
+// The 3 x C weights of the 1x1 convolutions are read through wave-uniform (scalar) loads straight from global memory, as k_head_tiled
+// does since round 4: no product kernel keeps a wave-uniformly read LDS weight table.  LDS holds only data the workgroup
+// itself produced (head planes, logits).  dynamic LDS: BPB (3 ceil4(P2) + A + F) floats.
 template <int BPB> __global__ void __launch_bounds__(256)
 k_head_split(const unsigned char* __restrict__ x, const float* __restrict__ hw, const float* __restrict__ hb, const float* __restrict__ wp_t,
              const float* __restrict__ bp, const float* __restrict__ w1_t, const float* __restrict__ b1, const float* __restrict__ w2, float b2,
              float* __restrict__ priors, float* __restrict__ values, long long boards, int C, int P2, int A, int F, int npol) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int P2P = (P2 + 3) & ~3;                   // a head plane's row in LDS, padded to 16 bytes: the fully connected loop reads float4s
-    float* ws = sm;                                  // [3][C]
-    float* hp = ws + 3 * C;                          // [BPB][3][P2P]
+    const float* __restrict__ ws = hw;               // [3][C], wave-uniform indices below -> s_load
+    float* hp = sm;                                  // [BPB][3][P2P]
     float* out = hp + BPB * 3 * P2P;                 // [BPB][A + F]
     const int tid = threadIdx.x, nch = C / 8;
     const long long b0 = (long long)blockIdx.x * BPB;
-    for (int i = tid; i < 3 * C; i += 256) ws[i] = hw[i];
-    __syncthreads();
     const size_t plane = (size_t)nch * P2 * 16;
     // head planes: one thread per (board, position) computes all three planes from ONE pass over the position's C channels (the first
     // version walked (board, plane, position) items and read every activation three times: 1.13 ms per forward at 17x17, rocprofv3 round 4)
@@ -378,7 +386,7 @@ template <bool RES, int NCH, bool XLO0 = false> __host__ __device__ constexpr in
 // AZSP_FEAT_F16_SPLIT) -- the lo strips are not loaded, their fragments not read and the w_hi x_lo product is skipped (it is exactly zero).
 template <bool RES, int NCH, int NCG, bool XLO0 = false> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
-             const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu) {
+             const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int ntiles, int relu, unsigned* range) {
     typedef SpGeo9 G;
     constexpr int C = 64 * NCG, CIN = 8 * NCH, KSUB = NCH / 4;
     constexpr int KS = 9 * KSUB;                             // k-steps per unit (one tap x 32 input channels)
@@ -707,7 +715,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     for (int j = 0; j < NJ1; ++j)
 #pragma unroll
         for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, NJ0 + j, yprev, o, true);
-    sp_range_report(mx);
+    sp_range_report(mx, range);
 }
 
 #endif  // __HIPCC__

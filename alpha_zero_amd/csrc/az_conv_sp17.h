@@ -156,7 +156,7 @@ template <bool RES, int NCH, bool XLO0 = false> __host__ __device__ constexpr in
 // product are skipped (see k_conv3x3_sp).
 template <bool RES, int NCH, bool XLO0 = false> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
-               const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int nboards, int relu) {
+               const unsigned char* __restrict__ res, unsigned char* __restrict__ y, int nboards, int relu, unsigned* range) {
     typedef Sp17Geo G;
     constexpr int C = 64, CIN = 8 * NCH, KSUB = NCH / 4;
     constexpr int KS = 9 * KSUB;                             // k-steps per unit (one tap x 32 input channels)
@@ -400,6 +400,6 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
 #pragma unroll
             for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, j0 + j, yprev, o, true);
     }
-    sp_range_report(mx);
+    sp_range_report(mx, range);
 }
 #endif  // __HIPCC__

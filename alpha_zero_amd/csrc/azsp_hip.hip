@@ -277,67 +277,66 @@ int launch_tile_layout(const void* src, void* dst, long long boards, int S, int 
                        (unsigned char*)dst, nchunks, to_tiled, nch, tile_rows);
     return AZ_HIP(hipGetLastError());
 }
-int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* st) {
+int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* st, unsigned* range) {
     if (C % 8 || S < 1) return 1;
     const long long nchunks = boards * S * S * (C / 8);
     hipLaunchKernelGGL(k_split_layout, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)st, (const unsigned char*)src,
-                       (unsigned char*)dst, nchunks, to_split, C / 8, S * S);
+                       (unsigned char*)dst, nchunks, to_split, C / 8, S * S, range);
     return AZ_HIP(hipGetLastError());
 }
 template <bool RES, int NCH, int NCG, bool XLO0 = false>
-static int launch_sp(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
+static int launch_sp(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st, unsigned* range) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
     long long nslot = n_cu / NCG > 0 ? n_cu / NCG : 1;  // one persistent workgroup per CU; the cout groups of a board run side by side
     if (boards < nslot) nslot = boards;
     hipLaunchKernelGGL((k_conv3x3_sp<RES, NCH, NCG, XLO0>), dim3((unsigned)(nslot * NCG)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
-                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu, range);
     return AZ_HIP(hipGetLastError());
 }
 template <bool RES, int NCH, bool XLO0 = false>
-static int launch_sp17(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st) {
+static int launch_sp17(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int relu, void* st, unsigned* range) {
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
     const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles
     hipLaunchKernelGGL((k_conv3x3_sp17<RES, NCH, XLO0>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x,
-                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+                       (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu, range);
     return AZ_HIP(hipGetLastError());
 }
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
-                         void* st) {
+                         void* st, unsigned* range) {
     if (S == Sp17Geo::S && C == 64)  // 17x17 planes x 64 filters: the 13x13 Gomoku tower (half-board tiles)
-        return res ? launch_sp17<true, 8>(x, w, bias, res, y, boards, relu, st) : launch_sp17<false, 8>(x, w, bias, res, y, boards, relu, st);
+        return res ? launch_sp17<true, 8>(x, w, bias, res, y, boards, relu, st, range) : launch_sp17<false, 8>(x, w, bias, res, y, boards, relu, st, range);
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
-    if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st);
-    return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st);
+    if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st, range);
+    return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st, range);
 }
-int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st) {
+int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st, unsigned* range) {
     if (cin < 1 || cin > 32 || S < 1) return 1;
     const long long nitems = boards * 4 * S * S;
     hipLaunchKernelGGL(k_split_features, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, (hipStream_t)st, src, (unsigned char*)dst, nitems, cin,
-                       S * S);
+                       S * S, range);
     return AZ_HIP(hipGetLastError());
 }
 int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* st,
-                      int x_lo_zero) {
+                      int x_lo_zero, unsigned* range) {
     if (S == 13 && C == 64 && pad == 3)  // 13x13 boards -> 17x17 planes
-        return x_lo_zero ? launch_sp17<false, 4, true>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp17<false, 4>(x, w, bias, nullptr, y, boards, relu, st);
+        return x_lo_zero ? launch_sp17<false, 4, true>(x, w, bias, nullptr, y, boards, relu, st, range) : launch_sp17<false, 4>(x, w, bias, nullptr, y, boards, relu, st, range);
     if (S != SpGeo9::S || (C != 128 && C != 64) || pad != 1) return 1;
     if (x_lo_zero)
-        return C == 128 ? launch_sp<false, 4, 2, true>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp<false, 4, 1, true>(x, w, bias, nullptr, y, boards, relu, st);
-    return C == 128 ? launch_sp<false, 4, 2>(x, w, bias, nullptr, y, boards, relu, st) : launch_sp<false, 4, 1>(x, w, bias, nullptr, y, boards, relu, st);
+        return C == 128 ? launch_sp<false, 4, 2, true>(x, w, bias, nullptr, y, boards, relu, st, range) : launch_sp<false, 4, 1, true>(x, w, bias, nullptr, y, boards, relu, st, range);
+    return C == 128 ? launch_sp<false, 4, 2>(x, w, bias, nullptr, y, boards, relu, st, range) : launch_sp<false, 4, 1>(x, w, bias, nullptr, y, boards, relu, st, range);
 }
-int split_range_status(unsigned out[2], int reset, void* st) {
-    if (AZ_HIP(hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(g_sp_range), 2 * sizeof(unsigned), 0, hipMemcpyDeviceToHost, (hipStream_t)st))) return -1;
-    if (reset) {
-        static const unsigned zero[2] = {0u, 0u};
-        if (AZ_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sp_range), zero, 2 * sizeof(unsigned), 0, hipMemcpyHostToDevice, (hipStream_t)st))) return -1;
-    }
+int split_range_read(const unsigned* rec, unsigned out[2], int reset, void* st) {
+    void* p = (void*)rec;  // null: the per-device default record
+    if (!p && AZ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_sp_range)))) return -1;
+    if (AZ_HIP(hipMemcpyAsync(out, p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)st))) return -1;
+    if (reset && AZ_HIP(hipMemsetAsync(p, 0, 2 * sizeof(unsigned), (hipStream_t)st))) return -1;
     return AZ_HIP(hipStreamSynchronize((hipStream_t)st));
 }
 template <int BPB> static int launch_head_split_bpb(const HeadSplitArgs& a, void* st) {
     const int P2 = a.S * a.S;
-    const size_t lds = (size_t)(3 * a.C + BPB * (3 * ((P2 + 3) & ~3) + a.A + a.F)) * sizeof(float);
+    const size_t lds = (size_t)(BPB * (3 * ((P2 + 3) & ~3) + a.A + a.F)) * sizeof(float);
     if (lds > 64 * 1024) return 1;
     hipLaunchKernelGGL((k_head_split<BPB>), dim3((unsigned)((a.boards + BPB - 1) / BPB)), dim3(256), lds, (hipStream_t)st, (const unsigned char*)a.x, a.hw,
                        a.hb, a.wp_t, a.bp, a.w1_t, a.b1, a.w2, a.b2, a.priors, a.values, a.boards, a.C, P2, a.A, a.F, a.npol);

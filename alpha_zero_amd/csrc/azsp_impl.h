@@ -547,9 +547,10 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
 int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
                           void* stream);
 int launch_tile_layout(const void* src, void* dst, long long boards, int S, int C, int to_tiled, void* stream);
-int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* stream);
+// range: the caller's range record (two device words: events, bits of the largest |v|), null = the per-device default record
+int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* stream, unsigned* range);
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
-                         void* stream);
+                         void* stream, unsigned* range);
 struct HeadSplitArgs {
     const void* x;
     const float *hw, *hb, *wp_t, *bp, *w1_t, *b1, *w2;
@@ -558,10 +559,10 @@ struct HeadSplitArgs {
     long long boards;
     int S, C, A, F, npol;
 };
-int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* stream);
+int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* stream, unsigned* range);
 int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
-                      int x_lo_zero = 0);
-int split_range_status(unsigned out[2], int reset, void* stream);  // synchronises the stream
+                      int x_lo_zero, unsigned* range);
+int split_range_read(const unsigned* rec, unsigned out[2], int reset, void* stream);  // rec null = the default record; synchronises the stream
 int launch_head_split(const HeadSplitArgs& a, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
                       int f16 = 0);
@@ -1049,50 +1050,57 @@ int64_t azsp_split_bytes(int64_t boards, int32_t S, int32_t C) {
     return boards * 2 * (int64_t)S * S * C * 2;
 }
 
-int azsp_split_layout(const void* src, void* dst, int64_t boards, int32_t S, int32_t C, int32_t to_split, void* stream) {
+int azsp_split_layout(const void* src, void* dst, int64_t boards, int32_t S, int32_t C, int32_t to_split, uint32_t* range_rec, void* stream) {
     if (!src || !dst || boards < 0 || boards > 0x7fffffff || S <= 0 || C <= 0 || C % 8) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_split_layout(src, dst, (long long)boards, S, C, to_split, stream);
+    const int rc = azb::launch_split_layout(src, dst, (long long)boards, S, C, to_split, stream, range_rec);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
 int azsp_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, int64_t boards, int32_t S, int32_t C,
-                       int32_t relu, void* stream) {
+                       int32_t relu, uint32_t* range_rec, void* stream) {
     if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    // 17x17: 15 of a board's 304 column slots repeat a position of an EARLIER column tile, whose store has happened by the time the
+    // repeat loads its residual -- in place (residual == y) the repeat would add the skip twice.  Refused, not silently wrong.
+    if (S == 17 && res == y) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_conv3x3_split(x, w, bias, res, y, (long long)boards, S, C, relu, stream);
+    const int rc = azb::launch_conv3x3_split(x, w, bias, res, y, (long long)boards, S, C, relu, stream, range_rec);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
-int azsp_split_features(const float* planes, void* dst, int64_t boards, int32_t S, int32_t cin, void* stream) {
+int azsp_split_features(const float* planes, void* dst, int64_t boards, int32_t S, int32_t cin, uint32_t* range_rec, void* stream) {
     if (!planes || !dst || boards < 0 || boards > 0x7fffffff || S <= 0 || cin < 1 || cin > 32) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_split_features(planes, dst, (long long)boards, S, cin, stream);
+    const int rc = azb::launch_split_features(planes, dst, (long long)boards, S, cin, stream, range_rec);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
 int azsp_stem_split(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
-                    void* stream) {
+                    uint32_t* range_rec, void* stream) {
     if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream);
+    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream, 0, range_rec);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
 int azsp_stem_split_exact(const void* x, const void* w, const float* bias, void* y, int64_t boards, int32_t S, int32_t C, int32_t pad, int32_t relu,
-                          void* stream) {
+                          uint32_t* range_rec, void* stream) {
     if (!x || !w || !bias || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
-    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream, 1);
+    const int rc = azb::launch_stem_split(x, w, bias, y, (long long)boards, S, C, pad, relu, stream, 1, range_rec);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 
-int azsp_split_range_status(uint32_t* events, float* max_abs, int32_t reset, void* stream) {
+int azsp_split_range_read(const uint32_t* range_rec, uint32_t* events, float* max_abs, int32_t reset, void* stream) {
     unsigned r[2] = {0u, 0u};
-    if (azb::split_range_status(r, reset, stream) != 0) return AZSP_EDEVICE;
+    if (azb::split_range_read(range_rec, r, reset, stream) != 0) return AZSP_EDEVICE;
     if (events) *events = r[0];
     if (max_abs) memcpy(max_abs, &r[1], sizeof(float));
     return AZSP_OK;
+}
+
+int azsp_split_range_status(uint32_t* events, float* max_abs, int32_t reset, void* stream) {
+    return azsp_split_range_read(nullptr, events, max_abs, reset, stream);
 }
 
 int azsp_head_split(const void* x, const float* head_w, const float* head_b, const float* pol_fc_wt, const float* pol_fc_b, const float* val_fc1_wt,

@@ -23,7 +23,7 @@ Before --warmup / --steps apply, an untimed, argument-independent PRE-ROLL bring
 from staggered random openings, then rounds run until every slot has committed >= 2 searched moves and >= 300 rounds have passed
 (a fresh tree needs 26 rounds to its first move; afterwards inherited sub-trees of different sizes de-phase the slots), so that
 move completions are spread evenly over rounds and a 20-round window measures the same moves/s as a 300-round one.  The timed
-region always contains at least one harvest + gather (every min(--harvest-every, --steps) rounds).
+region always contains at least two harvests + gathers (every min(--harvest-every, --steps / 2) rounds).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -208,7 +208,7 @@ def preroll(act, args, world, dev, min_rounds=None):
 
 def timed(act, args, world, dev, warmup, steps):
     """--warmup untimed rounds, then exactly --steps rounds between barrier + synchronize on both sides."""
-    h_every = max(1, min(args.harvest_every, steps))  # the timed region always pays for >= 1 harvest + gather
+    h_every = max(1, min(args.harvest_every, steps // 2))  # the timed region always pays for >= 2 harvests + gathers (1 when steps == 1)
     for i in range(warmup):
         act.run_round()
         if (i + 1) % h_every == 0:
@@ -261,8 +261,11 @@ def per_rank_report(cnt, elapsed, world, dev):
 
 
 def tower_replay(actor, args, dev, reps=5):
-    """Replays the forward's own tower launch sequence on the live activations of the last forward, one HIP event after every launch
-    (the events are recorded on the stream the kernels are launched on).  Returns None when the tower is not on hand-written kernels."""
+    """Times the dominant kernel: the forward's own tower launch sequence, one HIP event after every launch (recorded on the stream the
+    kernels are launched on), on the REAL activations of the last forward -- the tower input that forward's stem produced is kept in a
+    copy and every repetition restarts from it, so each timed launch sees exactly the data it sees inside the step (round 4 chained the
+    repetitions on their own output: a 50-block-deep random network whose activations left f16's range and tripped the range record).
+    Returns None when the tower is not on hand-written kernels.  The network's range record is left as it was found."""
     import ctypes
 
     inf, dll = actor.infer, actor.binding.dll
@@ -275,36 +278,79 @@ def tower_replay(actor, args, dev, reps=5):
     if not (split or tiled):
         return None
     fused = tiled and inf.use_fused_block and (args.filters, S_t) in ((64, 17), (64, 9)) and args.net_dtype == "bf16"  # one launch per ResNetBlock
+    e = actor.engine
+    # re-create the forward's tower input: run the stem of the engine-facing forward once more on the live features (slot 0's buffer `a`)
     if split:
         (a, m, o), _, _, _ = inf._split_buffers(rows, S_t, args.filters, dev, 0)  # slot 0 = the engine-facing forward's buffers
-        conv_fn, wts = dll.azsp_conv3x3_split, inf.wsp
+        rr = inf._range_ptr(dev)
+        assert dll.azsp_stem_split_exact(e.features.data_ptr(), inf.stem_wsp.data_ptr(), inf.stem_b_sp.data_ptr(), a.data_ptr(), rows, n, args.filters,
+                                         inf.stem_pad, 1, rr, st) == 0
+        conv_fn = lambda x, i, r, y: dll.azsp_conv3x3_split(x.data_ptr(), inf.wsp[i].data_ptr(), inf.b_sp[i].data_ptr(),  # noqa: E731
+                                                            None if r is None else r.data_ptr(), y.data_ptr(), rows, S_t, args.filters, 1, rr, st)
     else:
         a, m, o = inf._tiled
-        conv_fn, wts = (dll.azsp_conv3x3_tiled_f16 if args.net_dtype == "fp16" else dll.azsp_conv3x3_tiled), inf.wp
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps * inf.n_blocks + 1)]
+        stem = dll.azsp_stem_tiled_f16 if args.net_dtype == "fp16" else dll.azsp_stem_tiled
+        assert stem(e.features.data_ptr(), inf.stem_wp.data_ptr(), inf.stem_b32.data_ptr(), a.data_ptr(), rows, n, args.filters, inf.stem_pad, 1, st) == 0
+        fn = dll.azsp_conv3x3_tiled_f16 if args.net_dtype == "fp16" else dll.azsp_conv3x3_tiled
+        conv_fn = lambda x, i, r, y: fn(x.data_ptr(), inf.wp[i].data_ptr(), inf.b32[i].data_ptr(), None if r is None else r.data_ptr(),  # noqa: E731
+                                        y.data_ptr(), rows, S_t, args.filters, 1, st)
+    x0 = a.clone()  # the tower input of a real forward
+    a0, o0 = a, o
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2 * inf.n_blocks + 1)] for _ in range(reps)]
     torch.cuda.synchronize(dev)
-    k = 0
-    ev[0].record()
-    for _ in range(reps):
+    d = []
+    for rep in range(reps):
+        a, o = a0, o0
+        a.copy_(x0)  # every repetition = the forward's tower on the forward's own input (untimed copy)
+        k = 0
+        ev[rep][0].record()
         for i in range(inf.n_blocks):  # the forward's own launch sequence
             if fused:
                 assert dll.azsp_resblock_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), inf.wp[2 * i + 1].data_ptr(),
                                                inf.b32[2 * i + 1].data_ptr(), o.data_ptr(), rows, S_t, args.filters, st) == 0
                 k += 1
-                ev[k].record()
+                ev[rep][k].record()
                 a, o = o, a
                 continue
-            assert conv_fn(a.data_ptr(), wts[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), None, m.data_ptr(), rows, S_t, args.filters, 1, st) == 0
+            assert conv_fn(a, 2 * i, None, m) == 0
             k += 1
-            ev[k].record()
-            assert conv_fn(m.data_ptr(), wts[2 * i + 1].data_ptr(), inf.b32[2 * i + 1].data_ptr(), a.data_ptr(), o.data_ptr(), rows, S_t, args.filters, 1, st) == 0
+            ev[rep][k].record()
+            assert conv_fn(m, 2 * i + 1, a, o) == 0
             k += 1
-            ev[k].record()
+            ev[rep][k].record()
             a, o = o, a
-    torch.cuda.synchronize(dev)
-    d = [ev[j].elapsed_time(ev[j + 1]) for j in range(k)]
-    return {"launches": k, "avg_ms": float(np.mean(d)), "planes": S_t, "fused_block": fused, "split": split,
-            "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2]))}
+        torch.cuda.synchronize(dev)
+        d += [ev[rep][j].elapsed_time(ev[rep][j + 1]) for j in range(k)]
+    del x0
+    return {"launches": len(d), "avg_ms": float(np.mean(d)), "planes": S_t, "fused_block": fused, "split": split,
+            "avg_ms_plain": None if fused else float(np.mean(d[0::2])), "avg_ms_residual": None if fused else float(np.mean(d[1::2])),
+            "data": "the real activations of a forward of the timed run (every repetition restarts from the stem's output)"}
+
+
+def evaluator_range(actor):
+    """Range record of the actor's fp32-class evaluator since the record was last read (InferenceNet.range_rec, this network's own):
+    events = kernel lanes that met |v| > 65504 (scaled units) and clamped it.  None for evaluators without the record."""
+    inf = actor.infer
+    if actor.net_dtype != torch.float32 or not hasattr(inf, "range_rec") or not inf.range_rec.is_cuda:
+        return None
+    ev, mx = inf.split_range_status(reset=True)
+    return {"events": ev + actor.range_events, "largest_abs": max(mx * 2.0 ** inf.act_shift, actor.range_max_abs), "act_shift": inf.act_shift,
+            "calibrated_max_abs": round(inf.act_max_abs, 4), "rescales_during_run": actor.range_rescales,
+            "fallback": inf.split_fallback_reason or None}
+
+
+def power_ceiling(split):
+    """MFMA-only throughput under the package power limit on this kernel's operand mix, from profiles/mfma_power_probe.json (the
+    output of tools/probes/mfma_power_probe.hip on MI355X; nothing is hard-coded here).  None when the file is absent."""
+    pth = os.path.join(ROOT, "profiles", "mfma_power_probe.json")
+    try:
+        pj = json.load(open(pth))
+        if split:
+            return {"value": float(pj["split_mix_mfma_only_tflops"]), "source": "from_profiles: profiles/mfma_power_probe.json (split-precision operand mix, f16)"}
+        v = [c["tflops"] for c in pj["cases"] if c["mfma"] == "v_mfma_f32_32x32x16_bf16" and c["operands"].startswith("A dense")]
+        return {"value": float(v[0]), "source": "from_profiles: profiles/mfma_power_probe.json (bf16, A dense, B half zeros)"}
+    except Exception:
+        return None
 
 
 def tower_roofline(conv, args, step_ms):
@@ -367,10 +413,11 @@ def tower_roofline(conv, args, step_ms):
                 "avg_launch_ms_plain": round(conv["avg_ms_plain"], 4) if conv["avg_ms_plain"] is not None else None,
                 "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4) if conv["avg_ms_residual"] is not None else None,
                 "launches_per_step": launches_per_step, "share_of_step": round(launches_per_step * conv["avg_ms"] / step_ms, 4),
-                # annotation, not a measurement of this run: the MFMA-only ceiling on post-ReLU-like operands at the 1400 W package limit,
-                # measured by tools/probes/mfma_power_probe.hip
-                "power_limited_mfma_only_tflops": {"value": 1840.0, "source": "from_profiles: profiles/r02_mfma_power_probe.txt"},
-                "frac_of_power_limited_ceiling": round(tf / 1840.0, 4)}
+                "timed_on": conv.get("data"),
+                # annotation, not a measurement of this run: the MFMA-only ceiling on this kernel's operand mix at the package power limit,
+                # measured by tools/probes/mfma_power_probe.hip and read from its committed output
+                "power_limited_mfma_only_tflops": power_ceiling(split),
+                "frac_of_power_limited_ceiling": (round(tf / power_ceiling(split)["value"], 4) if power_ceiling(split) else None)}
     roofline.update(extra)
     return roofline
 
@@ -378,6 +425,7 @@ def tower_roofline(conv, args, step_ms):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    rc_fail = False
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -441,6 +489,8 @@ def main(argv=None):
     eng = actor.engine
     preroll_rounds = preroll(actor, args, world, dev)
     elapsed, cnt, evs, samples_at_root = timed(actor, args, world, dev, args.warmup, args.steps)
+    # range record of the HEADLINE actor's evaluator over pre-roll + warm-up + timed region, read before anything else touches the network
+    erange = evaluator_range(actor)
     bk_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))  # expand/backup + end-of-move kernels
     k_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))   # select kernel (the dominant hand-written kernel)
     nn_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
@@ -452,6 +502,10 @@ def main(argv=None):
 
     # ---- dominant kernel (the tower convolution): average launch duration, HIP events on the launch stream -----------
     conv = tower_replay(actor, args, dev) if rank == 0 else None
+    replay_range = None
+    if rank == 0 and erange is not None:  # (the replay runs the forward's own launches on its own data: expected 0 too); leaves the record clean
+        ev_r, mx_r = actor.infer.split_range_status(reset=True)
+        replay_range = {"events": ev_r, "largest_abs": mx_r * 2.0 ** actor.infer.act_shift}
 
     if args.split_round and rank == 0:
         ea = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -610,14 +664,27 @@ def main(argv=None):
             "speedup_vs_reference_equivalent_cpu": (round(total_moves / elapsed_max / cpu["reference_equivalent_value"], 1)
                                                     if cpu and cpu.get("reference_equivalent_value") else None),
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
-            "cpu_baseline": cpu, "c1_cpu_reference_path": c1,
+            "cpu_baseline": cpu if world == 1 else "measured at N=1 only", "c1_cpu_reference_path": c1,
+            # fp32-class evaluator: lanes that met a value beyond the f16-pair format's range during pre-roll + warm-up + timed region of
+            # THIS run's headline actor (its own range record, read before the kernel replay); must be 0 for the line to be valid
+            "evaluator_range_events": erange["events"] if erange else None, "evaluator_range": erange,
+            "kernel_replay_range_events": replay_range["events"] if replay_range else None,
+            # weak scaling: value(N) = sum over ranks of moves / max over ranks of time; the only inter-rank work is harvest + gather
+            "expected_value_formula": "value(N) ~= N * value(1) * (1 - per_rank.harvest_gather_share_of_time)" if world > 1 else None,
         }
         print(json.dumps(line), flush=True)
+        if erange and erange["events"]:
+            # the timed forward clamped activations: the number is not the fp32-class evaluator's (the actor has rescaled / fallen back
+            # for the rounds after the event, see evaluator_range) -- fail loudly instead of reporting it as valid
+            print(f"bench.py: ERROR the evaluator clamped {erange['events']} activation lanes inside the measured run", file=sys.stderr, flush=True)
+            rc_fail = True
     if pg_active():
         import torch.distributed as dist
 
         dist.barrier()
         dist.destroy_process_group()
+    if rc_fail:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -273,19 +273,24 @@ int azsp_resblock_tiled(const void* x_dev, const void* w1_packed_dev, const floa
  * accumulated in fp32: 22-bit significands, per-product error <= 3 * 2^-22, i.e. fp32 round-off class (bounded against fp64 next to
  * the library's fp32 convolution in tests/test_split_tower.py).  RANGE: a value beyond f16's finite range (|v| > 65504) cannot be
  * split; it is clamped to +-65504 where the reference's fp32 network would carry it on.  That never happens silently: every kernel
- * that splits values records such an event in a sticky device-side record, see azsp_split_range_status below (BatchNorm-folded
- * AlphaZero towers stay far inside the range: activations of the shipped networks peak at ~1e2).
+ * that splits values records such an event in a sticky device-side RANGE RECORD (below; BatchNorm-folded AlphaZero towers stay far
+ * inside the range -- activations of the shipped networks peak at ~1e2 -- and alpha_zero_amd.core.network.InferenceNet rescales a
+ * network's activations by an exact power of two when a calibration pass finds them near the limit).
  * "Split layout": [board][plane: hi, lo][C/8 channel chunks][S*S positions][8 ch] f16 = azsp_split_bytes(boards, S, C) bytes;
  * azsp_split_layout converts fp32 channels-last rows [boards][S][S][C] to (to_split = 1) / from (0) it.
- * azsp_conv3x3_split: y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y in the split layout (x must not alias y; residual
- * may), w_split [2 planes: hi, lo][9 taps (ky*3+kx)][C out][C in] f16 with lo = (w - hi) * 2048, bias float[C].  On the device:
+ * azsp_conv3x3_split: y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y in the split layout; x must not alias y; residual
+ * may alias y at 9x9 and must NOT at 17x17 (AZSP_EINVAL: the half-board tiles repeat 15 positions per board in later column tiles);
+ * w_split [2 planes: hi, lo][9 taps (ky*3+kx)][C out][C in] f16 with lo = (w - hi) * 2048, bias float[C].  On the device:
  * (S, C) = (9, 128), (9, 64) and (17, 64) (the 13x13 Gomoku tower behind its pad-3 stem, network.py:101-105; half-board tiles,
- * az_conv_sp17.h); AZSP_EINVAL for other shapes. */
+ * az_conv_sp17.h); AZSP_EINVAL for other shapes.
+ * range_rec_dev: the caller's range record -- two zero-initialised uint32 words in device memory, owned by the caller (one per
+ * network: two evaluators in one process never see each other's events), read with azsp_split_range_read; NULL selects the library's
+ * per-device default record (azsp_split_range_status). */
 int64_t azsp_split_bytes(int64_t boards, int32_t board_size, int32_t channels);
 int azsp_split_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t to_split,
-                      void* stream);
+                      uint32_t* range_rec_dev, void* stream);
 int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
-                       int64_t boards, int32_t board_size, int32_t channels, int32_t relu, void* stream);
+                       int64_t boards, int32_t board_size, int32_t channels, int32_t relu, uint32_t* range_rec_dev, void* stream);
 
 /* The rest of the fp32-class evaluator on the split layout (core/network.py:101-156):
  * azsp_split_features: observation planes [boards][in_channels <= 32][S][S] fp32 (the engine's AZSP_FEAT_F32 features) -> split
@@ -299,22 +304,28 @@ int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* 
  *   ReLU (head_w [3][C], head_b [3]: npol policy planes first), policy Linear + softmax over all A actions (pol_fc_wt = the Linear's
  *   weight TRANSPOSED, [npol*S*S][A], inputs in nn.Flatten order), value Linear + ReLU + Linear + tanh (val_fc1_wt transposed
  *   [(3-npol)*S*S][F], val_fc2_w [F], val_fc2_b); priors float [boards][A], values float [boards].  Any (S, C) with C % 8 == 0. */
-int azsp_split_features(const float* planes_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t in_channels, void* stream);
+int azsp_split_features(const float* planes_dev, void* dst_dev, int64_t boards, int32_t board_size, int32_t in_channels,
+                        uint32_t* range_rec_dev, void* stream);
 int azsp_stem_split(const void* x_split32_dev, const void* w_split_dev, const float* bias_dev, void* y_dev, int64_t boards, int32_t board_size,
-                    int32_t channels, int32_t pad, int32_t relu, void* stream);
+                    int32_t channels, int32_t pad, int32_t relu, uint32_t* range_rec_dev, void* stream);
 /* azsp_stem_split for inputs whose lo plane is all zero -- values that are exact in f16, i.e. the engine's AZSP_FEAT_F16_SPLIT features (0 / 1
  * observation planes): the lo plane is neither loaded nor multiplied (its product is exactly zero), the result is identical to azsp_stem_split's. */
 int azsp_stem_split_exact(const void* x_split32_dev, const void* w_split_dev, const float* bias_dev, void* y_dev, int64_t boards, int32_t board_size,
-                          int32_t channels, int32_t pad, int32_t relu, void* stream);
+                          int32_t channels, int32_t pad, int32_t relu, uint32_t* range_rec_dev, void* stream);
 int azsp_head_split(const void* x_dev, const float* head_w_dev, const float* head_b_dev, const float* pol_fc_wt_dev, const float* pol_fc_b_dev,
                     const float* val_fc1_wt_dev, const float* val_fc1_b_dev, const float* val_fc2_w_dev, float val_fc2_b, float* priors_dev,
                     float* values_dev, int64_t boards, int32_t board_size, int32_t channels, int32_t num_actions, int32_t fc_units, int32_t npol,
                     void* stream);
 
-/* Range record of the split-precision evaluator (process-wide, sticky): *events_host = how many kernel lanes have met a value with
- * |v| > 65504 since the last reset (each such value was clamped; the reference would have carried it: core/pipeline.py:91-123
- * evaluates in fp32), *max_abs_host = the largest such |v| (0 if none).  Either pointer may be NULL; reset != 0 clears the record.
- * Synchronises `stream`.  alpha_zero_amd.core.pipeline.SelfPlayActor polls it at every harvest and raises a RuntimeWarning. */
+/* Range record of the split-precision evaluator (sticky): *events_host = how many kernel lanes have met a value with |v| > 65504 (or
+ * a NaN among the fp32 inputs of azsp_split_layout / azsp_split_features, recorded as +inf) since the last reset -- each such value was
+ * clamped; the reference would have carried it: core/pipeline.py:91-123 evaluates in fp32 -- and *max_abs_host = the largest such |v|
+ * (0 if none).  Either pointer may be NULL; reset != 0 clears the record.  Synchronises `stream`.
+ * azsp_split_range_read reads the record the caller passed to the kernels as range_rec_dev (NULL = the per-device default record);
+ * azsp_split_range_status reads the default record.  alpha_zero_amd.core.network.InferenceNet owns one record per network;
+ * SelfPlayActor polls it at every harvest and, on an event, rescales the network's activations by a power of two (exact) or falls
+ * back to the library's fp32 convolutions -- see InferenceNet.calibrate_activation_scale. */
+int azsp_split_range_read(const uint32_t* range_rec_dev, uint32_t* events_host, float* max_abs_host, int32_t reset, void* stream);
 int azsp_split_range_status(uint32_t* events_host, float* max_abs_host, int32_t reset, void* stream);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch

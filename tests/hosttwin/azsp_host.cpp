@@ -88,14 +88,19 @@ int launch_resblock_tiled(const void* x, const void* w1, const float* b1, const 
     return 0;
 }
 // ---- split-precision tower (azsp_split_layout / azsp_conv3x3_split): plain loops on the same hi / lo f16 arithmetic ----
-static unsigned g_sp_range_host[2] = {0u, 0u};  // the device library's sticky range record (azsp_split_range_status), per split value here
+static unsigned g_sp_range_host[2] = {0u, 0u};  // the device library's default range record (azsp_split_range_status), per split value here
+static unsigned* g_sp_range_cur = g_sp_range_host;  // the record of the running call (the caller's `range_rec`, or the default)
+struct SpRangeScope {
+    explicit SpRangeScope(unsigned* r) { g_sp_range_cur = r ? r : g_sp_range_host; }
+    ~SpRangeScope() { g_sp_range_cur = g_sp_range_host; }
+};
 static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
-    if (fabsf(v) > 65504.0f) {
+    if (!(fabsf(v) <= 65504.0f)) {  // (a NaN is an event too, recorded as +inf: sp_range_abs in az_conv_sp.h)
         unsigned bits;
-        const float a = fabsf(v);
+        const float a = v != v ? INFINITY : fabsf(v);
         memcpy(&bits, &a, 4);
-        g_sp_range_host[0] += 1u;
-        if (bits > g_sp_range_host[1]) g_sp_range_host[1] = bits;
+        g_sp_range_cur[0] += 1u;
+        if (bits > g_sp_range_cur[1]) g_sp_range_cur[1] = bits;
     }
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
     h = sp_h_from_f32(v);
@@ -103,7 +108,8 @@ static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
 }
 static inline float sp_h_join(unsigned short h, unsigned short l) { return fmaf(sp_h_to_f32(l), 1.0f / 2048.0f, sp_h_to_f32(h)); }
 // split layout [board][plane][C/8][P2][8] f16 <-> channels-last fp32 rows
-int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void*) {
+int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void*, unsigned* range) {
+    SpRangeScope scope(range);
     const int P2 = S * S, nch = C / 8;
     const size_t plane = (size_t)nch * P2 * 8;
     for (long long b = 0; b < boards; ++b)
@@ -155,17 +161,20 @@ static int host_conv_split(const void* x, const void* w, const float* bias, cons
     return 0;
 }
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
-                         void*) {
+                         void*, unsigned* range) {
     if (!((S == 9 && (C == 128 || C == 64)) || (S == 17 && C == 64))) return 1;
+    SpRangeScope scope(range);
     return host_conv_split(x, w, bias, res, y, boards, S, C, C, relu);
 }
-int split_range_status(unsigned out[2], int reset, void*) {
-    out[0] = g_sp_range_host[0], out[1] = g_sp_range_host[1];
-    if (reset) g_sp_range_host[0] = g_sp_range_host[1] = 0u;
+int split_range_read(const unsigned* rec, unsigned out[2], int reset, void*) {
+    unsigned* r = rec ? (unsigned*)rec : g_sp_range_host;
+    out[0] = r[0], out[1] = r[1];
+    if (reset) r[0] = r[1] = 0u;
     return 0;
 }
-int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void*) {
+int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void*, unsigned* range) {
     if (cin < 1 || cin > 32) return 1;
+    SpRangeScope scope(range);
     const int P2 = S * S;
     const size_t plane = (size_t)4 * P2 * 8;
     unsigned short* d = (unsigned short*)dst;
@@ -177,8 +186,10 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
             }
     return 0;
 }
-int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*, int) {
+int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void*, int,
+                      unsigned* range) {
     if (!((S == 9 && (C == 128 || C == 64) && pad == 1) || (S == 13 && C == 64 && pad == 3))) return 1;
+    SpRangeScope scope(range);
     if (pad == 1) return host_conv_split(x, w, bias, nullptr, y, boards, S, 32, C, relu);
     // embed the board at (pad - 1, pad - 1) of a zero plane of S + 2 (pad - 1): the pad-3 convolution of the board is the pad-1 convolution of that plane
     const int So = S + 2 * (pad - 1), off = pad - 1, P2 = S * S, Po = So * So;

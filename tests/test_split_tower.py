@@ -35,20 +35,20 @@ def _run_split_conv(bnd, x, r, w, b, relu, device):
     n = dll.azsp_split_bytes(B, S, C) // 2
     assert n == B * 2 * S * S * C
     xs, ys = torch.zeros(n, dtype=torch.float16, device=device), torch.zeros(n, dtype=torch.float16, device=device)
-    assert dll.azsp_split_layout(xc.data_ptr(), xs.data_ptr(), B, S, C, 1, None) == 0
+    assert dll.azsp_split_layout(xc.data_ptr(), xs.data_ptr(), B, S, C, 1, None, None) == 0
     rs = None
     if r is not None:
         rc = r.to(device).contiguous(memory_format=torch.channels_last)
         rs = torch.zeros(n, dtype=torch.float16, device=device)
-        assert dll.azsp_split_layout(rc.data_ptr(), rs.data_ptr(), B, S, C, 1, None) == 0
+        assert dll.azsp_split_layout(rc.data_ptr(), rs.data_ptr(), B, S, C, 1, None, None) == 0
     wsp, bb = split_weights_f16(w).to(device), b.float().to(device)
     assert dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bb.data_ptr(), rs.data_ptr() if rs is not None else None, ys.data_ptr(),
-                                  B, S, C, relu, None) == 0
+                                  B, S, C, relu, None, None) == 0
     y = torch.empty_like(xc)
-    assert dll.azsp_split_layout(ys.data_ptr(), y.data_ptr(), B, S, C, 0, None) == 0
+    assert dll.azsp_split_layout(ys.data_ptr(), y.data_ptr(), B, S, C, 0, None, None) == 0
     # the layout round trip of the input itself: 22-bit significands
     back = torch.empty_like(xc)
-    assert dll.azsp_split_layout(xs.data_ptr(), back.data_ptr(), B, S, C, 0, None) == 0
+    assert dll.azsp_split_layout(xs.data_ptr(), back.data_ptr(), B, S, C, 0, None, None) == 0
     if device != "cpu":
         torch.cuda.synchronize()
     # |v - hi - lo / 2048| <= 2^-22 |v| (+ the fp32 rounding of the join); below f16's normal range the lo half is a multiple of
@@ -79,9 +79,9 @@ def test_split_abi_host_twin():
         assert rt <= 2.0 ** -21, rt
         assert err <= 2e-6, (boards, res, relu, err)
     assert bnd.dll.azsp_split_bytes(3, 9, 128) == 3 * 2 * 81 * 128 * 2 and bnd.dll.azsp_split_bytes(1, 9, 12) == -1
-    assert bnd.dll.azsp_conv3x3_split(None, None, None, None, None, 1, 9, 128, 1, None) != 0
+    assert bnd.dll.azsp_conv3x3_split(None, None, None, None, None, 1, 9, 128, 1, None, None) != 0
     z = torch.zeros(2 * 2 * 121 * 64, dtype=torch.float16)
-    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.clone().data_ptr(), 1, 11, 64, 1, None) != 0  # unsupported plane size
+    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.clone().data_ptr(), 1, 11, 64, 1, None, None) != 0  # unsupported plane size
 
 
 def test_split_abi_host_twin_17x17_and_pad3_stem():
@@ -104,8 +104,8 @@ def test_split_abi_host_twin_17x17_and_pad3_stem():
     assert dp <= 2e-6 and dv <= 2e-6, (dp, dv)
     # shapes without a kernel are refused, not guessed
     z = torch.zeros(2 * 2 * 169 * 64, dtype=torch.float16)
-    assert bnd.dll.azsp_stem_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.clone().data_ptr(), 1, 13, 64, 1, 1, None) != 0  # 13x13 with pad 1
-    assert bnd.dll.azsp_stem_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.clone().data_ptr(), 1, 9, 64, 3, 1, None) != 0
+    assert bnd.dll.azsp_stem_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.clone().data_ptr(), 1, 13, 64, 1, 1, None, None) != 0  # 13x13 with pad 1
+    assert bnd.dll.azsp_stem_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.clone().data_ptr(), 1, 9, 64, 3, 1, None, None) != 0
 
 
 def test_split_range_record_host_twin_and_weight_check():
@@ -121,10 +121,10 @@ def test_split_range_record_host_twin_and_weight_check():
     assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 0, None) == 0 and ev.value == 0 and mx.value == 0.0
     x = torch.tensor([1.0, -3.0, 65504.0, 1e-7, 0.0, 3.0, -2.5e-5, 60000.0]).reshape(1, 8, 1, 1).contiguous(memory_format=torch.channels_last)
     s = torch.zeros(2 * 8, dtype=torch.float16)
-    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None) == 0
+    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None, None) == 0
     assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 0, None) == 0 and ev.value == 0  # +-65504 itself is in range
     x[0, 1, 0, 0], x[0, 5, 0, 0] = -1e5, 70000.0
-    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None) == 0
+    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None, None) == 0
     assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), None, 0, None) == 0 and ev.value == 2
     assert bnd.dll.azsp_split_range_status(None, ctypes.byref(mx), 1, None) == 0 and mx.value == 1e5
     assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 0, None) == 0 and ev.value == 0 and mx.value == 0.0
@@ -144,9 +144,9 @@ def test_split_tower_clamps_at_f16_range_host_twin():
     bnd = eu.hosttwin_binding()
     x = torch.tensor([1e5, -1e5, 65504.0, 1e-7, 0.0, 3.0, -2.5e-5, 70000.0]).reshape(1, 8, 1, 1).contiguous(memory_format=torch.channels_last)
     s = torch.zeros(2 * 8, dtype=torch.float16)
-    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None) == 0
+    assert bnd.dll.azsp_split_layout(x.data_ptr(), s.data_ptr(), 1, 1, 8, 1, None, None) == 0
     back = torch.empty_like(x)
-    assert bnd.dll.azsp_split_layout(s.data_ptr(), back.data_ptr(), 1, 1, 8, 0, None) == 0
+    assert bnd.dll.azsp_split_layout(s.data_ptr(), back.data_ptr(), 1, 1, 8, 0, None, None) == 0
     want = x.clamp(-65504.0, 65504.0)
     assert torch.isfinite(back).all() and ((back - want).abs() <= want.abs() * 2.0 ** -21 + 1e-11).all(), back.flatten()
 
@@ -446,7 +446,7 @@ def test_gpu_split_range_record_trips_and_resets(S, C):
     x3 = x.clone()
     x3[2, 1, 0, 0] = -1e6
     xs = torch.zeros(dll.azsp_split_bytes(5, S, C) // 2, dtype=torch.float16, device="cuda")
-    assert dll.azsp_split_layout(x3.cuda().contiguous(memory_format=torch.channels_last).data_ptr(), xs.data_ptr(), 5, S, C, 1, None) == 0
+    assert dll.azsp_split_layout(x3.cuda().contiguous(memory_format=torch.channels_last).data_ptr(), xs.data_ptr(), 5, S, C, 1, None, None) == 0
     assert status(1) == (1, 1e6)
 
 

@@ -31,11 +31,11 @@ if split:
     xs, rs, ys = (torch.zeros(n, dtype=torch.float16, device="cuda") for _ in range(3))
     for dst in (xs, rs):
         t = acts().cuda().contiguous(memory_format=torch.channels_last)
-        assert b.dll.azsp_split_layout(t.data_ptr(), dst.data_ptr(), B, S, C, 1, None) == 0
+        assert b.dll.azsp_split_layout(t.data_ptr(), dst.data_ptr(), B, S, C, 1, None, None) == 0
         del t
     wp = split_weights_f16(w).cuda()
     for i in range(N):
-        assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wp.data_ptr(), bias.data_ptr(), rs.data_ptr() if i % 2 else None, ys.data_ptr(), B, S, C, 1, None) == 0
+        assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wp.data_ptr(), bias.data_ptr(), rs.data_ptr() if i % 2 else None, ys.data_ptr(), B, S, C, 1, None, None) == 0
 else:
     n = b.dll.azsp_tiled_bytes(B, S, C) // 2
     xs, rs, ys = (torch.zeros(n, dtype=torch.bfloat16, device="cuda") for _ in range(3))

@@ -1,5 +1,8 @@
 // Sustained (power-limited) MFMA throughput by instruction shape and operand data: 256 CUs x 4 waves, register-resident operands,
 // dense random bf16 vs zeros, ~0.5 s per case.  Informs which MFMA shape burns fewer joules per flop (design probe, not product).
+// Round 5: + the split-precision kernel's own instruction and operand mix (v_mfma_f32_16x16x32_f16; A = hi / lo halves of weights,
+// B = hi / lo halves of post-ReLU activations, the three products w_hi x_hi, w_hi x_lo, w_lo x_hi in the kernel's ratio).  With an
+// argument the results are also written as JSON to that path (profiles/mfma_power_probe.json: bench.py reads its ceiling from there).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -60,7 +63,58 @@ template <int SHAPE> __global__ void __launch_bounds__(256, 1) k_mfma(float* out
     }
 }
 
-int main() {
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// the split kernel's mix: per k-step 5 column tiles x (w_hi x_hi, w_hi x_lo, w_lo x_hi); operands built like sp_split builds them
+__global__ void __launch_bounds__(256, 1) k_mfma_split(float* out, int iters) {
+    const unsigned tid = blockIdx.x * 256 + threadIdx.x;
+    f16x8 wh[4], wl[4], xh[5], xl[5];
+    auto split = [](float v, _Float16& h, _Float16& l) { h = (_Float16)v; l = (_Float16)((v - (float)h) * 2048.0f); };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float w = (((hashu(tid * 131u + i * 17u + e) & 0xffff) / 32768.0f) - 1.0f) * 0.08f;  // Kaiming-like weights
+            _Float16 h, l;
+            split(w, h, l);
+            wh[i][e] = h, wl[i][e] = l;
+        }
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = (((hashu(tid * 257u + i * 29u + e + 7777u) & 0xffff) / 32768.0f) - 1.0f) * 3.0f;  // post-ReLU: half zeros
+            if (x < 0.0f) x = 0.0f;
+            _Float16 h, l;
+            split(x, h, l);
+            xh[i][e] = h, xl[i][e] = l;
+        }
+    f32x4 am[5], ac[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) am[j][e] = ac[j][e] = 0.0f;
+    for (int it = 0; it < iters; ++it)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) am[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xh[j], am[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], xl[j], ac[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) ac[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], xh[j], ac[j], 0, 0, 0);
+        }
+    float s = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += am[j][e] + ac[j][e];
+    out[tid] = s;
+}
+
+int main(int argc, char** argv) {
+    FILE* js = argc > 1 ? fopen(argv[1], "w") : nullptr;
+    if (js) fprintf(js, "{\"tool\": \"tools/probes/mfma_power_probe.hip\", \"cases\": [");
+    bool first = true;
     float* out;
     hipMalloc(&out, 256 * 256 * 4);
     hipEvent_t e0, e1;
@@ -85,6 +139,30 @@ int main() {
             hipEventElapsedTime(&ms, e0, e1);
             const double tf = 2.0 * macs_per_iter * iters * 1024 / (ms * 1e-3) / 1e12;
             printf("%s  %-22s %.1f ms  %.0f TFLOP/s\n", shape == 0 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", mn[mode], ms, tf);
+            if (js) fprintf(js, "%s{\"mfma\": \"%s\", \"operands\": \"%s\", \"ms\": %.2f, \"tflops\": %.1f}", first ? "" : ", ",
+                            shape == 0 ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", mn[mode], ms, tf);
+            first = false;
         }
+    {   // the split-precision kernel's instruction and operand mix
+        const int iters = 50000;
+        const double macs_per_iter = 60.0 * 8192;  // per wave: 4 k-steps x 15 MFMAs of 16 x 16 x 32
+        hipLaunchKernelGGL(k_mfma_split, dim3(256), dim3(256), 0, 0, out, iters);
+        hipDeviceSynchronize();
+        float best = 0;
+        for (int r = 0; r < 3; ++r) {  // ~0.4 s each: long enough for the package power limit to bite
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_mfma_split, dim3(256), dim3(256), 0, 0, out, 8 * iters);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double tf = 2.0 * macs_per_iter * 8 * iters * 1024 / (ms * 1e-3) / 1e12;
+            printf("v_mfma_f32_16x16x32_f16   split-precision mix     %.1f ms  %.0f TFLOP/s (issued products)\n", ms, tf);
+            if (tf > best) best = (float)tf;
+            if (js) fprintf(js, ", {\"mfma\": \"v_mfma_f32_16x16x32_f16\", \"operands\": \"split-precision mix (w hi/lo x post-ReLU x hi/lo, 3 products)\", \"ms\": %.2f, \"tflops\": %.1f}", ms, tf);
+        }
+        if (js) fprintf(js, "], \"split_mix_mfma_only_tflops\": %.1f}\n", best);
+    }
+    if (js) fclose(js);
     return 0;
 }

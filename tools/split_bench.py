@@ -35,12 +35,12 @@ st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 torch.backends.cudnn.benchmark = True
 n = b.dll.azsp_split_bytes(B, S, C) // 2
 xs, rs, ys = (torch.zeros(n, dtype=torch.float16, device="cuda") for _ in range(3))
-assert b.dll.azsp_split_layout(x.data_ptr(), xs.data_ptr(), B, S, C, 1, st) == 0
-assert b.dll.azsp_split_layout(res.data_ptr(), rs.data_ptr(), B, S, C, 1, st) == 0
+assert b.dll.azsp_split_layout(x.data_ptr(), xs.data_ptr(), B, S, C, 1, None, st) == 0
+assert b.dll.azsp_split_layout(res.data_ptr(), rs.data_ptr(), B, S, C, 1, None, st) == 0
 
 
 def split(r):
-    assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bias.data_ptr(), rs.data_ptr() if r is not None else None, ys.data_ptr(), B, S, C, 1, st) == 0
+    assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bias.data_ptr(), rs.data_ptr() if r is not None else None, ys.data_ptr(), B, S, C, 1, None, st) == 0
 
 
 def lib(r):
@@ -70,7 +70,7 @@ for r in (None, res):  # correctness on the full batch against the library's fp3
     ref = lib(r).clone()
     split(r)
     y2 = torch.empty_like(x)
-    assert b.dll.azsp_split_layout(ys.data_ptr(), y2.data_ptr(), B, S, C, 0, st) == 0
+    assert b.dll.azsp_split_layout(ys.data_ptr(), y2.data_ptr(), B, S, C, 0, None, st) == 0
     torch.cuda.synchronize()
     d = (y2 - ref).abs().max().item() / ref.abs().max().item()
     out[f"max_rel_diff_vs_library_{'residual' if r is not None else 'plain'}"] = d
@@ -78,7 +78,7 @@ for r in (None, res):  # correctness on the full batch against the library's fp3
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
-    assert b.dll.azsp_split_layout(xk.data_ptr(), xs.data_ptr(), B, S, C, 1, st) == 0
+    assert b.dll.azsp_split_layout(xk.data_ptr(), xs.data_ptr(), B, S, C, 1, None, st) == 0
 e1.record()
 torch.cuda.synchronize()
 out["split_layout_ms"] = round(e0.elapsed_time(e1) / 10, 4)

@@ -17,10 +17,10 @@ xs, rs, ys = (torch.zeros(n, dtype=torch.float16, device="cuda") for _ in range(
 for dst in (xs, rs):
     t = torch.randn(B, C, S, S, generator=g)
     t = torch.where(torch.rand(B, C, S, S, generator=g) < 0.5, torch.zeros(()), t.abs()).cuda().contiguous(memory_format=torch.channels_last)
-    assert b.dll.azsp_split_layout(t.data_ptr(), dst.data_ptr(), B, S, C, 1, None) == 0
+    assert b.dll.azsp_split_layout(t.data_ptr(), dst.data_ptr(), B, S, C, 1, None, None) == 0
     del t
 wsp = split_weights_f16(torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
 bias = (torch.randn(C, generator=g) * 0.1).cuda()
 for i in range(6):
-    assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bias.data_ptr(), rs.data_ptr() if i % 2 else None, ys.data_ptr(), B, S, C, 1, None) == 0
+    assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bias.data_ptr(), rs.data_ptr() if i % 2 else None, ys.data_ptr(), B, S, C, 1, None, None) == 0
 torch.cuda.synchronize()
