@@ -171,15 +171,20 @@ class InferenceNet(nn.Module):
             self.wp = nn.ParameterList([nn.Parameter(w.permute(2, 3, 0, 1).reshape(9, w.shape[0], w.shape[1]).to(pk).contiguous(),
                                                      requires_grad=False) for w, _ in convs[1:]])
             self.b32 = nn.ParameterList([nn.Parameter(b.float().contiguous(), requires_grad=False) for _, b in convs[1:]])
+            # fp32-class path: every activation is carried as v * 2^-act_shift (an exact rescaling of a ReLU + skip tower, see set_act_shift)
+            self.act_shift, self.act_calibrated, self.act_max_abs = 0, False, 0.0
+            self.split_fallback_reason = ""  # set when the fp32-class kernels are given up for this network (library fp32 instead)
             if dtype == torch.float32:  # split-precision tower (azsp_conv3x3_split)
-                self.wsp = nn.ParameterList([nn.Parameter(split_weights_f16(w), requires_grad=False) for w, _ in convs[1:]])
+                try:
+                    packed = [split_weights_f16(w) for w, _ in convs[1:]]
+                except ValueError as e:  # a folded tower weight the f16-pair format cannot carry: this network runs on the library
+                    packed = [torch.zeros(2, 9, w.shape[0], w.shape[1], dtype=torch.float16) for w, _ in convs[1:]]
+                    self.split_fallback_reason = str(e).split(";")[0]
+                self.wsp = nn.ParameterList([nn.Parameter(p, requires_grad=False) for p in packed])
                 # tower biases as the split kernels see them: b * 2^-act_shift (set_act_shift); b32 keeps the unscaled values
                 self.b_sp = nn.ParameterList([nn.Parameter(b.float().clone().contiguous(), requires_grad=False) for _, b in convs[1:]])
                 # this network's own range record (include/azsp.h: range_rec_dev): [events, bits of the largest |v|]
                 self.register_buffer("range_rec", torch.zeros(2, dtype=torch.int32), persistent=False)
-            # fp32-class path: every activation is carried as v * 2^-act_shift (an exact rescaling of a ReLU + skip tower, see set_act_shift)
-            self.act_shift, self.act_calibrated, self.act_max_abs = 0, False, 0.0
-            self.split_fallback_reason = ""  # set when calibration gave the fp32-class kernels up for this network (library fp32 instead)
             self.w = nn.ParameterList([nn.Parameter(w.to(dtype).contiguous(memory_format=self.mf), requires_grad=False) for w, _ in convs])
             self.b = nn.ParameterList([nn.Parameter(b.to(dtype), requires_grad=False) for _, b in convs])
             # stem for the tiled path (azsp_stem_tiled): [tap][cout][32 in], input channels 17.. zero
@@ -194,14 +199,26 @@ class InferenceNet(nn.Module):
                     sw32 = torch.zeros(sw.shape[0], 32, 3, 3)
                     sw32[:, : sw.shape[1]] = sw
                     self.register_buffer("stem_w32", sw32.float().contiguous(), persistent=False)  # unscaled source of stem_wsp
-                    self.stem_wsp = nn.Parameter(split_weights_f16(sw32), requires_grad=False)
+                    # loud stem weights (|w| > 65504) are carried by an initial activation shift; beyond MAX_ACT_SHIFT: library fp32
+                    wmax = float(sw32.abs().max()) if bool(torch.isfinite(sw32).all()) else float("inf")
+                    k0 = 0
+                    while wmax * 2.0 ** -k0 > F16_MAX and k0 <= self.MAX_ACT_SHIFT:
+                        k0 += 1
+                    if k0 > self.MAX_ACT_SHIFT:
+                        self.split_fallback_reason = self.split_fallback_reason or f"folded stem weights reach {wmax:.3g}: beyond the f16-pair format"
+                        k0 = 0
+                    self.stem_wsp = nn.Parameter(split_weights_f16(sw32 * 2.0 ** -k0) if not self.split_fallback_reason
+                                                 else torch.zeros(2, 9, sw.shape[0], 32, dtype=torch.float16), requires_grad=False)
                     self.stem_b_sp = nn.Parameter(convs[0][1].float().clone().contiguous(), requires_grad=False)
+                    self._initial_act_shift = k0
             pw, pb = _fold(net.policy_head[0], net.policy_head[1])
             vw, vb = _fold(net.value_head[0], net.value_head[1])
             self.npol, self.nval = pw.shape[0], vw.shape[0]
             self.head_w32 = nn.Parameter(torch.cat([pw, vw], 0).reshape(pw.shape[0] + vw.shape[0], -1).float().contiguous(), requires_grad=False)
             if dtype == torch.float32:  # azsp_head_split reads head_w32 * 2^act_shift (undoes the activation scale exactly)
                 self.head_w_sp = nn.Parameter(self.head_w32.detach().clone(), requires_grad=False)
+                if getattr(self, "_initial_act_shift", 0) and not self.split_fallback_reason:
+                    self.set_act_shift(self._initial_act_shift)
             self.head_b32 = nn.Parameter(torch.cat([pb, vb], 0).float().contiguous(), requires_grad=False)
             # both 1x1 heads share one convolution (2 policy planes + 1 value plane)
             self.head_w = nn.Parameter(torch.cat([pw, vw], 0).to(dtype).contiguous(memory_format=self.mf), requires_grad=False)
@@ -244,6 +261,7 @@ class InferenceNet(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     SPLIT_TOWER_SHAPES = ((128, 9), (64, 9), (64, 17))          # (filters, tower planes) with an azsp_conv3x3_split kernel
+    SPLIT_FUSED_SHAPES = ((64, 17),)                            # ... with a one-launch-per-block kernel (azsp_resblock_split)
     SPLIT_EVAL_SHAPES = ((128, 9, 1), (64, 9, 1), (64, 13, 3))  # (filters, board, stem pad) whose whole evaluator runs on the split kernels
 
     def _split_tower_ok(self, x):
@@ -435,6 +453,14 @@ class InferenceNet(nn.Module):
     def _blocks_split(self, a, m, o, B, S, C, st, rr=None, probe=None):
         """All residual blocks on split-layout buffers; returns the buffer holding the tower output."""
         dll, ck = self.binding.dll, self._ck
+        if self.use_fused_block and (C, S) in self.SPLIT_FUSED_SHAPES and probe is None:
+            # 64 filters on 17x17 planes: one launch per ResNetBlock, the intermediate activation stays in LDS (azsp_resblock_split:
+            # two tensor passes through HBM per block instead of five; bit-identical to the two launches below)
+            for i in range(self.n_blocks):
+                ck(dll.azsp_resblock_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b_sp[2 * i].data_ptr(), self.wsp[2 * i + 1].data_ptr(),
+                                           self.b_sp[2 * i + 1].data_ptr(), o.data_ptr(), B, S, C, rr, st), "azsp_resblock_split")
+                a, o = o, a
+            return a
         for i in range(self.n_blocks):
             ck(dll.azsp_conv3x3_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b_sp[2 * i].data_ptr(), None, m.data_ptr(), B, S, C, 1, rr, st),
                "azsp_conv3x3_split")

@@ -19,9 +19,10 @@
 //     with one zero cell between rows; rows outside the board are never written (zero).  A tap (dy, dx) is the constant cell offset
 //     20 dy + dx.  Double buffered (2 x 61,952 B), filled by LDS-DMA: wave q moves cells [64 q, 64 q + 64) of every chunk strip.
 //     A CU only ever sees tiles of one half (its zero rows are static): tile streams are per (cout half, board half).
-//   * (column tile, lane) -> position from a residue-class table as in az_conv.h; six of the sixteen classes have 13 members for
-//     12 lane groups, so 6 of the 190 positions sit in a group that already holds their residue (a 2-way conflict on 6 of 192
-//     lanes); unused slots repeat a cell and are never stored.
+//   * (column tile, lane) -> position from a residue-class table per board half as in az_conv.h (C9Map): six residue classes of a
+//     10-row tile would have 13 members for 12 lane groups; the upper half leaves six positions of the shared row 9 to the lower half
+//     (which holds that row anyway), so every class of both halves has <= 12 members: conflict-free (round 5; rounds 2-4 had a 2-way
+//     conflict in 6 of 12 lane groups); unused slots repeat a cell and are never stored.
 //   * epilogue straight from the accumulators, 8-byte slots; SOFTWARE-PIPELINED (round 3): a unit is ONE column tile (72 MFMAs that
 //     accumulate into the same 16 registers back to back), two accumulator sets, the epilogue of unit u - 1 (addend add, bf16
 //     rounding, ReLU, stores) is issued one instruction per MFMA gap inside unit u, the B-fragment ring runs on across units and
@@ -44,37 +45,41 @@
 
 struct C9Map {
     unsigned short cell[C9_NCT * 32], pos[C9_NCT * 32];  // pos: tile-relative (row * 19 + col), 0xffff = no store
+    bool ok;
 };
-constexpr C9Map c9_make_map() {
+// Board row 9 lies in both halves' images.  Six of the sixteen residue classes (cell mod 16) of a 10-row tile have 13 members for the
+// 12 lane groups of its 6 column tiles (rounds 2-4: a 2-way bank conflict in 6 of 12 groups, 13.6 % of the LDS cycles in the PMC pass);
+// each of them has a member in row 9, so the UPPER half (hf = 0) leaves those six positions of row 9 -- columns 0, 1, 2, 12, 13, 14 -- to
+// the LOWER half (hf = 1), which computes rows 10-18 + exactly these six: every class of both maps has <= 12 members, every lane
+// group reads 16 distinct residues: conflict-free.
+constexpr bool c9_handed_over(int col) { return col <= 2 || (col >= 12 && col <= 14); }
+constexpr bool c9_in_map(int hf, int p) {  // tile-relative position p = row * 19 + col of half hf: computed AND stored by that half?
+    const int row = p / C9_S, col = p % C9_S;
+    if (hf == 0) return !(row == C9_ROWS - 1 && c9_handed_over(col));
+    return row >= 1 || c9_handed_over(col);
+}
+constexpr C9Map c9_make_map(int hf) {
     C9Map m{};
     const int lanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
     const int NG = 2 * C9_NCT;
     int cnt[16] = {}, fill[NG] = {};
     bool used[NG][16] = {};
-    int deferred[32] = {}, ndef = 0;
+    bool ok = true;
     for (int i = 0; i < C9_NCT * 32; ++i) {
         m.cell[i] = 0;
         m.pos[i] = 0xffff;
     }
     for (int p = 0; p < C9_NPOS; ++p) {
+        if (!c9_in_map(hf, p)) continue;
         const int cell = C9_CELL0 + C9_PITCH * (p / C9_S) + p % C9_S, r = cell & 15, k = cnt[r]++;
-        if (k >= NG) {
-            deferred[ndef++] = p;
+        if (k >= NG) {  // a class with more members than lane groups would need a 2-way conflict
+            ok = false;
             continue;
         }
         const int idx = (k >> 1) * 32 + lanes[k & 1][fill[k]++];
         m.cell[idx] = (unsigned short)cell;
         m.pos[idx] = (unsigned short)p;
         used[k][r] = true;
-    }
-    for (int d = 0; d < ndef; ++d) {  // classes with more members than lane groups: into the emptiest group (one 2-way conflict each)
-        const int p = deferred[d], cell = C9_CELL0 + C9_PITCH * (p / C9_S) + p % C9_S;
-        int best = 0;
-        for (int k = 1; k < NG; ++k)
-            if (fill[k] < fill[best]) best = k;
-        const int idx = (best >> 1) * 32 + lanes[best & 1][fill[best]++];
-        m.cell[idx] = (unsigned short)cell;
-        m.pos[idx] = (unsigned short)p;
     }
     for (int k = 0; k < NG; ++k)  // unused slots: a cell of a residue the group lacks (conflict-free), never stored
         for (int r = 0; r < 16 && fill[k] < 16; ++r) {
@@ -89,9 +94,32 @@ constexpr C9Map c9_make_map() {
                 }
             }
         }
+    for (int k = 0; k < NG; ++k) {  // every lane group: 16 slots, 16 distinct residues
+        bool seen[16] = {};
+        if (fill[k] != 16) ok = false;
+        for (int i = 0; i < 16; ++i) {
+            const int r = m.cell[(k >> 1) * 32 + lanes[k & 1][i]] & 15;
+            if (seen[r]) ok = false;
+            seen[r] = true;
+        }
+    }
+    m.ok = ok;
     return m;
 }
-static __device__ const C9Map c9_map = c9_make_map();
+constexpr bool c9_maps_cover_the_board() {  // every board position is stored by exactly one half
+    const C9Map m0 = c9_make_map(0), m1 = c9_make_map(1);
+    int seen[C9_P2] = {};
+    for (int i = 0; i < C9_NCT * 32; ++i) {
+        if (m0.pos[i] != 0xffff) seen[m0.pos[i]]++;
+        if (m1.pos[i] != 0xffff) seen[m1.pos[i] + 9 * C9_S]++;
+    }
+    for (int p = 0; p < C9_P2; ++p)
+        if (seen[p] != 1) return false;
+    return true;
+}
+static_assert(c9_make_map(0).ok && c9_make_map(1).ok, "19x19 column-tile maps: conflict-free lane groups in both board halves");
+static_assert(c9_maps_cover_the_board(), "19x19 column-tile maps: every position stored exactly once");
+static __device__ const C9Map c9_maps[2] = {c9_make_map(0), c9_make_map(1)};
 
 // ADD: an addend tensor (the residual in launch A, the partial sum in launch B; may alias y).  NCH = input chunks contracted by this
 // launch: 16 (one half of the tower's 256 channels) or 4 (the stem: 17 planes padded to 32).  cin_total = row length of w_packed
@@ -187,14 +215,13 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
     };
 
     // this lane's 6 output positions: LDS byte offset of the (-1, -1) neighbour of its cell in its own chunk half (low 16 bits), its
-    // board position (high 16 bits; 0xffff = computed but not stored: repeated slots, and row 9 in the second board half)
+    // board position (high 16 bits; 0xffff = computed but not stored: the padding slots of this half's map)
     unsigned lmap[C9_NCT];
 #pragma unroll
     for (int ct = 0; ct < C9_NCT; ++ct) {
-        const unsigned tp = c9_map.pos[ct * 32 + l31];
-        unsigned gp = 0xffffu;
-        if (tp != 0xffffu && !(hf == 1 && tp < (unsigned)C9_S)) gp = tp + (unsigned)(r0 * C9_S);
-        lmap[ct] = (unsigned)((c9_map.cell[ct * 32 + l31] - C9_CELL0) * 16 + hi * C9_LBLK) | (gp << 16);
+        const unsigned tp = c9_maps[hf].pos[ct * 32 + l31];
+        const unsigned gp = tp != 0xffffu ? tp + (unsigned)(r0 * C9_S) : 0xffffu;
+        lmap[ct] = (unsigned)((c9_maps[hf].cell[ct * 32 + l31] - C9_CELL0) * 16 + hi * C9_LBLK) | (gp << 16);
     }
     unsigned long long smask[C9_NCT];  // lanes of a column tile that store their result
 #pragma unroll

@@ -1,0 +1,421 @@
+// az_resblock_sp17.h -- one whole ResNetBlock of a 64-filter tower on 17x17 planes in ONE launch, at the REFERENCE'S precision class
+// (the fp32-class split arithmetic of az_conv_sp.h: every value a hi + lo f16 pair, three f16 MFMA products per multiply, fp32 accumulation):
+//     y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2 + x)             (alpha_zero/core/network.py:42-82, eval mode, BatchNorm folded;
+//                                                                             evaluated in fp32 by core/pipeline.py:91-123)
+// This is the block of the reference's 13x13 Gomoku tower (network.py:101-105: the pad-3 stem makes 17x17 planes; BASELINE C2: 6 x 64).
+// Two k_conv3x3_sp17 launches per block move five tensor passes through HBM (x in, m out; m in, x in again as the skip, y out) and at 64
+// filters that kernel leans on both roofs (round 4: matrix pipe busy 0.64 - 0.71 at a clock the HBM traffic's share of the package
+// power pulls down, 3.3 TB/s; 0.427 of the f16 MFMA peak).  Here the intermediate activation m never leaves the CU:
+//   * tile = HALF a board (output rows 0-8 / 9-16), two phases per tile on the same persistent 256-thread workgroup (one wave per SIMD,
+//     wave q = couts [16 q, 16 q + 16) of BOTH convolutions: 2 x 144 = 288 weight registers, 256 of them AGPRs):
+//       phase A  conv1 on the x image in LDS (13 image rows) -> the m rows the tile's conv2 needs (rows 0-9 / 8-16: one halo row is
+//                recomputed per half: 21 + 19 = 40 column tiles of 16 positions per board against 38 unfused, + 5 % MFMAs), bias + ReLU +
+//                range record + split into hi / lo, written straight into the m image in LDS (ds_write_b64);
+//       barrier; phase B  conv2 on the m image, the skip from x in global memory (read by this CU's LDS-DMA a moment ago: an L2 hit),
+//                epilogue as in k_conv3x3_sp17<RES>, y to global memory; the NEXT tile's x image arrives by LDS-DMA under phase B's
+//                first MFMAs (the x buffer is free from the barrier on); barrier.
+//     HBM per block: x once (rows 7-10 twice, the second time from L2) + y once = 2 passes instead of 5.
+//   * LDS: x image 16 strips (plane, chunk) x 256 cells x 16 B = 64 KB, m image 16 x 240 cells = 60 KB, one buffer each (the phases
+//     alternate between them, nothing is double-buffered), + a 20 KB lane table = 144 KB.  Image rows: cell(ri, x) = 1 + 19 ri + x with two
+//     zero cells between rows; the two halves use shifted row windows so that the zero rows they need (above the board / below it)
+//     are cells nobody ever writes: x image H0: ri = r + 1 (ri 0 = row -1), H1: ri = r - 5 (ri 12 = row 17); m image H0: mi = r + 1, H1: mi = r - 6.
+//   * units of <= 2 column tiles with two accumulator sets; the epilogue of unit u rides in the MFMA stream of unit u + 1 as
+//     one-instruction micro-ops (SpSpread); only the last unit of phase A finishes exposed (its m values must be in LDS before the barrier).
+//     Per-(column tile, lane) offsets (B-fragment base, output slot) live in an LDS table and are fetched one unit ahead into a rotating
+//     set of 3 x 2 register pairs: the kernel carries 6 such registers instead of 40 (the 288 weight registers leave ~220 for everything else).
+// Results are BIT-IDENTICAL to two azsp_conv3x3_split launches (same MFMA order per output, same roundings): tests/test_split_tower.py.
+// y must not alias x (the lower half re-reads x rows 7-8 after the upper half has written y rows 0-8).
+#pragma once
+#include "az_conv_sp17.h"
+
+#if defined(__HIPCC__)
+struct Sb17 {
+    static constexpr int S = 17, P2 = 289, PITCH = 19;
+    static constexpr int XCELLS = 256, MCELLS = 240;       // 1 + 13 * 19 = 248 / 1 + 12 * 19 = 229, rounded up to multiples of 16 cells
+    static constexpr int NSEG = 4, NSEQ = 21, NTILE = 40;  // segments (A,H0) (B,H0) (A,H1) (B,H1); units and column tiles per board
+    static constexpr int seg_ph(int g) { return g & 1; }   // 0 = phase A (conv1: x image -> m image), 1 = phase B (conv2: m image -> y)
+    static constexpr int seg_h(int g) { return g >> 1; }
+    static constexpr int seg_r0(int g) { return g == 0 ? 0 : g == 1 ? 0 : g == 2 ? 8 : 9; }     // first output row of the segment
+    static constexpr int seg_nr(int g) { return g == 0 ? 10 : g == 1 ? 9 : g == 2 ? 9 : 8; }    // output rows
+    static constexpr int seg_nct(int g) { return g == 0 ? 11 : g == 1 ? 10 : g == 2 ? 10 : 9; }  // column tiles
+    static constexpr int seg_rbase(int g) { return g == 0 ? 0 : g == 1 ? 0 : g == 2 ? 6 : 7; }   // B-fragment base cell of (r, x) = 19 (r - rbase) + x
+    static constexpr int seg_nu(int g) { return (seg_nct(g) + 1) / 2; }
+    static constexpr int seg_tile0(int g) { return g == 0 ? 0 : g == 1 ? 11 : g == 2 ? 21 : 31; }
+    static constexpr int seg_seq0(int g) { return g == 0 ? 0 : g == 1 ? 6 : g == 2 ? 11 : 16; }
+    static constexpr int unit_nj(int g, int u) { return seg_nct(g) - 2 * u >= 2 ? 2 : 1; }
+    // m-image cell of an m position = its phase-A base cell + this (H0: mi = r + 1 -> 1 + 19 (r + 1) + x = base + 20; H1: mi = r - 6 -> base + 1)
+    static constexpr int m_cell_of_base(int h) { return h ? 1 : 20; }
+    // source row of x-image row ri of half h (-1: a row the DMA never writes)
+    static constexpr int x_src_row(int h, int ri) {
+        if (h == 0) return (ri >= 1 && ri <= 11) ? ri - 1 : -1;
+        return (ri >= 2 && ri <= 11) ? ri + 5 : -1;
+    }
+    static constexpr int x_pos_of_cell(int h, int cell) {
+        const int k = cell - 1;
+        if (k < 0) return -1;
+        const int ri = k / PITCH, xx = k % PITCH;
+        if (xx >= S) return -1;
+        const int r = x_src_row(h, ri);
+        return r < 0 ? -1 : r * S + xx;
+    }
+};
+static_assert(Sb17::seg_seq0(3) + Sb17::seg_nu(3) == Sb17::NSEQ && Sb17::seg_tile0(3) + Sb17::seg_nct(3) == Sb17::NTILE, "unit / tile numbering");
+static_assert(Sb17::NSEQ % 3 == 0, "the rotating lane-table registers keep their phase from board to board");
+
+// (segment, column tile, lane & 15) -> position: column tile k of a segment takes the k-th position of every residue class (base cell
+// mod 16); unfilled slots repeat the first position of a residue class the tile still lacks (the repeats compute and store the same value).
+struct Sb17Map {
+    unsigned short pos[Sb17::NTILE * 16];
+    bool ok;
+};
+constexpr Sb17Map sb17_make_map() {
+    typedef Sb17 G;
+    Sb17Map m{};
+    bool ok = true;
+    for (int g = 0; g < G::NSEG; ++g) {
+        int cnt[16] = {}, fill[11] = {};
+        bool used[11][16] = {};
+        bool seen_pos[G::P2] = {};
+        const int nct = G::seg_nct(g), t0 = G::seg_tile0(g), r0 = G::seg_r0(g), r1 = r0 + G::seg_nr(g), rb = G::seg_rbase(g);
+        for (int r = r0; r < r1; ++r)
+            for (int x = 0; x < G::S; ++x) {
+                const int res = (G::PITCH * (r - rb) + x) & 15, k = cnt[res]++;
+                if (k >= nct) {
+                    ok = false;
+                    continue;
+                }
+                m.pos[(t0 + k) * 16 + fill[k]++] = (unsigned short)(r * G::S + x);
+                used[k][res] = true;
+                seen_pos[r * G::S + x] = true;
+            }
+        for (int k = 0; k < nct; ++k)
+            for (int res = 0; res < 16 && fill[k] < 16; ++res) {
+                if (used[k][res]) continue;
+                bool found = false;
+                for (int r = r0; r < r1 && !found; ++r)
+                    for (int x = 0; x < G::S && !found; ++x)
+                        if (((G::PITCH * (r - rb) + x) & 15) == res) {
+                            m.pos[(t0 + k) * 16 + fill[k]++] = (unsigned short)(r * G::S + x);
+                            used[k][res] = true;
+                            found = true;
+                        }
+                if (!found) ok = false;
+            }
+        for (int k = 0; k < nct; ++k) {  // every column tile: 16 slots inside the segment's rows, 16 distinct residues
+            bool seen[16] = {};
+            if (fill[k] != 16) ok = false;
+            for (int s = 0; s < 16; ++s) {
+                const int p = m.pos[(t0 + k) * 16 + s], r = p / G::S, x = p % G::S;
+                if (r < r0 || r >= r1) ok = false;
+                const int res = (G::PITCH * (r - rb) + x) & 15;
+                if (seen[res]) ok = false;
+                seen[res] = true;
+            }
+        }
+        for (int r = r0; r < r1; ++r)
+            for (int x = 0; x < G::S; ++x)
+                if (!seen_pos[r * G::S + x]) ok = false;
+    }
+    m.ok = ok;
+    return m;
+}
+static_assert(sb17_make_map().ok, "column-tile maps of the fused 17x17 block: every position of every segment covered, conflict-free lane groups");
+static __device__ const Sb17Map sb17_map = sb17_make_map();
+
+// w1, w2: [plane: hi, lo][9 taps][64 couts][64 cin] f16 with lo = (w - hi) * 2^11 (the packing of azsp_conv3x3_split); b1, b2 fp32 [64].
+__global__ void __launch_bounds__(CW_THREADS, 1)
+k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__ w1, const float* __restrict__ b1, const _Float16* __restrict__ w2,
+                const float* __restrict__ b2, unsigned char* __restrict__ y, int nboards, unsigned* range) {
+    typedef Sb17 G;
+    constexpr int C = 64, NCH = 8, CIN = 64, KSUB = 2;
+    constexpr int KS = 9 * KSUB;                             // k-steps per unit (one tap x 32 input channels)
+    constexpr int NJM = 2, R = 3;                            // most column tiles per unit; ring slots (k-steps)
+    constexpr int XBLK = G::XCELLS * 16, XPLANE = NCH * XBLK, XBUF = 2 * XPLANE;    // 4096, 32768, 65536
+    constexpr int MBLK = G::MCELLS * 16, MPLANE = NCH * MBLK, MBUF = 2 * MPLANE;    // 3840, 30720, 61440
+    constexpr int TBL0 = XBUF + MBUF, TBL = G::NTILE * 64 * 8;                      // lane table: [tile][lane] {B base offset, output offset}
+    constexpr int GBLK = G::P2 * 16, GPLANE = NCH * GBLK, GTILE = 2 * GPLANE;       // split layout of a board in global memory
+    constexpr int NP = G::XCELLS / 64;                       // DMA pieces of 64 cells per strip
+    constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips and DMA pieces per wave and tile: 4, 16
+    constexpr int NFC = 2 * KS, NF = 2 * NFC;                // A fragments per convolution (2 planes x 18 k-steps), in all: 72
+    // epilogue micro-ops per column tile.  TO THE M IMAGE (phase A): per element 4 (join, ReLU, range record, clamp), per pair of
+    // elements 6 more (packed hi convert, 2 scalings, 2 remainders, packed lo convert), 2 LDS stores: 30.  TO GLOBAL MEMORY (phase B):
+    // per element 6 (join, residual join, add, ReLU, range record, clamp), per pair 6 more, 2 stores: 38.
+    constexpr int E1M = 4, PAIRM = 2 * E1M + 6, CTM = 2 * PAIRM + 2;
+    constexpr int E1G = 6, PAIRG = 2 * E1G + 6, CTG = 2 * PAIRG + 2;
+    constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
+    static_assert(KS % R == 0, "every unit starts at ring phase 0");
+    static_assert(KS - 2 >= NPIECE, "the next tile's pieces ride in the first unit of phase B");
+    static_assert((2 * G::PITCH + 2) * 16 + (KSUB - 1) * 4 * XBLK + XPLANE < 65536, "fragment addresses are a per-lane base + a 16-bit immediate");
+    static_assert(XBLK % 256 == 0 && MBLK % 256 == 0, "strips are multiples of 256 B: the four 8-channel groups of a fragment share banks");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[TBL0 + TBL];
+    static_assert(TBL0 + TBL <= 160 * 1024, "LDS budget");
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int slot = (int)blockIdx.x, nslot = (int)gridDim.x;
+    for (int i = tid; i < TBL0 / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    // lane table (identical for the four waves: the wave's own channel offset is wave-uniform and added where it is used)
+    for (int i = tid; i < G::NTILE * 64; i += CW_THREADS) {
+        const int tile = i >> 6, ln = i & 63, tl15 = ln & 15, tkg = ln >> 4;
+        int g = 0;
+        while (g < 3 && tile >= G::seg_tile0(g + 1)) ++g;
+        const int pos = sb17_map.pos[tile * 16 + tl15], r = pos / G::S, xx = pos % G::S;
+        const int base = G::PITCH * (r - G::seg_rbase(g)) + xx;
+        unsigned boff, ooff;
+        if (G::seg_ph(g) == 0) {
+            boff = (unsigned)(base * 16 + tkg * XBLK);
+            ooff = (unsigned)((base + G::m_cell_of_base(G::seg_h(g))) * 16 + (tkg & 1) * 8 + (tkg >> 1) * MBLK);
+        } else {
+            boff = (unsigned)(base * 16 + tkg * MBLK);
+            ooff = (unsigned)(pos * 16 + (tkg >> 1) * GBLK + (tkg & 1) * 8);
+        }
+        *(cv_u32x2*)(lds + TBL0 + i * 8) = (cv_u32x2){boff, ooff};
+    }
+    CV_BARRIER();  // the zero cells and the table are final before any LDS-DMA piece can land
+    if (slot >= nboards) return;  // (uniform per workgroup)
+
+    // A fragments: fragment f = conv * NFC + plane * KS + (tap * KSUB + ks): lane (cout = 16 wave + l15, cin = 32 ks + 8 kg .. + 8)
+    sp_f16x8 wf[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int cv = f / NFC, pl = (f % NFC) / KS, st = f % KS;
+        const _Float16* w = cv ? w2 : w1;
+        wf[f] = *(const sp_f16x8*)(w + ((size_t)((pl * 9 + st / KSUB) * C + wave * 16 + l15)) * CIN + (st % KSUB) * 32 + kg * 8);
+    }
+    c6_f32x4 bv[2];  // biases in the D layout (rows = couts 4 kg + e of the wave's 16): the C operand of a unit's first k-step
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[0][e] = b1[wave * 16 + 4 * kg + e], bv[1][e] = b2[wave * 16 + 4 * kg + e];
+
+    // LDS-DMA plan per half: a strip is NP pieces of 64 cells; wave q moves strips SPW q .. SPW q + SPW - 1 (strip = plane * NCH + chunk)
+    unsigned dsrc[2][NP];
+    unsigned long long dmask[2][NP];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = G::x_pos_of_cell(h, 64 * i + lane);
+            dsrc[h][i] = (unsigned)((p < 0 ? 0 : p) * 16);
+            dmask[h][i] = __builtin_amdgcn_ballot_w64(p >= 0);
+        }
+    auto dma_piece = [&](const unsigned char* src, bool live, int h, int i) __attribute__((always_inline)) {
+        const int c = SPW * wave + i / NP, pc = i % NP;
+        const unsigned long long base = (unsigned long long)(src + (size_t)c * GBLK);
+        const unsigned long long mask = live ? dmask[h][pc] : 0ull;
+        const unsigned dst = lds0 + (unsigned)(c * XBLK + pc * 1024);
+        asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                     :
+                     : "s"(mask), "s"(dst), "v"(dsrc[h][pc]), "s"(base)
+                     : "memory");
+    };
+    const unsigned char* Xs = lds;
+    const unsigned char* Ms = lds + XBUF;
+    unsigned char* Mw = lds + XBUF + (wave * 2) * MBLK;     // this wave's two chunk strips of the m image (hi plane; lo at + MPLANE)
+    const unsigned char* tbl = lds + TBL0 + lane * 8;
+    cv_u32x2 lm[3][NJM];  // rotating lane-table registers [unit sequence number % 3][column tile of the unit] = {B base offset, output offset}
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < NJM; ++j) lm[a][j] = (cv_u32x2){0u, 0u};
+    auto load_lm = [&](int rot, int tile0, int nj) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJM; ++j)
+            if (j < nj) lm[rot][j] = *(const cv_u32x2*)(tbl + (tile0 + j) * 512);
+    };
+    sp_f16x8 bb[R][2][NJM];  // ring of B fragments [k-step slot][plane][column tile of the unit]
+    // fragments of k-step s of a unit whose lane-table registers are lm[rot] from image `img` (PH = 0: x image, 1: m image)
+    auto load_step = [&](auto PHC, const unsigned char* img, int rot, int nj, int s, int rs) __attribute__((always_inline)) {
+        constexpr int PH = decltype(PHC)::value, BLK = PH ? MBLK : XBLK, PLANE = PH ? MPLANE : XPLANE;
+        const int tap = s / KSUB;
+        const int off = ((tap / 3) * G::PITCH + (tap % 3)) * 16 + (s % KSUB) * (4 * BLK);
+#pragma unroll
+        for (int j = 0; j < NJM; ++j)
+            if (j < nj) bb[rs][0][j] = *(const sp_f16x8*)(img + lm[rot][j].x + off);
+#pragma unroll
+        for (int j = 0; j < NJM; ++j)
+            if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + lm[rot][j].x + off + PLANE);
+    };
+
+    {   // first tile (upper half of the first board): all pieces at once, then the first lane-table registers and fragments
+        const unsigned char* src = x + (size_t)slot * GTILE;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) dma_piece(src, true, 0, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CV_BARRIER();
+        load_lm(0, G::seg_tile0(0), G::unit_nj(0, 0));
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) load_step(CpInt<0>{}, Xs, 0, G::unit_nj(0, 0), s, s);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {  // the compiler's wait for the weight loads belongs in front of the loop (see az_conv.h)
+        if (f < 64) asm volatile("" : : "a"(wf[f]));
+        else asm volatile("" : : "v"(wf[f]));
+    }
+    asm volatile("" : : "v"(bv[0]), "v"(bv[1]), "v"(dsrc[0][0]), "v"(dsrc[1][NP - 1]));
+
+    c6_f32x4 accm[2][NJM], accc[2][NJM];  // [accumulator set][column tile of the unit]
+    cv_u32x2 rr[2][NJM][2];               // skip values of a phase-B unit: [accumulator set][column tile][plane]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < NJM; ++j) {
+            accm[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accc[a][j] = (c6_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            rr[a][j][0] = (cv_u32x2){0u, 0u}, rr[a][j][1] = (cv_u32x2){0u, 0u};
+        }
+    float evv[2] = {0.0f, 0.0f}, sc[2] = {0.0f, 0.0f}, t0 = 0.0f, mx = 0.0f;  // mx: largest |value| this lane produced (range record)
+    unsigned hpk[2] = {0u, 0u}, lpk[2] = {0u, 0u};
+    // micro-op `o` of the epilogue of column tile j of the unit with accumulator set `set`: ONE VALU / memory instruction.
+    // GLOBAL = false: phase A (bias + ReLU -> m image at Mw + ooff); true: phase B (bias + skip + ReLU -> global memory at out + ooff)
+    auto epi_op = [&](auto GC, int set, int j, unsigned ooff, unsigned char* out, int o, bool store_ok) __attribute__((always_inline)) {
+        constexpr bool GLOBAL = decltype(GC)::value != 0;
+        constexpr int E1 = GLOBAL ? E1G : E1M, PAIR = 2 * E1 + 6;
+        if (o < 2 * PAIR) {
+            const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
+            if (k < 2 * E1) {
+                const int ei = k / E1, kk = k % E1, e = 2 * pr + ei;
+                const unsigned rh = pr == 0 ? rr[set][j][0].x : rr[set][j][0].y, rl = pr == 0 ? rr[set][j][1].x : rr[set][j][1].y;
+                const int tail = kk - (GLOBAL ? 3 : 1);
+                if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
+                else if (GLOBAL && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
+                else if (GLOBAL && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
+                else if (tail == 0) evv[ei] = fmaxf(evv[ei], 0.0f);
+                else if (tail == 1) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
+                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], -SP_F16_MAX, SP_F16_MAX);                   // ... is clamped here (and recorded)
+            } else {
+                const int kk = k - 2 * E1;
+                if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
+                else if (kk == 1) sc[0] = evv[0] * SP_SCALE;
+                else if (kk == 2) sc[1] = evv[1] * SP_SCALE;
+                else if (kk == 3) sc[0] = sp_mix_rem<0>(hpk[pr], sc[0]);
+                else if (kk == 4) sc[1] = sp_mix_rem<1>(hpk[pr], sc[1]);
+                else lpk[pr] = sp_cvt_pk(sc[0], sc[1]);
+            }
+        } else if constexpr (GLOBAL) {
+            if (o == 2 * PAIR) {
+                if (store_ok) *(cv_u32x2*)(out + ooff) = (cv_u32x2){hpk[0], hpk[1]};
+            } else if (store_ok) *(cv_u32x2*)(out + GPLANE + ooff) = (cv_u32x2){lpk[0], lpk[1]};
+        } else {
+            if (o == 2 * PAIR) *(cv_u32x2*)(Mw + ooff) = (cv_u32x2){hpk[0], hpk[1]};
+            else *(cv_u32x2*)(Mw + MPLANE + ooff) = (cv_u32x2){lpk[0], lpk[1]};
+        }
+    };
+
+    int it = 0;
+    unsigned char* yprev = y;
+    for (int board = slot; board < nboards; board += nslot, ++it) {
+        const bool has_next = board + nslot < nboards;
+        const unsigned char* xb = x + (size_t)board * GTILE;
+        const unsigned char* xnb = x + (size_t)(has_next ? board + nslot : board) * GTILE;
+        const size_t yo = (size_t)board * GTILE + (size_t)(wave * 2) * GBLK;  // uniform: the lane part comes from the lane table
+        const unsigned char* rbase = xb + (size_t)(wave * 2) * GBLK;          // the skip = the block's own input
+        unsigned char* ybase = y + yo;
+        const bool have_prev = it > 0;
+        // unit U of segment SG
+        auto unit = [&](auto GC, auto UC) __attribute__((always_inline)) {
+            constexpr int SG = decltype(GC)::value, U = decltype(UC)::value;
+            constexpr int PH = G::seg_ph(SG), H = G::seg_h(SG), NU = G::seg_nu(SG);
+            constexpr int SEQ = G::seg_seq0(SG) + U, ROT = SEQ % 3, PROT = (SEQ + 2) % 3, NROT = (SEQ + 1) % 3;
+            constexpr int nj = G::unit_nj(SG, U);
+            constexpr int set = PH == 0 ? (U & 1) : ((U + NU) & 1);                  // phase B: its last unit uses set 1 (phase A starts on set 0)
+            constexpr bool LAST = U == NU - 1, FIRST = U == 0;
+            // the next unit (the ring and the lane-table registers run one unit ahead)
+            constexpr int NSG = LAST ? (SG + 1) & 3 : SG, NUU = LAST ? 0 : U + 1;
+            constexpr int nnj = G::unit_nj(NSG, NUU), ntile0 = G::seg_tile0(NSG) + 2 * NUU;
+            // the previous unit, whose epilogue rides here: phase A, first unit: the last unit of the previous phase B (global); phase A,
+            // later units: the previous unit of this phase (m image); phase B, first unit: nothing (phase A finished exposed); later: global
+            constexpr int PSG = FIRST ? (SG + 3) & 3 : SG, PU = FIRST ? G::seg_nu(PSG) - 1 : U - 1;
+            constexpr bool RIDE = !(PH == 1 && FIRST);
+            constexpr bool RGLOBAL = G::seg_ph(PSG) == 1;
+            constexpr int pnj = G::unit_nj(PSG, PU);
+            constexpr int pset = G::seg_ph(PSG) == 0 ? (PU & 1) : ((PU + G::seg_nu(PSG)) & 1);
+            static_assert(!RIDE || pset != set, "a unit and the epilogue riding in it use different accumulator sets");
+            constexpr int CT_OPS = RGLOBAL ? CTG : CTM;
+            constexpr int NQ = 3 * nj, P_OPS = RIDE ? pnj * CT_OPS : 1;              // MFMAs per k-step; micro-ops of the riding epilogue
+            constexpr int AVAIL = (PH == 1 && LAST ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;  // (riders end before the tile's second barrier)
+            typedef SpSpread<P_OPS, S0, AVAIL> SP;
+            static_assert(SP::MAXPER <= 2, "the previous unit's epilogue fits this unit's MFMA gaps");
+            const unsigned char* img = PH ? Ms : Xs;
+            // where the riding epilogue stores: phase B units of the previous board (first unit of a board) or of this board
+            unsigned char* pout = SG == 0 ? yprev : ybase;
+            const bool pstore = SG == 0 && FIRST ? have_prev : true;
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::value;
+                if constexpr (PH == 1 && LAST && t == KS - (R - 1)) {
+                    // end of the tile: every read of the m image has been issued, this wave's pieces of the next x image have landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    CV_BARRIER();
+                }
+                if constexpr (t == 3) load_lm(NROT, ntile0, nnj);  // the next unit's lane-table registers
+                if constexpr (t + R - 1 < KS) load_step(CpInt<PH>{}, img, ROT, nj, t + R - 1, (t + R - 1) % R);
+                else if constexpr (!LAST) load_step(CpInt<PH>{}, img, NROT, nnj, t + R - 1 - KS, (t + R - 1) % R);
+                else if constexpr (PH == 1) load_step(CpInt<0>{}, Xs, NROT, nnj, t + R - 1 - KS, (t + R - 1) % R);  // next tile's phase A (behind the barrier)
+                // (last unit of phase A: the m image is complete only behind the barrier -- phase B's first fragments are read there)
+                cp_for_each([&](auto QC) __attribute__((always_inline)) {
+                    constexpr int q = decltype(QC)::value, j = q % nj, prod = q / nj;  // product 0: main, 1: w_hi x_lo, 2: w_lo x_hi
+                    constexpr int fa = PH * NFC + (prod == 2 ? KS + t : t), pl = prod == 1 ? 1 : 0;
+                    if constexpr (prod == 0) {
+                        if constexpr (t == 0) sp_mfma_ac(accm[set][j], wf[fa], bb[t % R][pl][j], bv[PH]);
+                        else sp_mfma_a(accm[set][j], wf[fa], bb[t % R][pl][j]);
+                    } else if constexpr (prod == 1) {
+                        if constexpr (t == 0) sp_mfma_a0(accc[set][j], wf[fa], bb[t % R][pl][j]);
+                        else sp_mfma_a(accc[set][j], wf[fa], bb[t % R][pl][j]);
+                    } else {
+                        if constexpr (fa < 64) sp_mfma_a(accc[set][j], wf[fa], bb[t % R][pl][j]);
+                        else sp_mfma_v(accc[set][j], wf[fa], bb[t % R][pl][j]);
+                    }
+                    constexpr int sl = t * NQ + q;  // MFMA slot of the unit
+                    if constexpr (RIDE) {
+                        cp_for_each([&](auto KC) __attribute__((always_inline)) {
+                            constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
+                            if constexpr (o < SP::cum(sl)) epi_op(CpInt<RGLOBAL ? 1 : 0>{}, pset, o / CT_OPS, lm[PROT][o / CT_OPS].y, pout, o % CT_OPS, pstore);
+                        }, typename CpMakeSeq<SP::MAXPER>::type{});
+                    }
+                    if constexpr (PH == 1 && sl < 2 * nj) {  // this unit's skip values (used by its epilogue inside the next unit)
+                        constexpr int rj = sl >> 1, rp = sl & 1;
+                        rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * GPLANE + lm[ROT][rj].y);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }, typename CpMakeSeq<NQ>::type{});
+                if constexpr (PH == 1 && FIRST && t >= 1 && t - 1 < NPIECE) {
+                    // the tile after this one: the lower half of this board, or the upper half of this workgroup's next board
+                    if constexpr (H == 0) dma_piece(xb, true, 1, t - 1);
+                    else dma_piece(xnb, has_next, 0, t - 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }, typename CpMakeSeq<KS>::type{});
+            if constexpr (PH == 0 && LAST) {
+                // ---- end of phase A: this unit's m values go to LDS exposed, then the barrier, then phase B's first fragments
+                if constexpr (nj == 2) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accm[set][0]), "+v"(accm[set][1]), "+v"(accc[set][0]), "+v"(accc[set][1]));
+                else asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accm[set][0]), "+v"(accc[set][0]));
+#pragma unroll
+                for (int j = 0; j < nj; ++j)
+#pragma unroll
+                    for (int o = 0; o < CTM; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, o, true);
+                CV_BARRIER();
+#pragma unroll
+                for (int s = 0; s < R - 1; ++s) load_step(CpInt<1>{}, Ms, NROT, nnj, s, s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto segment = [&](auto GC) __attribute__((always_inline)) {
+            constexpr int SG = decltype(GC)::value;
+            cp_for_each([&](auto UC) __attribute__((always_inline)) { unit(CpInt<SG>{}, UC); }, typename CpMakeSeq<G::seg_nu(SG)>::type{});
+        };
+        segment(CpInt<0>{});
+        segment(CpInt<1>{});
+        segment(CpInt<2>{});
+        segment(CpInt<3>{});
+        yprev = ybase;
+    }
+    // epilogue of the very last unit (phase B of the lower half, last unit: accumulator set 1, lane-table registers of sequence number 20)
+    {
+        constexpr int nj = G::unit_nj(3, G::seg_nu(3) - 1), ROT = (G::NSEQ - 1) % 3;
+        static_assert(nj == 1, "the board's last unit holds one column tile");
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accm[1][0]), "+v"(accc[1][0]));
+#pragma unroll
+        for (int j = 0; j < nj; ++j)
+#pragma unroll
+            for (int o = 0; o < CTG; ++o) epi_op(CpInt<1>{}, 1, j, lm[ROT][j].y, yprev, o, true);
+    }
+    sp_range_report(mx, range);
+}
+#endif  // __HIPCC__

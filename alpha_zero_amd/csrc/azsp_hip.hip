@@ -10,6 +10,7 @@
 #include "az_conv19.h"
 #include "az_conv_sp.h"
 #include "az_conv_sp17.h"
+#include "az_resblock_sp17.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -310,6 +311,16 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
     if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st, range);
     return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st, range);
+}
+int launch_resblock_split(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
+                          void* st, unsigned* range) {
+    if (S != Sb17::S || C != 64) return 1;  // 17x17 planes x 64 filters: the 13x13 Gomoku tower
+    const int n_cu = cu_count();
+    if (n_cu < 0) return -1;
+    const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles x two phases
+    hipLaunchKernelGGL(k_resblock_sp17, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+                       (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
+    return AZ_HIP(hipGetLastError());
 }
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st, unsigned* range) {
     if (cin < 1 || cin > 32 || S < 1) return 1;

@@ -551,6 +551,9 @@ int launch_tile_layout(const void* src, void* dst, long long boards, int S, int 
 int launch_split_layout(const void* src, void* dst, long long boards, int S, int C, int to_split, void* stream, unsigned* range);
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void* stream, unsigned* range);
+// one whole ResNetBlock on the split layout in one launch (17x17 x 64: az_resblock_sp17.h); 1 = unsupported shape
+int launch_resblock_split(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
+                          void* stream, unsigned* range);
 struct HeadSplitArgs {
     const void* x;
     const float *hw, *hb, *wp_t, *bp, *w1_t, *b1, *w2;
@@ -1065,6 +1068,14 @@ int azsp_conv3x3_split(const void* x, const void* w, const float* bias, const vo
     if (S == 17 && res == y) return AZSP_EINVAL;
     if (boards == 0) return AZSP_OK;
     const int rc = azb::launch_conv3x3_split(x, w, bias, res, y, (long long)boards, S, C, relu, stream, range_rec);
+    return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
+}
+
+int azsp_resblock_split(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, int64_t boards, int32_t S, int32_t C,
+                        uint32_t* range_rec, void* stream) {
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || x == y || boards < 0 || boards > 0x7fffffff) return AZSP_EINVAL;
+    if (boards == 0) return AZSP_OK;
+    const int rc = azb::launch_resblock_split(x, w1, b1, w2, b2, y, (long long)boards, S, C, stream, range_rec);
     return rc == 0 ? AZSP_OK : (rc > 0 ? AZSP_EINVAL : AZSP_EDEVICE);
 }
 

@@ -92,6 +92,7 @@ def parse_args(argv=None):
                     help="evaluator precision class: fp32 (default) = the reference's (pipeline.py:91-123 evaluates in fp32) on the hand-written "
                          "split-precision kernels (hi + lo f16 pairs, three MFMA products, fp32 accumulation); bf16 / fp16 = the lower-precision evaluators")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fused-block", action="store_true", help="A/B: two convolution launches per ResNetBlock even where a one-launch block kernel exists")
     ap.add_argument("--stagger", type=int, default=60, help="random opening plies per slot so game phases are mixed from the start")
     ap.add_argument("--preroll-rounds", type=int, default=300, help="minimum untimed rounds after the stagger (steady state, see module docstring)")
     ap.add_argument("--preroll-moves", type=int, default=2, help="every slot must have committed this many searched moves before timing")
@@ -277,7 +278,8 @@ def tower_replay(actor, args, dev, reps=5):
     tiled = args.net_dtype != "fp32" and getattr(inf, "_tiled", None) is not None and actor.tiled_features
     if not (split or tiled):
         return None
-    fused = tiled and inf.use_fused_block and (args.filters, S_t) in ((64, 17), (64, 9)) and args.net_dtype == "bf16"  # one launch per ResNetBlock
+    fused = inf.use_fused_block and ((tiled and (args.filters, S_t) in ((64, 17), (64, 9)) and args.net_dtype == "bf16")  # one launch per ResNetBlock
+                                     or (split and (args.filters, S_t) in inf.SPLIT_FUSED_SHAPES))
     e = actor.engine
     # re-create the forward's tower input: run the stem of the engine-facing forward once more on the live features (slot 0's buffer `a`)
     if split:
@@ -305,6 +307,13 @@ def tower_replay(actor, args, dev, reps=5):
         k = 0
         ev[rep][0].record()
         for i in range(inf.n_blocks):  # the forward's own launch sequence
+            if fused and split:
+                assert dll.azsp_resblock_split(a.data_ptr(), inf.wsp[2 * i].data_ptr(), inf.b_sp[2 * i].data_ptr(), inf.wsp[2 * i + 1].data_ptr(),
+                                               inf.b_sp[2 * i + 1].data_ptr(), o.data_ptr(), rows, S_t, args.filters, rr, st) == 0
+                k += 1
+                ev[rep][k].record()
+                a, o = o, a
+                continue
             if fused:
                 assert dll.azsp_resblock_tiled(a.data_ptr(), inf.wp[2 * i].data_ptr(), inf.b32[2 * i].data_ptr(), inf.wp[2 * i + 1].data_ptr(),
                                                inf.b32[2 * i + 1].data_ptr(), o.data_ptr(), rows, S_t, args.filters, st) == 0
@@ -365,7 +374,7 @@ def tower_roofline(conv, args, step_ms):
     # HBM traffic per launch is NOT measured in this run: it comes from a separate `rocprofv3 --pmc` pass (the guide's recipe: counters in
     # their own run) whose summary is committed under profiles/ -- labelled as such in `traffic_source`
     if split:
-        cname = "split_kernel_pmc.json" if S_t == 9 else "split17_kernel_pmc.json"
+        cname = "split_kernel_pmc.json" if S_t == 9 else ("splitblock17_kernel_pmc.json" if fused else "split17_kernel_pmc.json")
     else:
         cname = "block64_kernel_pmc.json" if fused else {(9, 128): "conv_kernel_pmc.json", (19, 256): "conv19_kernel_pmc.json"}.get((S_t, args.filters), "conv64_kernel_pmc.json")
     ctraffic, csrc = None, None
@@ -387,9 +396,14 @@ def tower_roofline(conv, args, step_ms):
         issued = SPLIT_PRODUCTS * conv_flops
         tf = issued / (conv["avg_ms"] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS["fp16"]
-        kname = ("k_conv3x3_sp" if S_t == 9 else "k_conv3x3_sp17") + (" (split-precision 3x3 convolution of the residual tower: hi + lo f16 pairs, "
-                                                                     "three f16 MFMA products per multiply, fp32 accumulation; weight-stationary)")
-        elem, passes = 4, 2.5  # hi + lo f16 = 4 bytes per activation element; x in, y out, residual on every second layer
+        if fused:
+            kname = ("k_resblock_sp17 (one whole split-precision ResNetBlock per launch: both 3x3 convolutions, hi + lo f16 pairs, three f16 MFMA "
+                     "products per multiply, fp32 accumulation; intermediate activation in LDS, skip from the input)")
+            elem, passes = 4, 2.0  # x in, y out
+        else:
+            kname = ("k_conv3x3_sp" if S_t == 9 else "k_conv3x3_sp17") + (" (split-precision 3x3 convolution of the residual tower: hi + lo f16 pairs, "
+                                                                         "three f16 MFMA products per multiply, fp32 accumulation; weight-stationary)")
+            elem, passes = 4, 2.5  # hi + lo f16 = 4 bytes per activation element; x in, y out, residual on every second layer
         extra = {"mfma_products_per_multiply": SPLIT_PRODUCTS, "alg_flops_per_launch": conv_flops, "issued_f16_mfma_flops_per_launch": issued,
                  "fp32_equivalent_tflops": round(conv_flops / (conv["avg_ms"] * 1e-3) / 1e12, 2), "fp32_mfma_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
                  "fp32_equivalent_over_fp32_mfma_peak": round(conv_flops / (conv["avg_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS["fp32"], 3),
@@ -473,6 +487,8 @@ def main(argv=None):
         act = SelfPlayActor(net, game=game, board_size=n, num_games=args.games, num_simulations=args.sims, num_parallel=args.parallel,
                             warm_up_steps=16 if n <= 13 else 30, resign_threshold=-1.0, seed=1, rank=rank, device=dev, net_dtype=DT[dtype_name],
                             use_graph=not args.no_graph, engine_kw=None if reuse_tree else {"reuse_tree": False}, use_split_evaluator=split)
+        if args.no_fused_block:
+            act.infer.use_fused_block = False
         e = act.engine
         if args.stagger > 0:  # mixed game phases from the first round (documented in DESIGN.md "Measurement")
             rng = np.random.Generator(np.random.PCG64(1234 + rank))

@@ -292,6 +292,15 @@ int azsp_split_layout(const void* src_dev, void* dst_dev, int64_t boards, int32_
 int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* bias_dev, const void* residual_dev, void* y_dev,
                        int64_t boards, int32_t board_size, int32_t channels, int32_t relu, uint32_t* range_rec_dev, void* stream);
 
+/* One whole ResNetBlock (core/network.py:42-82: conv3x3 + BN + ReLU + conv3x3 + BN, + skip, ReLU; eval mode, BatchNorm folded) at the
+ * reference's precision class in ONE launch on the split layout: y = relu(conv3x3(relu(conv3x3(x, w1) + b1), w2) + b2 + x).  The
+ * intermediate activation stays in LDS (half-board tiles, the halo row of each half recomputed), so a block moves two tensor passes
+ * through HBM instead of five; results are bit-identical to two azsp_conv3x3_split calls (same MFMA order, same roundings).  w1 / w2 in
+ * the packing of azsp_conv3x3_split, b1 / b2 float[64]; y must NOT alias x.  On the device: (S, C) = (17, 64), the 13x13 Gomoku tower
+ * (az_resblock_sp17.h); AZSP_EINVAL for other shapes.  range_rec_dev as above. */
+int azsp_resblock_split(const void* x_dev, const void* w1_split_dev, const float* bias1_dev, const void* w2_split_dev, const float* bias2_dev,
+                        void* y_dev, int64_t boards, int32_t board_size, int32_t channels, uint32_t* range_rec_dev, void* stream);
+
 /* The rest of the fp32-class evaluator on the split layout (core/network.py:101-156):
  * azsp_split_features: observation planes [boards][in_channels <= 32][S][S] fp32 (the engine's AZSP_FEAT_F32 features) -> split
  *   layout with 32 channels (the missing ones zero), azsp_split_bytes(boards, S, 32) bytes.  Not needed when the engine writes its

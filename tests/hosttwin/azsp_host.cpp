@@ -166,6 +166,14 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
     SpRangeScope scope(range);
     return host_conv_split(x, w, bias, res, y, boards, S, C, C, relu);
 }
+int launch_resblock_split(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
+                          void*, unsigned* range) {
+    if (S != 17 || C != 64) return 1;
+    SpRangeScope scope(range);
+    std::vector<unsigned short> mid((size_t)boards * 2 * S * S * C);
+    if (host_conv_split(x, w1, b1, nullptr, mid.data(), boards, S, C, C, 1)) return 1;
+    return host_conv_split(mid.data(), w2, b2, x, y, boards, S, C, C, 1);
+}
 int split_range_read(const unsigned* rec, unsigned out[2], int reset, void*) {
     unsigned* r = rec ? (unsigned*)rec : g_sp_range_host;
     out[0] = r[0], out[1] = r[1];

@@ -480,3 +480,102 @@ def test_gpu_stem_on_engine_written_features_equals_the_general_stem(game, n, fi
         p0, v0 = inf.forward_split(x.cuda().contiguous())
         p1, v1 = inf.forward_split(eu.split_features(x).cuda(), split_features=(rows, n))
         assert torch.equal(p0, p1) and torch.equal(v0, v1), (game, n, filters, rows, float((p0 - p1).abs().max()))
+
+
+# ---- fused split-precision ResNetBlock at 17x17 x 64 (az_resblock_sp17.h, azsp_resblock_split) ------------------------------------
+def _resblock_inputs(boards, seed):
+    g = torch.Generator().manual_seed(seed)
+    C, S = 64, 17
+    x = torch.randn(boards, C, S, S, generator=g)
+    x = torch.where(torch.rand(boards, C, S, S, generator=g) < 0.5, torch.zeros(()), x.abs())
+    x[:, :8] *= 37.0
+    x[:, -8:] *= 3e-3
+    ws = [torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5 for _ in range(2)]
+    bs = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+    return x, ws, bs
+
+
+def _resblock_both_ways(bnd, x, ws, bs, device):
+    """(fused y, two-launch y) in the split layout, as raw f16 tensors, + the fused result as fp32 NCHW."""
+    B, C, S, _ = x.shape
+    dll = bnd.dll
+    n = dll.azsp_split_bytes(B, S, C) // 2
+    xs, ms, y2, yf = (torch.zeros(n, dtype=torch.float16, device=device) for _ in range(4))
+    xc = x.to(device).contiguous(memory_format=torch.channels_last)
+    assert dll.azsp_split_layout(xc.data_ptr(), xs.data_ptr(), B, S, C, 1, None, None) == 0
+    wsp = [split_weights_f16(w).to(device) for w in ws]
+    bb = [b.float().to(device) for b in bs]
+    assert dll.azsp_conv3x3_split(xs.data_ptr(), wsp[0].data_ptr(), bb[0].data_ptr(), None, ms.data_ptr(), B, S, C, 1, None, None) == 0
+    assert dll.azsp_conv3x3_split(ms.data_ptr(), wsp[1].data_ptr(), bb[1].data_ptr(), xs.data_ptr(), y2.data_ptr(), B, S, C, 1, None, None) == 0
+    assert dll.azsp_resblock_split(xs.data_ptr(), wsp[0].data_ptr(), bb[0].data_ptr(), wsp[1].data_ptr(), bb[1].data_ptr(), yf.data_ptr(), B, S, C, None, None) == 0
+    y = torch.empty_like(xc)
+    assert dll.azsp_split_layout(yf.data_ptr(), y.data_ptr(), B, S, C, 0, None, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    return yf, y2, y.cpu().contiguous()
+
+
+def test_split_resblock_abi_host_twin():
+    """azsp_resblock_split through the ABI on the host twin: equals two azsp_conv3x3_split calls; argument checks (y == x refused,
+    shapes without a fused kernel refused)."""
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    x, ws, bs = _resblock_inputs(2, 3)
+    yf, y2, y = _resblock_both_ways(bnd, x, ws, bs, "cpu")
+    assert torch.equal(yf, y2)
+    mid = torch.relu(F.conv2d(x.double(), ws[0].double(), bs[0].double(), padding=1))
+    ref = torch.relu(F.conv2d(mid, ws[1].double(), bs[1].double(), padding=1) + x.double())
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+    z = torch.zeros(2 * 2 * 17 * 17 * 64, dtype=torch.float16)
+    assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 17, 64, None, None) != 0  # y == x
+    zo = z.clone()
+    assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 9, 64, None, None) != 0
+    assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 17, 128, None, None) != 0
+    assert bnd.dll.azsp_resblock_split(None, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 17, 64, None, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 2, 3, 255, 256, 257, 513, 1100])
+def test_gpu_split_resblock17_bit_identical_to_two_launches(boards):
+    """k_resblock_sp17 (one launch per ResNetBlock, intermediate activation in LDS, half-board tiles with a recomputed halo row) gives
+    bit for bit the split-layout output of two k_conv3x3_sp17 launches -- every position's MFMA order and every rounding are the same.
+    Board counts around one / two / four boards per workgroup slot (256 slots) exercise the first-board, has-next and last-board paths
+    of the persistent loop.  Also against fp64: the block's error is of the size of two fp32 convolutions' round-off."""
+    from alpha_zero_amd import _lib
+
+    x, ws, bs = _resblock_inputs(boards, 100 + boards)
+    yf, y2, y = _resblock_both_ways(_lib.load(), x, ws, bs, "cuda")
+    if not torch.equal(yf, y2):
+        B, C, S = boards, 64, 17
+        d = (yf.view(B, 2, C // 8, S * S, 8) != y2.view(B, 2, C // 8, S * S, 8)).any(dim=4).any(dim=1)  # [B, chunk, pos]
+        bad = d.nonzero()
+        raise AssertionError(f"{len(bad)} (board, chunk, position) cells differ; first {bad[:12].tolist()}; rows {sorted(set((bad[:, 2] // 17).tolist()))[:20]}")
+    mid = torch.relu(F.conv2d(x.double(), ws[0].double(), bs[0].double(), padding=1))
+    ref = torch.relu(F.conv2d(mid, ws[1].double(), bs[1].double(), padding=1) + x.double())
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_gpu_split_resblock17_records_intermediate_overflow():
+    """The intermediate activation of the fused block is clamped and recorded exactly like the output of a first launch would be: a
+    block whose FIRST convolution leaves f16's range reports events in the caller's record although that tensor never reaches HBM."""
+    from alpha_zero_amd import _lib
+
+    dll = _lib.load().dll
+    x, ws, bs = _resblock_inputs(5, 9)
+    ws[0] = ws[0] * 4000.0   # m ~ 1e5 .. 1e6
+    ws[1] = ws[1] / 4000.0
+    B, C, S = 5, 64, 17
+    n = dll.azsp_split_bytes(B, S, C) // 2
+    xs, yf = torch.zeros(n, dtype=torch.float16, device="cuda"), torch.zeros(n, dtype=torch.float16, device="cuda")
+    xc = x.cuda().contiguous(memory_format=torch.channels_last)
+    rec = torch.zeros(2, dtype=torch.int32, device="cuda")
+    assert dll.azsp_split_layout(xc.data_ptr(), xs.data_ptr(), B, S, C, 1, rec.data_ptr(), None) == 0
+    wsp = [split_weights_f16(w).cuda() for w in ws]
+    bb = [b.float().cuda() for b in bs]
+    assert dll.azsp_resblock_split(xs.data_ptr(), wsp[0].data_ptr(), bb[0].data_ptr(), wsp[1].data_ptr(), bb[1].data_ptr(), yf.data_ptr(), B, S, C,
+                                   rec.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    r = rec.cpu()
+    assert int(r[0]) > 0 and float(r[1:].view(torch.float32)[0]) > 65504.0
