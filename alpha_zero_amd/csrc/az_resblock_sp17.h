@@ -123,13 +123,14 @@ static_assert(sb17_make_map().ok, "column-tile maps of the fused 17x17 block: ev
 static __device__ const Sb17Map sb17_map = sb17_make_map();
 
 // w1, w2: [plane: hi, lo][9 taps][64 couts][64 cin] f16 with lo = (w - hi) * 2^11 (the packing of azsp_conv3x3_split); b1, b2 fp32 [64].
-__global__ void __launch_bounds__(CW_THREADS, 1)
+// R = slots of the B-fragment ring (k-steps): a fragment is requested R - 1 k-steps before its MFMAs.
+template <int R> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__ w1, const float* __restrict__ b1, const _Float16* __restrict__ w2,
                 const float* __restrict__ b2, unsigned char* __restrict__ y, int nboards, unsigned* range) {
     typedef Sb17 G;
     constexpr int C = 64, NCH = 8, CIN = 64, KSUB = 2;
     constexpr int KS = 9 * KSUB;                             // k-steps per unit (one tap x 32 input channels)
-    constexpr int NJM = 2, R = 3;                            // most column tiles per unit; ring slots (k-steps)
+    constexpr int NJM = 2;                                   // most column tiles per unit
     constexpr int XBLK = G::XCELLS * 16, XPLANE = NCH * XBLK, XBUF = 2 * XPLANE;    // 4096, 32768, 65536
     constexpr int MBLK = G::MCELLS * 16, MPLANE = NCH * MBLK, MBUF = 2 * MPLANE;    // 3840, 30720, 61440
     constexpr int TBL0 = XBUF + MBUF, TBL = G::NTILE * 64 * 8;                      // lane table: [tile][lane] {B base offset, output offset}
@@ -330,7 +331,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
             static_assert(!RIDE || pset != set, "a unit and the epilogue riding in it use different accumulator sets");
             constexpr int CT_OPS = RGLOBAL ? CTG : CTM;
             constexpr int NQ = 3 * nj, P_OPS = RIDE ? pnj * CT_OPS : 1;              // MFMAs per k-step; micro-ops of the riding epilogue
-            constexpr int AVAIL = (PH == 1 && LAST ? (KS - (R - 1)) * NQ : NQ * KS - 4) - S0;  // (riders end before the tile's second barrier)
+            constexpr int AVAIL = NQ * KS - 4 - S0;                                  // the riders end 4 slots before the unit does
             typedef SpSpread<P_OPS, S0, AVAIL> SP;
             static_assert(SP::MAXPER <= 2, "the previous unit's epilogue fits this unit's MFMA gaps");
             const unsigned char* img = PH ? Ms : Xs;

@@ -318,8 +318,16 @@ int launch_resblock_split(const void* x, const void* w1, const float* b1, const 
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
     const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles x two phases
-    hipLaunchKernelGGL(k_resblock_sp17, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
-                       (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
+    static const int ring = [] {  // experiment knob (profiles/r05_*): AZSP_RB_RING=3 selects the shallow B-fragment ring
+        const char* e = getenv("AZSP_RB_RING");
+        return e && atoi(e) == 3 ? 3 : 6;
+    }();
+    if (ring == 3)
+        hipLaunchKernelGGL(k_resblock_sp17<3>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+                           (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
+    else
+        hipLaunchKernelGGL(k_resblock_sp17<6>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+                           (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
     return AZ_HIP(hipGetLastError());
 }
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st, unsigned* range) {
