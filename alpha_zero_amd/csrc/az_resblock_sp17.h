@@ -121,6 +121,26 @@ constexpr Sb17Map sb17_make_map() {
 }
 static_assert(sb17_make_map().ok, "column-tile maps of the fused 17x17 block: every position of every segment covered, conflict-free lane groups");
 static __device__ const Sb17Map sb17_map = sb17_make_map();
+typedef __attribute__((address_space(1))) unsigned char* sb17_gptr;         // pointers into global memory whose value the compiler must take
+typedef const __attribute__((address_space(1))) unsigned char* sb17_gcptr;  // as given (an opaque scalar base per plane, see the board loop)
+
+// f32 v minus the f16 half H of hpk: the remainder v - hi of the split, exact in fp32, one v_fma_mix_f32
+template <int H> __device__ __forceinline__ float sb17_mix_diff(unsigned hpk, float v) {
+    float r;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+    return r;
+}
+// f16(d * 2^11) (the product is exact in fp32: one rounding, to nearest even) into the low / high half of a packed pair
+__device__ __forceinline__ unsigned sb17_scale_cvt_lo(float d) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(r) : "v"(d), "s"(SP_SCALE));
+    return r;
+}
+__device__ __forceinline__ unsigned sb17_scale_cvt_hi(unsigned lo, float d) {
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(d), "s"(SP_SCALE));
+    return lo;
+}
 
 // w1, w2: [plane: hi, lo][9 taps][64 couts][64 cin] f16 with lo = (w - hi) * 2^11 (the packing of azsp_conv3x3_split); b1, b2 fp32 [64].
 // R = slots of the B-fragment ring (k-steps): a fragment is requested R - 1 k-steps before its MFMAs.
@@ -138,11 +158,12 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     constexpr int NP = G::XCELLS / 64;                       // DMA pieces of 64 cells per strip
     constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips and DMA pieces per wave and tile: 4, 16
     constexpr int NFC = 2 * KS, NF = 2 * NFC;                // A fragments per convolution (2 planes x 18 k-steps), in all: 72
-    // epilogue micro-ops per column tile.  TO THE M IMAGE (phase A): per element 4 (join, ReLU, range record, clamp), per pair of
-    // elements 6 more (packed hi convert, 2 scalings, 2 remainders, packed lo convert), 2 LDS stores: 30.  TO GLOBAL MEMORY (phase B):
-    // per element 6 (join, residual join, add, ReLU, range record, clamp), per pair 6 more, 2 stores: 38.
-    constexpr int E1M = 4, PAIRM = 2 * E1M + 6, CTM = 2 * PAIRM + 2;
-    constexpr int E1G = 6, PAIRG = 2 * E1G + 6, CTG = 2 * PAIRG + 2;
+    // epilogue micro-ops per column tile.  TO THE M IMAGE (phase A): per element 3 (join, range record, ReLU + clamp in one v_med3_f32), per
+    // pair of elements 5 more (packed hi convert, 2 exact remainders v - hi, 2 scale-and-convert v_fma_mixlo/hi_f16), 2 LDS stores: 24.
+    // TO GLOBAL MEMORY (phase B): per element 5 (join, skip join, add, range record, ReLU + clamp), per pair 5 more, 2 stores: 32.
+    // (k_conv3x3_sp17 spends 30 / 38 on the same arithmetic; the results are bit-identical.)
+    constexpr int E1M = 3, PAIRM = 2 * E1M + 5, CTM = 2 * PAIRM + 2;
+    constexpr int E1G = 5, PAIRG = 2 * E1G + 5, CTG = 2 * PAIRG + 2;
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert(KS % R == 0, "every unit starts at ring phase 0");
     static_assert(KS - 2 >= NPIECE, "the next tile's pieces ride in the first unit of phase B");
@@ -163,11 +184,13 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
         const int pos = sb17_map.pos[tile * 16 + tl15], r = pos / G::S, xx = pos % G::S;
         const int base = G::PITCH * (r - G::seg_rbase(g)) + xx;
         unsigned boff, ooff;
+        // B bases are offsets from the start of the LDS block (phase B's include the m image's own offset XBUF): every fragment
+        // address is lane register + an immediate below 64 K, the k-loop carries no address arithmetic
         if (G::seg_ph(g) == 0) {
             boff = (unsigned)(base * 16 + tkg * XBLK);
-            ooff = (unsigned)((base + G::m_cell_of_base(G::seg_h(g))) * 16 + (tkg & 1) * 8 + (tkg >> 1) * MBLK);
+            ooff = (unsigned)(XBUF + (base + G::m_cell_of_base(G::seg_h(g))) * 16 + (tkg & 1) * 8 + (tkg >> 1) * MBLK);
         } else {
-            boff = (unsigned)(base * 16 + tkg * MBLK);
+            boff = (unsigned)(XBUF + base * 16 + tkg * MBLK);
             ooff = (unsigned)(pos * 16 + (tkg >> 1) * GBLK + (tkg & 1) * 8);
         }
         *(cv_u32x2*)(lds + TBL0 + i * 8) = (cv_u32x2){boff, ooff};
@@ -209,8 +232,8 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                      : "memory");
     };
     const unsigned char* Xs = lds;
-    const unsigned char* Ms = lds + XBUF;
-    unsigned char* Mw = lds + XBUF + (wave * 2) * MBLK;     // this wave's two chunk strips of the m image (hi plane; lo at + MPLANE)
+    const unsigned char* Ms = lds;                           // (phase B's lane-table offsets carry the m image's offset XBUF)
+    unsigned char* Mw = lds + (wave * 2) * MBLK;             // this wave's two chunk strips of the m image (table offsets carry XBUF; lo plane at + MPLANE)
     const unsigned char* tbl = lds + TBL0 + lane * 8;
     cv_u32x2 lm[3][NJM];  // rotating lane-table registers [unit sequence number % 3][column tile of the unit] = {B base offset, output offset}
 #pragma unroll
@@ -266,9 +289,9 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     unsigned hpk[2] = {0u, 0u}, lpk[2] = {0u, 0u};
     // micro-op `o` of the epilogue of column tile j of the unit with accumulator set `set`: ONE VALU / memory instruction.
     // GLOBAL = false: phase A (bias + ReLU -> m image at Mw + ooff); true: phase B (bias + skip + ReLU -> global memory at out + ooff)
-    auto epi_op = [&](auto GC, int set, int j, unsigned ooff, unsigned char* out, int o, bool store_ok) __attribute__((always_inline)) {
+    auto epi_op = [&](auto GC, int set, int j, unsigned ooff, unsigned char* out, sb17_gptr out_lo, int o, bool store_ok) __attribute__((always_inline)) {
         constexpr bool GLOBAL = decltype(GC)::value != 0;
-        constexpr int E1 = GLOBAL ? E1G : E1M, PAIR = 2 * E1 + 6;
+        constexpr int E1 = GLOBAL ? E1G : E1M, PAIR = 2 * E1 + 5;
         if (o < 2 * PAIR) {
             const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
             if (k < 2 * E1) {
@@ -278,22 +301,20 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                 if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
                 else if (GLOBAL && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
                 else if (GLOBAL && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
-                else if (tail == 0) evv[ei] = fmaxf(evv[ei], 0.0f);
-                else if (tail == 1) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
-                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], -SP_F16_MAX, SP_F16_MAX);                   // ... is clamped here (and recorded)
+                else if (tail == 0) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
+                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], 0.0f, SP_F16_MAX);                           // ... is clamped here (ReLU in the same median)
             } else {
                 const int kk = k - 2 * E1;
                 if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
-                else if (kk == 1) sc[0] = evv[0] * SP_SCALE;
-                else if (kk == 2) sc[1] = evv[1] * SP_SCALE;
-                else if (kk == 3) sc[0] = sp_mix_rem<0>(hpk[pr], sc[0]);
-                else if (kk == 4) sc[1] = sp_mix_rem<1>(hpk[pr], sc[1]);
-                else lpk[pr] = sp_cvt_pk(sc[0], sc[1]);
+                else if (kk == 1) sc[0] = sb17_mix_diff<0>(hpk[pr], evv[0]);   // v - hi, exact in fp32
+                else if (kk == 2) sc[1] = sb17_mix_diff<1>(hpk[pr], evv[1]);
+                else if (kk == 3) lpk[pr] = sb17_scale_cvt_lo(sc[0]);           // f16((v - hi) * 2^11) into the low half ...
+                else lpk[pr] = sb17_scale_cvt_hi(lpk[pr], sc[1]);               // ... and the high half: one rounding each, as v_cvt_pk_f16_f32 does
             }
         } else if constexpr (GLOBAL) {
             if (o == 2 * PAIR) {
                 if (store_ok) *(cv_u32x2*)(out + ooff) = (cv_u32x2){hpk[0], hpk[1]};
-            } else if (store_ok) *(cv_u32x2*)(out + GPLANE + ooff) = (cv_u32x2){lpk[0], lpk[1]};
+            } else if (store_ok) *(__attribute__((address_space(1))) cv_u32x2*)(out_lo + ooff) = (cv_u32x2){lpk[0], lpk[1]};
         } else {
             if (o == 2 * PAIR) *(cv_u32x2*)(Mw + ooff) = (cv_u32x2){hpk[0], hpk[1]};
             else *(cv_u32x2*)(Mw + MPLANE + ooff) = (cv_u32x2){lpk[0], lpk[1]};
@@ -302,13 +323,20 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
 
     int it = 0;
     unsigned char* yprev = y;
+    sb17_gptr yprev_lo = (sb17_gptr)(unsigned long long)y;
     for (int board = slot; board < nboards; board += nslot, ++it) {
         const bool has_next = board + nslot < nboards;
         const unsigned char* xb = x + (size_t)board * GTILE;
         const unsigned char* xnb = x + (size_t)(has_next ? board + nslot : board) * GTILE;
         const size_t yo = (size_t)board * GTILE + (size_t)(wave * 2) * GBLK;  // uniform: the lane part comes from the lane table
         const unsigned char* rbase = xb + (size_t)(wave * 2) * GBLK;          // the skip = the block's own input
+        // one uniform base per plane, opaque to the compiler (it would otherwise fold base + GPLANE + lane offset into 64-bit VALU adds
+        // per access: GPLANE exceeds the 13-bit immediate): every skip load / y store is scalar base + lane offset
+        unsigned long long rlo = (unsigned long long)rbase + GPLANE, ylo = (unsigned long long)(y + yo) + GPLANE;
+        asm volatile("" : "+s"(rlo), "+s"(ylo));  // (opaque scalars, cast back to GLOBAL-address-space pointers: no flat accesses)
+        const sb17_gcptr rbase_lo = (sb17_gcptr)rlo;
         unsigned char* ybase = y + yo;
+        const sb17_gptr ybase_lo = (sb17_gptr)ylo;
         const bool have_prev = it > 0;
         // unit U of segment SG
         auto unit = [&](auto GC, auto UC) __attribute__((always_inline)) {
@@ -337,6 +365,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
             const unsigned char* img = PH ? Ms : Xs;
             // where the riding epilogue stores: phase B units of the previous board (first unit of a board) or of this board
             unsigned char* pout = SG == 0 ? yprev : ybase;
+            const sb17_gptr pout_lo = SG == 0 ? yprev_lo : ybase_lo;
             const bool pstore = SG == 0 && FIRST ? have_prev : true;
             cp_for_each([&](auto TC) __attribute__((always_inline)) {
                 constexpr int t = decltype(TC)::value;
@@ -367,12 +396,13 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                     if constexpr (RIDE) {
                         cp_for_each([&](auto KC) __attribute__((always_inline)) {
                             constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
-                            if constexpr (o < SP::cum(sl)) epi_op(CpInt<RGLOBAL ? 1 : 0>{}, pset, o / CT_OPS, lm[PROT][o / CT_OPS].y, pout, o % CT_OPS, pstore);
+                            if constexpr (o < SP::cum(sl)) epi_op(CpInt<RGLOBAL ? 1 : 0>{}, pset, o / CT_OPS, lm[PROT][o / CT_OPS].y, pout, pout_lo, o % CT_OPS, pstore);
                         }, typename CpMakeSeq<SP::MAXPER>::type{});
                     }
                     if constexpr (PH == 1 && sl < 2 * nj) {  // this unit's skip values (used by its epilogue inside the next unit)
                         constexpr int rj = sl >> 1, rp = sl & 1;
-                        rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * GPLANE + lm[ROT][rj].y);
+                        if constexpr (rp == 0) rr[set][rj][rp] = *(const cv_u32x2*)(rbase + lm[ROT][rj].y);
+                        else rr[set][rj][rp] = *(const __attribute__((address_space(1))) cv_u32x2*)(rbase_lo + lm[ROT][rj].y);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
@@ -390,7 +420,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
 #pragma unroll
                 for (int j = 0; j < nj; ++j)
 #pragma unroll
-                    for (int o = 0; o < CTM; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, o, true);
+                    for (int o = 0; o < CTM; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, (sb17_gptr)0, o, true);
                 CV_BARRIER();
 #pragma unroll
                 for (int s = 0; s < R - 1; ++s) load_step(CpInt<1>{}, Ms, NROT, nnj, s, s);
@@ -405,7 +435,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
         segment(CpInt<1>{});
         segment(CpInt<2>{});
         segment(CpInt<3>{});
-        yprev = ybase;
+        yprev = ybase, yprev_lo = ybase_lo;
     }
     // epilogue of the very last unit (phase B of the lower half, last unit: accumulator set 1, lane-table registers of sequence number 20)
     {
@@ -415,7 +445,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
 #pragma unroll
         for (int j = 0; j < nj; ++j)
 #pragma unroll
-            for (int o = 0; o < CTG; ++o) epi_op(CpInt<1>{}, 1, j, lm[ROT][j].y, yprev, o, true);
+            for (int o = 0; o < CTG; ++o) epi_op(CpInt<1>{}, 1, j, lm[ROT][j].y, yprev, yprev_lo, o, true);
     }
     sp_range_report(mx, range);
 }
