@@ -148,6 +148,33 @@ template <int H> __device__ __forceinline__ float sp_mix_rem(unsigned hpk, float
 __device__ __forceinline__ unsigned sp_cvt_pk(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
     return __builtin_bit_cast(unsigned, (sp_f16x2){(_Float16)a, (_Float16)b});
 }
+// f32 v minus the f16 half H of hpk: the remainder v - hi of the split, exact in fp32, one v_fma_mix_f32
+template <int H> __device__ __forceinline__ float sp_mix_diff(unsigned hpk, float v) {
+    float r;
+    if constexpr (H == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+    return r;
+}
+// f16(d * 2^11) (the product is exact in fp32: one rounding, to nearest even, as v_cvt_pk_f16_f32 rounds) into the low / high half of a pair
+__device__ __forceinline__ unsigned sp_scale_cvt_lo(float d) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(r) : "v"(d), "s"(SP_SCALE));
+    return r;
+}
+__device__ __forceinline__ unsigned sp_scale_cvt_hi(unsigned lo, float d) {
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(lo) : "v"(d), "s"(SP_SCALE));
+    return lo;
+}
+// Micro-ops of a riding epilogue (shared by the kernels and by the compile-time mirrors of their schedules, sp9_vm_younger /
+// sp17_vm_younger): per element E1 = join, [residual join, add,] range record, ReLU + clamp (one v_med3_f32: the lower bound is 0 with
+// ReLU, -65504 without); per pair of elements 5 more (packed hi convert, 2 exact remainders v - hi, 2 scale-and-convert
+// v_fma_mixlo/hi_f16); per column tile 2 stores.  (Round 4: 6 / 4 per element + 6 per pair = 38 / 30 per column tile; now 32 / 24.)
+__host__ __device__ constexpr int sp_epi_e1(bool res) { return res ? 5 : 3; }
+__host__ __device__ constexpr int sp_epi_pair(bool res) { return 2 * sp_epi_e1(res) + 5; }
+__host__ __device__ constexpr int sp_epi_ct_ops(bool res) { return 2 * sp_epi_pair(res) + 2; }
+typedef __attribute__((address_space(1))) unsigned char* sp_gptr;         // pointers into global memory whose value the compiler takes as
+typedef const __attribute__((address_space(1))) unsigned char* sp_gcptr;  // given: one opaque scalar base per plane (saddr + lane offset)
+
 // Static schedule of a riding epilogue: P_OPS micro-ops spread evenly over the MFMA slots [S0, S0 + AVAIL) of the carrying unit
 // (a 16-cycle MFMA hides about one VALU instruction: a flat ceil(P_OPS / AVAIL) per slot would issue bursts of two early and none late)
 template <int P_OPS, int S0, int AVAIL> struct SpSpread {
@@ -348,9 +375,13 @@ __device__ __forceinline__ void sp_mfma_a0(c6_f32x4& acc, const sp_f16x8& wa, co
 // Vector-memory instructions a wave of k_conv3x3_sp issues between the last LDS-DMA piece of the next board (unit 0, k-step NPIECE) and
 // the board's barrier (unit 1, k-step KS - 2): the stores of the riding epilogues (2 per column tile) and unit 1's residual loads (2 per
 // column tile, first slots of the unit).  Mirrors the kernel's schedule (same constants, same SpSpread arithmetic).
+// Slots of the B-fragment ring (k-steps): a fragment is requested R - 1 k-steps before its MFMAs.  (Round 5 tried 4 slots on the plain
+// 128-filter layer after the PMC wave-cycle breakdown showed 14 - 15 % of the wave time parked at s_waitcnt: no gain on the same box,
+// 1.792 vs 1.794 ms, profiles/r05_split_ablation.txt -- the waits are not fragment latency here; the skip layer has no registers for it.)
+__host__ __device__ constexpr int sp9_ring(int, bool) { return 3; }
 template <bool RES, int NCH, bool XLO0 = false> __host__ __device__ constexpr int sp9_vm_younger() {
-    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (SpGeo9::CELLS + 63) / 64, NPIECE = NP * ((XLO0 ? 1 : 2) * NCH / 4);
-    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
+    constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = sp9_ring(NCH, RES), S0 = 6, NP = (SpGeo9::CELLS + 63) / 64, NPIECE = NP * ((XLO0 ? 1 : 2) * NCH / 4);
+    constexpr int CT_OPS = sp_epi_ct_ops(RES);
     int n = 0;
     for (int i = 0; i < 2; ++i) {
         const int nj = i == 0 ? 3 : 2, pnj = i == 0 ? 2 : 3, NQ = (XLO0 ? 2 : 3) * nj, P_OPS = pnj * CT_OPS;
@@ -390,7 +421,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     typedef SpGeo9 G;
     constexpr int C = 64 * NCG, CIN = 8 * NCH, KSUB = NCH / 4;
     constexpr int KS = 9 * KSUB;                             // k-steps per unit (one tap x 32 input channels)
-    constexpr int NJ0 = 3, NJ1 = 2, R = 3;                   // column tiles of unit 0 / unit 1, ring slots (k-steps)
+    constexpr int NJ0 = 3, NJ1 = 2, R = sp9_ring(NCH, RES);       // column tiles of unit 0 / unit 1, ring slots (k-steps)
     constexpr int LBLK = G::CELLS * 16, LPLANE = NCH * LBLK, LBUF = 2 * LPLANE;
     constexpr int GBLK = G::P2 * 16, XPLANE = NCH * GBLK, XTILE = 2 * XPLANE;
     constexpr int YPLANE = (C / 8) * GBLK, YTILE = 2 * YPLANE;
@@ -399,9 +430,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     constexpr int NPROD = XLO0 ? 2 : 3;                               // MFMA products per multiply
     static_assert(!XLO0 || (!RES && NCH == 4), "exact-f16 inputs: the stem");
     constexpr int NF = 2 * KS, NF_A = NF < 64 ? NF : 64;
-    // epilogue micro-ops: per element E1 (join, [residual join, add,] ReLU, range record, clamp), per pair of elements 6 more (packed hi
-    // convert, 2 scalings, 2 remainders, packed lo convert), per column tile 2 stores
-    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
+    constexpr int E1 = sp_epi_e1(RES), PAIR = sp_epi_pair(RES), CT_OPS = sp_epi_ct_ops(RES);  // epilogue micro-ops (see sp_epi_e1)
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert((2 * KS) % R == 0, "a board's k-steps keep the ring phase");
     static_assert(KS - 1 >= NPIECE, "the next board's pieces ride in unit 0");
@@ -445,6 +474,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = bias[cg * 64 + wave * 16 + 4 * kg + e];
     const float lo_relu = relu ? 0.0f : -__builtin_inff();
+    const float lo_clamp = relu ? 0.0f : -SP_F16_MAX;  // lower bound of the epilogue's median: ReLU and the range clamp in one instruction
 
     // LDS-DMA plan: a strip is NP pieces of 64 cells; wave q moves strips SPW q .. SPW q + SPW - 1 (strip = plane * NCH + chunk)
     unsigned dsrc[NP];
@@ -475,6 +505,16 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                   ((unsigned)(pos * 16 + (kg >> 1) * GBLK + (kg & 1) * 8) << 16);
     }
     static_assert(G::P2 * 16 + GBLK + 8 < 65536, "output slot offsets fit 16 bits");
+    // the output slot offsets once more as plain 32-bit lane offsets: a global access is then scalar base + this register (the
+    // `out_off` barrier below keeps the zero-extension next to its use, where instruction selection folds it into the saddr form)
+    unsigned omap[G::NCT];
+#pragma unroll
+    for (int j = 0; j < G::NCT; ++j) omap[j] = lmap[j] >> 16;
+    auto out_off = [&](int j) __attribute__((always_inline)) {
+        unsigned v = omap[j];
+        asm volatile("" : "+v"(v));
+        return v;
+    };
     sp_f16x8 bb[R][2][NJ0];  // ring of B fragments [k-step slot][plane][column tile of the unit]
     auto load_step = [&](const unsigned char* img, int j0, int nj, int s, int rs) {
         const int tap = s / KSUB;
@@ -517,7 +557,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
     float evv[2] = {0.0f, 0.0f}, sc[2] = {0.0f, 0.0f}, t0 = 0.0f, mx = 0.0f;  // mx: the largest |value| this lane produced (range record, sp_range_report)
     unsigned hpk[2] = {0u, 0u}, lpk[2] = {0u, 0u};
     // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`: ONE VALU / memory instruction
-    auto epi_op = [&](int set, int j, int mj, unsigned char* out, int o, bool store_ok) {
+    auto epi_op = [&](int set, int j, int mj, unsigned char* out, sp_gptr out_lo, int o, bool store_ok) {
         if (o < 2 * PAIR) {
             const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
             if (k < 2 * E1) {
@@ -527,23 +567,21 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                 if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
                 else if (RES && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
                 else if (RES && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
-                else if (tail == 0) evv[ei] = fmaxf(evv[ei], lo_relu);
-                else if (tail == 1) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
-                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], -SP_F16_MAX, SP_F16_MAX);                   // ... is clamped here (and recorded)
+                else if (tail == 0) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
+                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], lo_clamp, SP_F16_MAX);                       // ... is clamped here (ReLU in the same median)
             } else {
                 const int kk = k - 2 * E1;
                 if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
-                else if (kk == 1) sc[0] = evv[0] * SP_SCALE;
-                else if (kk == 2) sc[1] = evv[1] * SP_SCALE;
-                else if (kk == 3) sc[0] = sp_mix_rem<0>(hpk[pr], sc[0]);
-                else if (kk == 4) sc[1] = sp_mix_rem<1>(hpk[pr], sc[1]);
-                else lpk[pr] = sp_cvt_pk(sc[0], sc[1]);
+                else if (kk == 1) sc[0] = sp_mix_diff<0>(hpk[pr], evv[0]);
+                else if (kk == 2) sc[1] = sp_mix_diff<1>(hpk[pr], evv[1]);
+                else if (kk == 3) lpk[pr] = sp_scale_cvt_lo(sc[0]);
+                else lpk[pr] = sp_scale_cvt_hi(lpk[pr], sc[1]);
             }
         } else {
-            const unsigned gq = lmap[mj] >> 16;
+            const unsigned gq = out_off(mj);
             if (o == 2 * PAIR) {
                 if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){hpk[0], hpk[1]};
-            } else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){lpk[0], lpk[1]};
+            } else if (store_ok) *(__attribute__((address_space(1))) cv_u32x2*)(out_lo + gq) = (cv_u32x2){lpk[0], lpk[1]};
         }
     };
 
@@ -562,6 +600,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
 
     int it = 0;
     unsigned char* yprev = y;
+    sp_gptr yprev_lo = (sp_gptr)(unsigned long long)y;
     for (int tile = slot; tile < ntiles; tile += nslot, ++it) {
         const int buf = it & 1;
         const unsigned char* Xs = lds + buf * LBUF;
@@ -572,6 +611,12 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
         const size_t yo = (size_t)tile * YTILE + (size_t)(cg * 8 + wave * 2) * GBLK;  // uniform: the lane part is in lmap
         const unsigned char* rbase = RES ? res + yo : nullptr;
         unsigned char* ybase = y + yo;
+        // one uniform base per plane, opaque to the compiler (it would otherwise fold base + YPLANE + lane offset into 64-bit VALU adds per
+        // access: YPLANE exceeds the 13-bit immediate): every residual load / y store is scalar base + 32-bit lane offset
+        unsigned long long rlo = (unsigned long long)(RES ? res + yo : y + yo) + YPLANE, ylo = (unsigned long long)(y + yo) + YPLANE;
+        asm volatile("" : "+s"(rlo), "+s"(ylo));
+        const sp_gcptr rbase_lo = (sp_gcptr)rlo;
+        const sp_gptr ybase_lo = (sp_gptr)ylo;
         const bool have_prev = it > 0;
         auto unit = [&](auto IC) __attribute__((always_inline)) {
             constexpr int i = decltype(IC)::value, set = i, pset = i ^ 1;
@@ -585,6 +630,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             typedef SpSpread<P_OPS, S0, AVAIL> SP;
             static_assert(SP::MAXPER <= (NCH >= 16 ? 1 : NCH >= 8 ? 2 : XLO0 ? 6 : 4), "the previous unit's epilogue fits this unit's MFMA gaps");
             unsigned char* pout = i == 0 ? yprev : ybase;
+            const sp_gptr pout_lo = i == 0 ? yprev_lo : ybase_lo;
             const bool pstore = i > 0 || have_prev;
             cp_for_each([&](auto TC) __attribute__((always_inline)) {
                 constexpr int t = decltype(TC)::value;
@@ -621,11 +667,12 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
                     constexpr int sl = t * NQ + q;  // MFMA slot of the unit
                     cp_for_each([&](auto KC) __attribute__((always_inline)) {
                         constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
-                        if constexpr (o < SP::cum(sl)) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
+                        if constexpr (o < SP::cum(sl)) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, pout_lo, o % CT_OPS, pstore);
                     }, typename CpMakeSeq<SP::MAXPER>::type{});
                     if constexpr (RES && sl < 2 * nj) {  // this unit's residual (used by its epilogue inside the next unit)
                         constexpr int rj = sl >> 1, rp = sl & 1;
-                        rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * YPLANE + (lmap[j0 + rj] >> 16));
+                        if constexpr (rp == 0) rr[set][rj][rp] = *(const cv_u32x2*)(rbase + out_off(j0 + rj));
+                        else rr[set][rj][rp] = *(const __attribute__((address_space(1))) cv_u32x2*)(rbase_lo + out_off(j0 + rj));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
@@ -641,7 +688,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
         };
         unit(CpInt<0>{});
         unit(CpInt<1>{});
-        yprev = ybase;
+        yprev = ybase, yprev_lo = ybase_lo;
         if ((it & 15) == 15 || !has_next) {
             // ---- the corner (8, 0) of the last (it & 15) + 1 boards: a [16 couts] x [<= 16 boards] x [4 taps x cin] tile per wave on the resident
             // filter banks.  The side buffer is complete: every wave passed this board's barrier after the copy of its column.
@@ -714,7 +761,7 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
 #pragma unroll
     for (int j = 0; j < NJ1; ++j)
 #pragma unroll
-        for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, NJ0 + j, yprev, o, true);
+        for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, NJ0 + j, yprev, yprev_lo, o, true);
     sp_range_report(mx, range);
 }
 

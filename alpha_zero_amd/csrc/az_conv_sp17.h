@@ -126,7 +126,7 @@ static_assert(sp17_uj0(0, 3) + sp17_unj(0, 3) == Sp17Geo::NCT0 && sp17_uj0(1, 3)
 // column tile, first slots of a unit).  Mirrors the schedule of k_conv3x3_sp17 below (same constants, same SpSpread).
 template <bool RES, int NCH, bool XLO0 = false> __host__ __device__ constexpr int sp17_vm_younger(int h) {
     constexpr int KSUB = NCH / 4, KS = 9 * KSUB, R = 3, S0 = 6, NP = (Sp17Geo::CELLS + 63) / 64, NPIECE = NP * ((XLO0 ? 1 : 2) * NCH / 4);
-    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
+    constexpr int CT_OPS = sp_epi_ct_ops(RES);
     int n = 0;
     for (int u = 0; u < 4; ++u) {
         const int nj = sp17_unj(h, u), NQ = (XLO0 ? 2 : 3) * nj;
@@ -170,9 +170,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
     constexpr int NPROD = XLO0 ? 2 : 3;
     static_assert(!XLO0 || (!RES && NCH == 4), "exact-f16 inputs: the stem");
     constexpr int NF = 2 * KS;
-    // epilogue micro-ops: per element E1 (join, [residual join, add,] ReLU, range record, clamp), per pair of elements 6 more (packed hi
-    // convert, 2 scalings, 2 remainders, packed lo convert), per column tile 2 stores
-    constexpr int E1 = RES ? 6 : 4, PAIR = 2 * E1 + 6, CT_OPS = 2 * PAIR + 2;
+    constexpr int E1 = sp_epi_e1(RES), PAIR = sp_epi_pair(RES), CT_OPS = sp_epi_ct_ops(RES);  // epilogue micro-ops (az_conv_sp.h sp_epi_e1)
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert(NF <= 64, "all A fragments live in AGPRs");
     static_assert((4 * KS) % R == 0, "a tile's k-steps keep the ring phase");
@@ -199,7 +197,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
     c6_f32x4 bv;  // bias in the D layout (rows = couts 4 kg + e of the wave's 16): the C operand of the first k-step
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[e] = bias[wave * 16 + 4 * kg + e];
-    const float lo_relu = relu ? 0.0f : -__builtin_inff();
+    const float lo_clamp = relu ? 0.0f : -SP_F16_MAX;  // lower bound of the epilogue's median: ReLU and the range clamp in one instruction
 
     // LDS-DMA plan per half: a strip is NP pieces of 64 cells; wave q moves strips SPW q .. SPW q + SPW - 1 (strip = plane * NCH + chunk)
     unsigned dsrc[2][NP];
@@ -271,7 +269,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
     float evv[2] = {0.0f, 0.0f}, sc[2] = {0.0f, 0.0f}, t0 = 0.0f, mx = 0.0f;  // mx: largest |value| this lane produced (range record)
     unsigned hpk[2] = {0u, 0u}, lpk[2] = {0u, 0u};
     // micro-op `o` of the epilogue of column tile j (lmap index mj) of the unit with accumulator set `set`: ONE VALU / memory instruction
-    auto epi_op = [&](int set, int j, int mj, unsigned char* out, int o, bool store_ok) {
+    auto epi_op = [&](int set, int j, int mj, unsigned char* out, sp_gptr out_lo, int o, bool store_ok) {
         if (o < 2 * PAIR) {
             const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
             if (k < 2 * E1) {
@@ -281,28 +279,27 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                 if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
                 else if (RES && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
                 else if (RES && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
-                else if (tail == 0) evv[ei] = fmaxf(evv[ei], lo_relu);
-                else if (tail == 1) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
-                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], -SP_F16_MAX, SP_F16_MAX);                   // ... is clamped here (and recorded)
+                else if (tail == 0) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
+                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], lo_clamp, SP_F16_MAX);                       // ... is clamped here (ReLU in the same median)
             } else {
                 const int kk = k - 2 * E1;
                 if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
-                else if (kk == 1) sc[0] = evv[0] * SP_SCALE;
-                else if (kk == 2) sc[1] = evv[1] * SP_SCALE;
-                else if (kk == 3) sc[0] = sp_mix_rem<0>(hpk[pr], sc[0]);
-                else if (kk == 4) sc[1] = sp_mix_rem<1>(hpk[pr], sc[1]);
-                else lpk[pr] = sp_cvt_pk(sc[0], sc[1]);
+                else if (kk == 1) sc[0] = sp_mix_diff<0>(hpk[pr], evv[0]);
+                else if (kk == 2) sc[1] = sp_mix_diff<1>(hpk[pr], evv[1]);
+                else if (kk == 3) lpk[pr] = sp_scale_cvt_lo(sc[0]);
+                else lpk[pr] = sp_scale_cvt_hi(lpk[pr], sc[1]);
             }
         } else {
             const unsigned gq = lmap[mj] >> 16;
             if (o == 2 * PAIR) {
                 if (store_ok) *(cv_u32x2*)(out + gq) = (cv_u32x2){hpk[0], hpk[1]};
-            } else if (store_ok) *(cv_u32x2*)(out + YPLANE + gq) = (cv_u32x2){lpk[0], lpk[1]};
+            } else if (store_ok) *(__attribute__((address_space(1))) cv_u32x2*)(out_lo + gq) = (cv_u32x2){lpk[0], lpk[1]};
         }
     };
 
     int it = 0;
     unsigned char* yprev = y;
+    sp_gptr yprev_lo = (sp_gptr)(unsigned long long)y;
     for (int board = slot; board < nboards; board += nslot, ++it) {
         const bool has_next = board + nslot < nboards;
         const unsigned char* xb = x + (size_t)board * XTILE;
@@ -310,6 +307,11 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
         const size_t yo = (size_t)board * YTILE + (size_t)(wave * 2) * GBLK;  // uniform: the lane part is in lmap
         const unsigned char* rbase = RES ? res + yo : nullptr;
         unsigned char* ybase = y + yo;
+        // one opaque uniform base per plane: every residual load / y store is scalar base + 32-bit lane offset (see k_conv3x3_sp)
+        unsigned long long rlo = (unsigned long long)(RES ? res + yo : y + yo) + YPLANE, ylo = (unsigned long long)(y + yo) + YPLANE;
+        asm volatile("" : "+s"(rlo), "+s"(ylo));
+        const sp_gcptr rbase_lo = (sp_gcptr)rlo;
+        const sp_gptr ybase_lo = (sp_gptr)ylo;
         const bool have_prev = it > 0;
         // unit U of half H (tile H of the board lives in LDS buffer H)
         auto unit = [&](auto HC, auto UC) __attribute__((always_inline)) {
@@ -330,6 +332,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
             const unsigned char* Xn = lds + (H ^ 1) * LBUF;
             // previous unit's output: the first unit of a board finishes the previous board's lower half
             unsigned char* pout = (H == 0 && U == 0) ? yprev : ybase;
+            const sp_gptr pout_lo = (H == 0 && U == 0) ? yprev_lo : ybase_lo;
             const bool pstore = (H == 0 && U == 0) ? have_prev : true;
             // the tile after this one: the lower half of this board, or the upper half of this workgroup's next board
             const unsigned char* nsrc = H == 0 ? xb : xnb;
@@ -369,11 +372,12 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                     constexpr int sl = t * NQ + q;  // MFMA slot of the unit
                     cp_for_each([&](auto KC) __attribute__((always_inline)) {
                         constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
-                        if constexpr (o < SP::cum(sl)) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, o % CT_OPS, pstore);
+                        if constexpr (o < SP::cum(sl)) epi_op(pset, o / CT_OPS, pj0 + o / CT_OPS, pout, pout_lo, o % CT_OPS, pstore);
                     }, typename CpMakeSeq<SP::MAXPER>::type{});
                     if constexpr (RES && sl < 2 * nj) {  // this unit's residual (used by its epilogue inside the next unit)
                         constexpr int rj = sl >> 1, rp = sl & 1;
-                        rr[set][rj][rp] = *(const cv_u32x2*)(rbase + rp * YPLANE + (lmap[j0 + rj] >> 16));
+                        if constexpr (rp == 0) rr[set][rj][rp] = *(const cv_u32x2*)(rbase + (lmap[j0 + rj] >> 16));
+                        else rr[set][rj][rp] = *(const __attribute__((address_space(1))) cv_u32x2*)(rbase_lo + (lmap[j0 + rj] >> 16));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
@@ -389,7 +393,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
         unit(CpInt<1>{}, CpInt<1>{});
         unit(CpInt<1>{}, CpInt<2>{});
         unit(CpInt<1>{}, CpInt<3>{});
-        yprev = ybase;
+        yprev = ybase, yprev_lo = ybase_lo;
     }
     // epilogue of the very last unit (lower half, unit 3: accumulator set 1)
     {
@@ -398,7 +402,7 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
 #pragma unroll
         for (int j = 0; j < nj; ++j)
 #pragma unroll
-            for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, j0 + j, yprev, o, true);
+            for (int o = 0; o < CT_OPS; ++o) epi_op(1, j, j0 + j, yprev, yprev_lo, o, true);
     }
     sp_range_report(mx, range);
 }
