@@ -42,6 +42,21 @@ def patch(text, variant):
     elif variant == "NO_EXPOSED":
         rep("                    for (int o = 0; o < CTM; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, o, true);",
             "                    for (int o = 0; o < 0; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, o, true);")
+    elif variant.startswith("DMA_Q"):  # NOT an ablation: the next tile's DMA piece of a k-step is issued behind MFMA slot Q instead of behind the last
+        q = int(variant[5:])
+        rep("                if constexpr (PH == 1 && FIRST && t >= 1 && t - 1 < NPIECE) {\n", "                if constexpr (false) {\n")
+        rep("                    __builtin_amdgcn_sched_barrier(0);\n                }, typename CpMakeSeq<NQ>::type{});",
+            "                    if constexpr (PH == 1 && FIRST && t >= 1 && t - 1 < NPIECE && q == %d) {\n"
+            "                        if constexpr (H == 0) dma_piece(xb, true, 1, t - 1);\n"
+            "                        else dma_piece(xnb, has_next, 0, t - 1);\n"
+            "                    }\n"
+            "                    __builtin_amdgcn_sched_barrier(0);\n                }, typename CpMakeSeq<NQ>::type{});" % q)
+    elif variant == "TWO_PER_STEP":  # two DMA pieces per k-step in k-steps 1 .. 8: the x image is complete half a unit earlier
+        rep("                if constexpr (PH == 1 && FIRST && t >= 1 && t - 1 < NPIECE) {\n                    // the tile after this one: the lower half of this board, or the upper half of this workgroup's next board\n"
+            "                    if constexpr (H == 0) dma_piece(xb, true, 1, t - 1);\n                    else dma_piece(xnb, has_next, 0, t - 1);\n",
+            "                if constexpr (PH == 1 && FIRST && t >= 1 && 2 * (t - 1) < NPIECE) {\n"
+            "                    if constexpr (H == 0) dma_piece(xb, true, 1, 2 * (t - 1)), dma_piece(xb, true, 1, 2 * (t - 1) + 1);\n"
+            "                    else dma_piece(xnb, has_next, 0, 2 * (t - 1)), dma_piece(xnb, has_next, 0, 2 * (t - 1) + 1);\n")
     elif variant != "FULL":
         raise SystemExit("unknown variant " + variant)
     return text

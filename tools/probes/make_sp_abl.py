@@ -3,7 +3,8 @@ the kernels removed per build (results are wrong, timings tell what each part co
 script patches copies under a build directory and compiles them to tools/probes/libazsp_abl_<VARIANT>.so, which tools/split_bench.py
 times through AZ_BENCH_LIB.  Variants: FULL (unpatched), HALF_FRAG (B fragments of every second k-step are not read from LDS: the ring
 slot keeps its old contents), NO_FRAG (no fragment reads after the first k-steps), NO_DMA (the next tile's LDS-DMA pieces are not
-issued), NO_CORNER (9x9: no corner phase), NO_STORE (no output stores and no residual loads; the compiler then drops the whole epilogue arithmetic as dead code)."""
+issued), VMCNT0 (NOT an ablation: every counted s_waitcnt vmcnt(N) before a tile barrier replaced by vmcnt(0) -- tools/vmcnt_check.py compares
+its outputs bit for bit with the product's), NO_CORNER (9x9: no corner phase), NO_STORE (no output stores and no residual loads; the compiler then drops the whole epilogue arithmetic as dead code)."""
 import os
 import shutil
 import subprocess
@@ -39,6 +40,12 @@ def patch(text, variant, name):
     elif variant == "NO_CORNER":  # 9x9 kernel only: the corner phase (position (8, 0) of the last <= 16 boards) is skipped
         if name == "az_conv_sp.h":
             rep("        if ((it & 15) == 15 || !has_next) {", "        if (false) {")
+    elif variant == "VMCNT0":  # every counted s_waitcnt vmcnt(N) in front of a tile barrier becomes vmcnt(0): results must stay bit-identical
+        if name == "az_conv_sp.h":
+            rep('if (have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");', 'if (false) asm volatile("s_nop 0");')
+            rep('else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first board', 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first board')
+        else:
+            rep('else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");', 'else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
     elif variant == "NO_STORE":
         rep("if (store_ok) *(cv_u32x2*)", "if (false) *(cv_u32x2*)", 0)
         rep("                        rr[set][rj][rp] = *(const cv_u32x2*)", "                        if (false) rr[set][rj][rp] = *(const cv_u32x2*)")
