@@ -102,6 +102,11 @@ F16_MAX = 65504.0
 KERNEL_WIDTHS = {"fp32": {(9, 1): (64, 128), (13, 3): (64,)}, "lowp": {(9, 1): (64, 128), (13, 3): (64,), (19, 1): (256,)}}
 
 
+# widening multiplies the tower's FLOPs by (w / f)^2; the hand-written kernels are 4.5 - 5x the library's fp32 convolutions (measured: 40 -> 64 =
+# 2.56x the FLOPs is still 1.7x faster than the library at 40), so anything beyond 4x the FLOPs is left to the library path
+MAX_WIDEN_FLOPS_RATIO = 4.0
+
+
 def widen_for_kernels(net: "AlphaZeroNet", board_size: int, dtype):
     """The network to hand to InferenceNet so that its evaluation runs on hand-written kernels: `net` itself when its filter count has
     kernels for this board (or none could help), else a function-preserving widened copy (widen_network: zero-weight extra channels,
@@ -118,6 +123,8 @@ def widen_for_kernels(net: "AlphaZeroNet", board_size: int, dtype):
     if f in widths or not widths or f > max(widths):
         return net, ""
     w = min(v for v in widths if v >= f)
+    if (w / f) ** 2 > MAX_WIDEN_FLOPS_RATIO:  # e.g. 64 -> 256 at 19x19: 16x the FLOPs of the tower -- the library at the true width is faster
+        return net, ""
     return widen_network(net, w), f" (network widened {f} -> {w} filters, function-preserving)"
 
 

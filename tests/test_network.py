@@ -590,3 +590,25 @@ def test_gpu_two_forwards_in_flight_on_two_streams_equal_the_serial_results(dtyp
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     json.dump(dict(dtype=dtype_name, rounds=n_rounds, rows=rows, differing=bad), open(os.path.join(root, "gpurun_out", f"two_stream_forwards_{dtype_name}.json"), "w"))
     assert not bad, bad[:5]
+
+
+def test_widen_for_kernels_only_when_it_pays():
+    """widen_for_kernels: the reference's shipped 10 x 40 Gomoku width goes to 64 (2.56x the FLOPs, on kernels 4.5 - 5x the library's
+    speed); widths that have kernels stay; a widening beyond 4x the tower's FLOPs (64 -> 256 at 19x19 = 16x) is left to the library."""
+    from alpha_zero_amd.core.network import widen_for_kernels
+
+    g40 = AlphaZeroNet((17, 13, 13), 169, 2, 40, 64, gomoku=True)
+    w, note = widen_for_kernels(g40, 13, torch.float32)
+    assert w.conv_block[0].out_channels == 64 and "40 -> 64" in note
+    x = (torch.rand(3, 17, 13, 13) > 0.6).float()
+    with torch.no_grad():
+        (l0, v0), (l1, v1) = g40.eval()(x), w.eval()(x)
+    assert torch.allclose(l0, l1, atol=1e-6) and torch.allclose(v0, v1, atol=1e-6)  # the same function
+    g64 = AlphaZeroNet((17, 13, 13), 169, 1, 64, 64, gomoku=True)
+    assert widen_for_kernels(g64, 13, torch.float32)[0] is g64
+    go64_19 = AlphaZeroNet((17, 19, 19), 362, 1, 64, 64)
+    assert widen_for_kernels(go64_19, 19, torch.bfloat16) == (go64_19, "")          # 16x the FLOPs: no
+    go128_19 = AlphaZeroNet((17, 19, 19), 362, 1, 128, 64)
+    w2, note2 = widen_for_kernels(go128_19, 19, torch.bfloat16)
+    assert w2.conv_block[0].out_channels == 256 and "128 -> 256" in note2           # 4x: still worth it
+    assert widen_for_kernels(go128_19, 19, torch.float32) == (go128_19, "")          # no fp32-class kernels at 19x19
