@@ -48,7 +48,10 @@ def patch(text, variant, name):
             rep('else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");', 'else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
     elif variant == "NO_STORE":
         rep("if (store_ok) *(cv_u32x2*)", "if (false) *(cv_u32x2*)", 0)
-        rep("                        rr[set][rj][rp] = *(const cv_u32x2*)", "                        if (false) rr[set][rj][rp] = *(const cv_u32x2*)")
+        rep("} else if (store_ok) *(__attribute__((address_space(1))) cv_u32x2*)", "} else if (false) *(__attribute__((address_space(1))) cv_u32x2*)", 0)
+        rep("                        if constexpr (rp == 0) rr[set][rj][rp] = *(const cv_u32x2*)", "                        if constexpr (false) rr[set][rj][rp] = *(const cv_u32x2*)")
+        rep("                        else rr[set][rj][rp] = *(const __attribute__((address_space(1))) cv_u32x2*)",
+            "                        else if constexpr (false) rr[set][rj][rp] = *(const __attribute__((address_space(1))) cv_u32x2*)")
     return text
 
 

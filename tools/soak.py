@@ -47,4 +47,5 @@ cnt = actor.counters()
 dt = time.time() - t0
 print(json.dumps(dict(evaluator=actor.evaluator_path, rounds=rounds, seconds=round(dt, 1), games=games, samples=samples, mean_len=round(float(np.mean(lens)), 1) if lens else None,
                       winners=results, moves=cnt["moves"], moves_per_s=round(cnt["moves"] / dt, 1), sims_per_move=round(cnt["sims"] / max(1, cnt["moves"]), 1),
-                      stalls=cnt["stalls"], dup_leaves=cnt["dup_leaves"], terminal_hits=cnt["terminal_hits"], range_events=actor.range_events)))
+                      stalls=cnt["stalls"], dup_leaves=cnt["dup_leaves"], terminal_hits=cnt["terminal_hits"], range_events=actor.range_events,
+                      range_rescales=actor.range_rescales, act_shift=actor.infer.act_shift, calibrated_max_abs=round(actor.infer.act_max_abs, 3))))
