@@ -560,7 +560,9 @@ class InferenceNet(nn.Module):
             if (self.filters, s) in ((128, 9), (64, 17), (64, 9), (256, 19)):
                 return "hand-written tower (azsp_conv3x3_tiled) behind a library stem and heads"
         if self.supports_split_features(board_size, device):
-            return ("fp32 class, hand-written: split-precision stem / tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, "
+            fused = self.use_fused_block and (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_FUSED_SHAPES
+            tower = ("azsp_resblock_split: one launch per ResNetBlock, intermediate activation in LDS; " if fused else "azsp_conv3x3_split: ")
+            return (f"fp32 class, hand-written: split-precision stem / tower ({tower}hi + lo f16 pairs, three MFMA products, "
                     "fp32 accumulation) / fp32 heads (libazsp)")
         if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower:
             if (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_TOWER_SHAPES:

@@ -353,6 +353,7 @@ def test_gpu_gomoku13_full_size_c2_properties_and_same_seed_stream():
         act = SelfPlayActor(net, game="gomoku", board_size=13, num_games=G, num_simulations=200, num_parallel=8, warm_up_steps=8, seed=5, device="cuda",
                             engine_kw={"max_steps": 44})
         assert "split-precision" in act.evaluator_path and "hand-written" in act.evaluator_path, act.evaluator_path
+        assert "azsp_resblock_split" in act.evaluator_path  # the tower runs on the one-launch-per-block kernel (az_resblock_sp17.h)
         rng = np.random.Generator(np.random.PCG64(9))
         plies = rng.integers(24, 35, size=G)
         out = act.engine.env_step(None)
