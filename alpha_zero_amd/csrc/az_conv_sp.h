@@ -166,12 +166,17 @@ __device__ __forceinline__ unsigned sp_scale_cvt_hi(unsigned lo, float d) {
     return lo;
 }
 // Micro-ops of a riding epilogue (shared by the kernels and by the compile-time mirrors of their schedules, sp9_vm_younger /
-// sp17_vm_younger): per element E1 = join, [residual join, add,] range record, ReLU + clamp (one v_med3_f32: the lower bound is 0 with
-// ReLU, -65504 without); per pair of elements 5 more (packed hi convert, 2 exact remainders v - hi, 2 scale-and-convert
-// v_fma_mixlo/hi_f16); per column tile 2 stores.  (Round 4: 6 / 4 per element + 6 per pair = 38 / 30 per column tile; now 32 / 24.)
-__host__ __device__ constexpr int sp_epi_e1(bool res) { return res ? 5 : 3; }
-__host__ __device__ constexpr int sp_epi_pair(bool res) { return 2 * sp_epi_e1(res) + 5; }
+// sp17_vm_younger): per element E1 = join [, residual join, add]; per pair of elements 8 more: range record of both (one v_max3_f32), 2 x
+// ReLU + clamp (one v_med3_f32 each: the lower bound is 0 with ReLU, -65504 without), packed hi convert, 2 exact remainders v - hi,
+// 2 scale-and-convert v_fma_mixlo/hi_f16; per column tile 2 stores.  (Round 4: 38 / 30 micro-ops per column tile; now 30 / 22.)
+__host__ __device__ constexpr int sp_epi_e1(bool res) { return res ? 3 : 1; }
+__host__ __device__ constexpr int sp_epi_pair(bool res) { return 2 * sp_epi_e1(res) + 8; }
 __host__ __device__ constexpr int sp_epi_ct_ops(bool res) { return 2 * sp_epi_pair(res) + 2; }
+// mx = max(mx, |a|, |b|) in one v_max3_f32 (the range record of a pair of elements)
+__device__ __forceinline__ float sp_max3_abs(float mx, float a, float b) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(a), "v"(b));
+    return mx;
+}
 typedef __attribute__((address_space(1))) unsigned char* sp_gptr;         // pointers into global memory whose value the compiler takes as
 typedef const __attribute__((address_space(1))) unsigned char* sp_gcptr;  // given: one opaque scalar base per plane (saddr + lane offset)
 
@@ -563,18 +568,18 @@ k_conv3x3_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w
             if (k < 2 * E1) {
                 const int ei = k / E1, kk = k % E1, e = 2 * pr + ei;
                 const unsigned rh = pr == 0 ? rr[set][j][0].x : rr[set][j][0].y, rl = pr == 0 ? rr[set][j][1].x : rr[set][j][1].y;
-                const int tail = kk - (RES ? 3 : 1);
                 if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
                 else if (RES && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
                 else if (RES && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
-                else if (tail == 0) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
-                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], lo_clamp, SP_F16_MAX);                       // ... is clamped here (ReLU in the same median)
             } else {
                 const int kk = k - 2 * E1;
-                if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
-                else if (kk == 1) sc[0] = sp_mix_diff<0>(hpk[pr], evv[0]);
-                else if (kk == 2) sc[1] = sp_mix_diff<1>(hpk[pr], evv[1]);
-                else if (kk == 3) lpk[pr] = sp_scale_cvt_lo(sc[0]);
+                if (kk == 0) mx = sp_max3_abs(mx, evv[0], evv[1]);                                            // what the reference would carry on ...
+                else if (kk == 1) evv[0] = __builtin_amdgcn_fmed3f(evv[0], lo_clamp, SP_F16_MAX);                  // ... is clamped here (ReLU in the same median)
+                else if (kk == 2) evv[1] = __builtin_amdgcn_fmed3f(evv[1], lo_clamp, SP_F16_MAX);
+                else if (kk == 3) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
+                else if (kk == 4) sc[0] = sp_mix_diff<0>(hpk[pr], evv[0]);
+                else if (kk == 5) sc[1] = sp_mix_diff<1>(hpk[pr], evv[1]);
+                else if (kk == 6) lpk[pr] = sp_scale_cvt_lo(sc[0]);
                 else lpk[pr] = sp_scale_cvt_hi(lpk[pr], sc[1]);
             }
         } else {

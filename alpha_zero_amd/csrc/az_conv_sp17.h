@@ -275,18 +275,18 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
             if (k < 2 * E1) {
                 const int ei = k / E1, kk = k % E1, e = 2 * pr + ei;
                 const unsigned rh = pr == 0 ? rr[set][j][0].x : rr[set][j][0].y, rl = pr == 0 ? rr[set][j][1].x : rr[set][j][1].y;
-                const int tail = kk - (RES ? 3 : 1);
                 if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
                 else if (RES && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
                 else if (RES && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
-                else if (tail == 0) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
-                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], lo_clamp, SP_F16_MAX);                       // ... is clamped here (ReLU in the same median)
             } else {
                 const int kk = k - 2 * E1;
-                if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
-                else if (kk == 1) sc[0] = sp_mix_diff<0>(hpk[pr], evv[0]);
-                else if (kk == 2) sc[1] = sp_mix_diff<1>(hpk[pr], evv[1]);
-                else if (kk == 3) lpk[pr] = sp_scale_cvt_lo(sc[0]);
+                if (kk == 0) mx = sp_max3_abs(mx, evv[0], evv[1]);                                            // what the reference would carry on ...
+                else if (kk == 1) evv[0] = __builtin_amdgcn_fmed3f(evv[0], lo_clamp, SP_F16_MAX);                  // ... is clamped here (ReLU in the same median)
+                else if (kk == 2) evv[1] = __builtin_amdgcn_fmed3f(evv[1], lo_clamp, SP_F16_MAX);
+                else if (kk == 3) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
+                else if (kk == 4) sc[0] = sp_mix_diff<0>(hpk[pr], evv[0]);
+                else if (kk == 5) sc[1] = sp_mix_diff<1>(hpk[pr], evv[1]);
+                else if (kk == 6) lpk[pr] = sp_scale_cvt_lo(sc[0]);
                 else lpk[pr] = sp_scale_cvt_hi(lpk[pr], sc[1]);
             }
         } else {

@@ -158,15 +158,15 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     constexpr int NP = G::XCELLS / 64;                       // DMA pieces of 64 cells per strip
     constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips and DMA pieces per wave and tile: 4, 16
     constexpr int NFC = 2 * KS, NF = 2 * NFC;                // A fragments per convolution (2 planes x 18 k-steps), in all: 72
-    // epilogue micro-ops per column tile.  TO THE M IMAGE (phase A): per element 3 (join, range record, ReLU + clamp in one v_med3_f32), per
-    // pair of elements 5 more (packed hi convert, 2 exact remainders v - hi, 2 scale-and-convert v_fma_mixlo/hi_f16), 2 LDS stores: 24.
-    // TO GLOBAL MEMORY (phase B): per element 5 (join, skip join, add, range record, ReLU + clamp), per pair 5 more, 2 stores: 32.
-    // (k_conv3x3_sp17 spends 30 / 38 on the same arithmetic; the results are bit-identical.)
-    constexpr int E1M = 3, PAIRM = 2 * E1M + 5, CTM = 2 * PAIRM + 2;
-    constexpr int E1G = 5, PAIRG = 2 * E1G + 5, CTG = 2 * PAIRG + 2;
+    // epilogue micro-ops per column tile (sp_epi_* in az_conv_sp.h).  TO THE M IMAGE (phase A): per element 1 (join), per pair of elements 8
+    // (range record of both in one v_max3_f32, 2 x ReLU + clamp in one v_med3_f32, packed hi convert, 2 exact remainders v - hi, 2
+    // scale-and-convert v_fma_mixlo/hi_f16), 2 LDS stores: 22.  TO GLOBAL MEMORY (phase B): per element 3 (join, skip join, add), per pair 8, 2
+    // stores: 30.  (k_conv3x3_sp17 of round 4 spent 30 / 38 on the same arithmetic; the results are bit-identical.)
+    constexpr int E1M = sp_epi_e1(false), PAIRM = sp_epi_pair(false), CTM = sp_epi_ct_ops(false);
+    constexpr int E1G = sp_epi_e1(true), PAIRG = sp_epi_pair(true), CTG = sp_epi_ct_ops(true);
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert(KS % R == 0, "every unit starts at ring phase 0");
-    static_assert(KS - 2 >= NPIECE, "the next tile's pieces ride in the first unit of phase B");
+    static_assert(NPIECE % 2 == 0 && KS - 2 >= NPIECE / 2, "the next tile's pieces ride in the first unit of phase B, two per k-step");
     static_assert((2 * G::PITCH + 2) * 16 + (KSUB - 1) * 4 * XBLK + XPLANE < 65536, "fragment addresses are a per-lane base + a 16-bit immediate");
     static_assert(XBLK % 256 == 0 && MBLK % 256 == 0, "strips are multiples of 256 B: the four 8-channel groups of a fragment share banks");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[TBL0 + TBL];
@@ -291,25 +291,25 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     // GLOBAL = false: phase A (bias + ReLU -> m image at Mw + ooff); true: phase B (bias + skip + ReLU -> global memory at out + ooff)
     auto epi_op = [&](auto GC, int set, int j, unsigned ooff, unsigned char* out, sb17_gptr out_lo, int o, bool store_ok) __attribute__((always_inline)) {
         constexpr bool GLOBAL = decltype(GC)::value != 0;
-        constexpr int E1 = GLOBAL ? E1G : E1M, PAIR = 2 * E1 + 5;
+        constexpr int E1 = GLOBAL ? E1G : E1M, PAIR = GLOBAL ? PAIRG : PAIRM;
         if (o < 2 * PAIR) {
             const int pr = o / PAIR, k = o % PAIR;  // pair pr = elements 2 pr, 2 pr + 1 (one packed dword of each plane)
             if (k < 2 * E1) {
                 const int ei = k / E1, kk = k % E1, e = 2 * pr + ei;
                 const unsigned rh = pr == 0 ? rr[set][j][0].x : rr[set][j][0].y, rl = pr == 0 ? rr[set][j][1].x : rr[set][j][1].y;
-                const int tail = kk - (GLOBAL ? 3 : 1);
                 if (kk == 0) evv[ei] = fmaf(accc[set][j][e], SP_INV_SCALE, accm[set][j][e]);
                 else if (GLOBAL && kk == 1) t0 = ei == 0 ? sp_mix_join<0>(rh, rl) : sp_mix_join<1>(rh, rl);
                 else if (GLOBAL && kk == 2) evv[ei] = cw_add_f32(evv[ei], t0);
-                else if (tail == 0) mx = fmaxf(mx, __builtin_fabsf(evv[ei]));                               // what the reference would carry on ...
-                else evv[ei] = __builtin_amdgcn_fmed3f(evv[ei], 0.0f, SP_F16_MAX);                           // ... is clamped here (ReLU in the same median)
             } else {
                 const int kk = k - 2 * E1;
-                if (kk == 0) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
-                else if (kk == 1) sc[0] = sb17_mix_diff<0>(hpk[pr], evv[0]);   // v - hi, exact in fp32
-                else if (kk == 2) sc[1] = sb17_mix_diff<1>(hpk[pr], evv[1]);
-                else if (kk == 3) lpk[pr] = sb17_scale_cvt_lo(sc[0]);           // f16((v - hi) * 2^11) into the low half ...
-                else lpk[pr] = sb17_scale_cvt_hi(lpk[pr], sc[1]);               // ... and the high half: one rounding each, as v_cvt_pk_f16_f32 does
+                if (kk == 0) mx = sp_max3_abs(mx, evv[0], evv[1]);                                            // what the reference would carry on ...
+                else if (kk == 1) evv[0] = __builtin_amdgcn_fmed3f(evv[0], 0.0f, SP_F16_MAX);                  // ... is clamped here (ReLU in the same median)
+                else if (kk == 2) evv[1] = __builtin_amdgcn_fmed3f(evv[1], 0.0f, SP_F16_MAX);
+                else if (kk == 3) hpk[pr] = sp_cvt_pk(evv[0], evv[1]);
+                else if (kk == 4) sc[0] = sb17_mix_diff<0>(hpk[pr], evv[0]);
+                else if (kk == 5) sc[1] = sb17_mix_diff<1>(hpk[pr], evv[1]);
+                else if (kk == 6) lpk[pr] = sb17_scale_cvt_lo(sc[0]);
+                else lpk[pr] = sb17_scale_cvt_hi(lpk[pr], sc[1]);
             }
         } else if constexpr (GLOBAL) {
             if (o == 2 * PAIR) {
@@ -406,10 +406,11 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
-                if constexpr (PH == 1 && FIRST && t >= 1 && t - 1 < NPIECE) {
-                    // the tile after this one: the lower half of this board, or the upper half of this workgroup's next board
-                    if constexpr (H == 0) dma_piece(xb, true, 1, t - 1);
-                    else dma_piece(xnb, has_next, 0, t - 1);
+                if constexpr (PH == 1 && FIRST && t >= 1 && 2 * (t - 1) < NPIECE) {
+                    // the tile after this one: the lower half of this board, or the upper half of this workgroup's next board; two pieces per
+                    // k-step (same-box A/B, profiles/r05_split_ablation.txt (5): -0.5 % against one per k-step; where in the k-step: no difference)
+                    if constexpr (H == 0) dma_piece(xb, true, 1, 2 * (t - 1)), dma_piece(xb, true, 1, 2 * (t - 1) + 1);
+                    else dma_piece(xnb, has_next, 0, 2 * (t - 1)), dma_piece(xnb, has_next, 0, 2 * (t - 1) + 1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<KS>::type{});
