@@ -103,14 +103,20 @@ class DeviceEvaluator:
     on the device; calling the object with (state, batched) numpy arrays honours the reference's eval_func contract
     (pipeline.py:91-123), so the same object also serves the drop-in searches."""
 
+    POLL_EVERY = 32  # leaf batches between two polls of the fp32-class evaluator's range record (a poll synchronises the stream)
+
     def __init__(self, inference_net):
         self.inf = inference_net
+        self._calls = 0
 
     def device_eval(self, x):
         import torch
 
         with torch.no_grad():
             pri, v = self.inf.forward_planes(x) if hasattr(self.inf, "forward_planes") else self.inf(x)
+        self._calls += 1
+        if self._calls % self.POLL_EVERY == 0 and hasattr(self.inf, "poll_range"):
+            self.inf.poll_range(x)  # never silent, never left clamping: warn + rescale (InferenceNet.poll_range)
         return pri.float(), v.float()
 
     def __call__(self, state, batched=False):

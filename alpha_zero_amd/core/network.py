@@ -378,6 +378,26 @@ class InferenceNet(nn.Module):
             self._ck(self.binding.dll.azsp_split_range_read(rec, ctypes.byref(ev), ctypes.byref(mx), int(bool(reset)), stream), "azsp_split_range_read")
         return int(ev.value), float(mx.value)
 
+    def poll_range(self, planes=None):
+        """For callers that drive the InferenceNet themselves (evaluation games, drop-in eval_func wrappers: no SelfPlayActor polls for
+        them): reads and resets this network's range record; on an event it warns, raises the activation scale and -- given the batch
+        that was just evaluated -- re-calibrates on it.  Returns the number of events.  Synchronises the stream."""
+        if self.dtype != torch.float32 or not hasattr(self, "range_rec") or not self.range_rec.is_cuda or self.split_fallback_reason:
+            return 0
+        ev, mx = self.split_range_status(reset=True)
+        if ev:
+            import warnings
+
+            old = self.act_shift
+            if planes is not None and self.supports_split_features(planes.shape[2], planes.device):
+                self.set_act_shift(min(self.MAX_ACT_SHIFT, old + 2))
+                self.calibrate_activation_scale(planes.float().contiguous())
+            what = (f"library fp32 convolutions from now on ({self.split_fallback_reason})" if self.split_fallback_reason
+                    else f"activation scale 2^-{old} -> 2^-{self.act_shift}")
+            warnings.warn(f"alpha_zero_amd: the fp32-class evaluator clamped {ev} activation lanes beyond f16's range (largest |v| = "
+                          f"{mx * 2.0 ** old:.6g}); {what}", RuntimeWarning, stacklevel=2)
+        return ev
+
     # -- range safety: exact power-of-two activation scale -------------------------------------------------------------------
     MAX_ACT_SHIFT = 9   # beyond 2^-9 the scaled stem weights lose fp32-class accuracy (their hi halves become f16 subnormals)
     ACT_HEADROOM = 16.0  # calibration leaves this factor between the largest activation it saw and f16's limit

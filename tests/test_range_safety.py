@@ -246,3 +246,28 @@ def test_gpu_split_conv_keeps_f16_subnormal_operands():
     y64 = F.conv2d(x.double(), w.double(), None, padding=1)
     err = (y.cpu().double() - y64).abs().max().item() / y64.abs().max().item()
     assert err <= 5e-6, err  # flushed subnormals would leave y = 0: an error of 1
+
+
+@pytest.mark.gpu
+def test_gpu_poll_range_repairs_a_directly_driven_network():
+    """Callers that drive an InferenceNet themselves (evaluation games through DeviceEvaluator, drop-in eval_func wrappers) have no actor
+    polling for them: InferenceNet.poll_range reads the network's own record, warns, and re-calibrates on the batch it is given."""
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.evaluate import DeviceEvaluator
+
+    net = _loud_net(9, 64, 2, gain=2e5, seed=4)
+    inf = InferenceNet(net, dtype=torch.float32, binding=_lib.load()).cuda()
+    inf.act_calibrated = True  # defeat the first-call calibration: the network clamps at shift 0
+    ev = DeviceEvaluator(inf)
+    ev.POLL_EVERY = 2
+    x = (torch.rand(16, 17, 9, 9, generator=torch.Generator().manual_seed(2)) > 0.6).to(torch.int8).cuda()
+    p64, v64 = _ref64(net, x.cpu().float())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ev.device_eval(x)
+        assert not w and inf.act_shift == 0
+        ev.device_eval(x)  # the second call polls: events -> warning + re-calibration on this batch
+    assert [m for m in w if "clamped" in str(m.message)] and inf.act_shift >= 2 and not inf.split_fallback_reason
+    p, v = ev.device_eval(x)
+    assert inf.poll_range(x) == 0
+    assert (p.cpu().double() - p64).abs().max().item() <= 2e-4 and (v.cpu().double() - v64).abs().max().item() <= 2e-4
