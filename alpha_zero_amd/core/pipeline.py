@@ -253,7 +253,17 @@ class SelfPlayActor:
             what = (f"falls back to the library's fp32 convolutions ({inf.split_fallback_reason})" if inf.split_fallback_reason
                     else f"activation scale raised 2^-{old_shift} -> 2^-{inf.act_shift}")
         else:
-            what = "evaluate this network with use_split_tower = False"
+            # the split tower behind a library stem / heads (shapes without split stem or head kernels): no layer-by-layer calibration
+            # pass exists for it -- raise the scale by what the record shows (a lower bound: clamped values hide the true maximum) + 16x
+            import math
+
+            k = min(inf.MAX_ACT_SHIFT, old_shift + max(2, math.ceil(math.log2(max(mx, 65504.0) / 65504.0)) + 4))
+            if k > old_shift:
+                inf.set_act_shift(k)
+                self.range_rescales += 1
+                what = f"activation scale raised 2^-{old_shift} -> 2^-{inf.act_shift}"
+            else:
+                what = "the scale is at its limit: evaluate this network with use_split_tower = False"
         warnings.warn(f"alpha_zero_amd: the fp32-class evaluator clamped {ev} activation lanes beyond f16's range (largest |v| = "
                       f"{mx * 2.0 ** old_shift:.6g}); the reference's fp32 network would have carried them -- {what}",
                       RuntimeWarning, stacklevel=3)
