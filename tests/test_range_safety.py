@@ -113,12 +113,13 @@ def test_activation_shift_is_function_preserving_host_twin():
 @pytest.mark.gpu
 @pytest.mark.parametrize("board,filters,gomoku", [(9, 128, False), (13, 64, True)])
 def test_gpu_network_with_activations_of_1e6_runs_in_range_after_calibration(board, filters, gomoku):
-    """a network whose tower activations reach ~1e6 (15x beyond f16's largest number).  Uncalibrated the kernels
-    clamp (and record it); the calibration pass picks an exact power-of-two scale and the evaluator then matches the fp64 module
-    within the whole-network bound (2e-4) with range_events == 0."""
+    """a network whose tower activations reach ~1e6 (15x beyond f16's largest number) -- the 10-block x 128 Go network of
+    the headline shape with its block-10 output at 1e6, and the 6 x 64 Gomoku network of C2.  Uncalibrated the kernels clamp (and record
+    it); the calibration pass picks an exact power-of-two scale and the evaluator then matches the fp64 module within the whole-network
+    bound (2e-4) with range_events == 0."""
     from alpha_zero_amd import _lib
 
-    net = _loud_net(board, filters, 6, gain=2.5e4 if not gomoku else 3e4, gomoku=gomoku)
+    net = _loud_net(board, filters, 6 if gomoku else 10, gain=3e4 if gomoku else 6.7e3, gomoku=gomoku)
     g = torch.Generator().manual_seed(11)
     x = (torch.rand(24, 17, board, board, generator=g) > 0.6).float()
     peak = _tower_peak(net, x)
