@@ -260,6 +260,7 @@ class SelfPlayActor:
             k = min(inf.MAX_ACT_SHIFT, old_shift + max(2, math.ceil(math.log2(max(mx, 65504.0) / 65504.0)) + 4))
             if k > old_shift:
                 inf.set_act_shift(k)
+                self._graph = None  # (this path multiplies by 2^-k with a host constant: a captured graph holds the old one)
                 self.range_rescales += 1
                 what = f"activation scale raised 2^-{old_shift} -> 2^-{inf.act_shift}"
             else:
