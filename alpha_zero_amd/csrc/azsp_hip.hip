@@ -318,16 +318,20 @@ int launch_resblock_split(const void* x, const void* w1, const float* b1, const 
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
     const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles x two phases
-    static const int ring = [] {  // experiment knob (profiles/r05_*): AZSP_RB_RING=3 selects the shallow B-fragment ring
+    // (the 3-slot ring of the A/B in profiles/r05_pmc_splitblock17_ring3*.txt: build with -DAZSP_EXPERIMENT_RING3 and set AZSP_RB_RING=3)
+#ifdef AZSP_EXPERIMENT_RING3
+    static const int ring3 = [] {
         const char* e = getenv("AZSP_RB_RING");
-        return e && atoi(e) == 3 ? 3 : 6;
+        return e && atoi(e) == 3;
     }();
-    if (ring == 3)
+    if (ring3) {
         hipLaunchKernelGGL(k_resblock_sp17<3>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
                            (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
-    else
-        hipLaunchKernelGGL(k_resblock_sp17<6>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
-                           (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
+        return AZ_HIP(hipGetLastError());
+    }
+#endif
+    hipLaunchKernelGGL(k_resblock_sp17<6>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+                       (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
     return AZ_HIP(hipGetLastError());
 }
 int launch_split_features(const float* src, void* dst, long long boards, int S, int cin, void* st, unsigned* range) {
