@@ -272,3 +272,30 @@ def test_gpu_poll_range_repairs_a_directly_driven_network():
     p, v = ev.device_eval(x)
     assert inf.poll_range(x) == 0
     assert (p.cpu().double() - p64).abs().max().item() <= 2e-4 and (v.cpu().double() - v64).abs().max().item() <= 2e-4
+
+
+def test_calibration_pass_on_the_host_twin():
+    """InferenceNet.calibrate_activation_scale driven by hand on the host twin (CPU tensors; the twin has the kernels' arithmetic and their
+    range record): a network whose activations reach ~1e6 clamps at shift 0, the calibration pass finds the exact power-of-two scale, and the
+    evaluator then matches the fp64 module within the whole-network bound.  Also: a network beyond the format falls back at construction."""
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    net = _loud_net(9, 64, 2, gain=2e5, seed=1)
+    x = (torch.rand(2, 17, 9, 9, generator=torch.Generator().manual_seed(3)) > 0.6).float()
+    peak = _tower_peak(net, x)
+    assert 3e5 < peak < 1.9e6, peak
+    p64, v64 = _ref64(net, x)
+    inf = InferenceNet(net, dtype=torch.float32, binding=bnd)
+    assert bnd.dll.azsp_split_range_status(None, None, 1, None) == 0
+    pc, vc = inf.forward_split(x)  # (CPU tensors: no automatic calibration) -- clamps, and the twin's default record says so
+    ev = ctypes.c_uint32(0)
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), None, 1, None) == 0 and ev.value > 0
+    shift, worst = inf.calibrate_activation_scale(x)
+    assert inf.act_calibrated and 3 <= shift <= inf.MAX_ACT_SHIFT and abs(worst / peak - 1) < 1e-3 and not inf.split_fallback_reason
+    assert bnd.dll.azsp_split_range_status(None, None, 1, None) == 0  # (the probing passes clamped by design)
+    p, v = inf.forward_split(x)
+    assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), None, 1, None) == 0 and ev.value == 0
+    assert (p.double() - p64).abs().max().item() <= 2e-4 and (v.double() - v64).abs().max().item() <= 2e-4
+    far = InferenceNet(_loud_net(9, 64, 1, gain=3e8), dtype=torch.float32, binding=bnd)
+    assert far.split_fallback_reason and "library fp32" in far.evaluator_path(9, "cpu") and far.act_shift == 0
