@@ -11,7 +11,7 @@ SYMBOLS = [
     "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
     "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
     "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act",
-    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled", "azsp_replay_gather", "azsp_rng_probe", "azsp_harvest_moves", "azsp_fc_heads", "azsp_harvest_extra", "azsp_set_actor_state", "azsp_resblock_tiled", "azsp_select_range", "azsp_expand_backup_range", "azsp_split_bytes", "azsp_split_layout", "azsp_conv3x3_split", "azsp_split_features", "azsp_stem_split", "azsp_head_split", "azsp_conv3x3_tiled_f16", "azsp_stem_tiled_f16", "azsp_head_tiled_f16", "azsp_fc_heads_f16", "azsp_split_range_status", "azsp_stem_split_exact", "azsp_split_range_read", "azsp_resblock_split",
+    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled", "azsp_replay_gather", "azsp_rng_probe", "azsp_harvest_moves", "azsp_fc_heads", "azsp_harvest_extra", "azsp_set_actor_state", "azsp_resblock_tiled", "azsp_select_range", "azsp_expand_backup_range", "azsp_split_bytes", "azsp_split_layout", "azsp_conv3x3_split", "azsp_split_features", "azsp_stem_split", "azsp_head_split", "azsp_conv3x3_tiled_f16", "azsp_stem_tiled_f16", "azsp_head_tiled_f16", "azsp_fc_heads_f16", "azsp_split_range_status", "azsp_stem_split_exact", "azsp_split_range_read", "azsp_resblock_split", "azsp_dropin_step",
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
@@ -52,7 +52,7 @@ class Binding:
             "azsp_env_step": [V, V, V, V, V, V, V], "azsp_set_state": [V, I, V, V, I, I, I, I, I, I, V],
             "azsp_begin_move": [V, V, I, V], "azsp_select": [V, V, V, V], "azsp_expand_backup": [V, V, V, V],
             "azsp_round": [V, V, V, V, V, V], "azsp_select_range": [V, V, V, I, I, V], "azsp_expand_backup_range": [V, V, V, I, I, V], "azsp_get_status": [V, V, V, V], "azsp_get_search": [V, I, I, V, V, V, V],
-            "azsp_commit_move": [V, V, V], "azsp_harvest": [V, V, V, V, I, V, I, P(I), P(I), V],
+            "azsp_commit_move": [V, V, V], "azsp_dropin_step": [V, V, V, V, V, V, V, V, V, V, V, C.c_int64, V], "azsp_harvest": [V, V, V, V, I, V, I, P(I), P(I), V],
             "azsp_counters": [V, V, I, V], "azsp_dihedral": [V, V, I, V, V, I, I, I, I, I, I, V],
             "azsp_bias_act": [V, V, V, C.c_int64, I, I, I, V],
             "azsp_conv3x3_tiled": [V, V, V, V, V, C.c_int64, I, I, I, V], "azsp_tile_layout": [V, V, C.c_int64, I, I, I, V],

@@ -203,6 +203,28 @@ class Engine:
         self._ck(self.b.dll.azsp_get_status(self.h, st.ctypes.data, q.ctypes.data, self._stream()), "azsp_get_status")
         return st, q
 
+    def dropin_step(self, priors=None, values=None, feature_rows=None):
+        """One iteration of uct_search's simulation loop in ONE host round trip (azsp_dropin_step): upload eval_func's `priors`
+        float32[rows, A] / `values` float32[rows] for the previous leaves (None on the first call of a search), expand / backup, select
+        the next leaves, and return (status int32[G, 8], q float64[G, 2], valid bool[rows], obs [feature_rows, 17, N, N] of the engine's
+        feature dtype).  Feature dtypes with a plain [rows, 17, N, N] tensor only (AZSP_FEAT_I8 / F32)."""
+        assert not (self.features_tiled or self.features_split)
+        nrow = self.rows if feature_rows is None else int(feature_rows)
+        if getattr(self, "_dropin_bufs", None) is None:
+            np_dt = {torch.int8: np.int8, torch.float32: np.float32}[self.features.dtype]
+            self._dropin_bufs = (np.zeros((self.G, 8), dtype=np.int32), np.zeros((self.G, 2), dtype=np.float64), np.zeros(self.rows, dtype=np.uint8),
+                                 np.zeros((self.rows, 17, self.N, self.N), dtype=np_dt))
+        st, q, valid, obs = self._dropin_bufs
+        pp = vp = None
+        if priors is not None:
+            priors = np.ascontiguousarray(priors, dtype=np.float32).reshape(self.rows, self.A)
+            values = np.ascontiguousarray(values, dtype=np.float32).reshape(self.rows)
+            pp, vp = priors.ctypes.data, values.ctypes.data
+        self._ck(self.b.dll.azsp_dropin_step(self.h, pp, vp, self.priors.data_ptr(), self.values.data_ptr(), self.features.data_ptr(),
+                                             self.valid.data_ptr(), st.ctypes.data, q.ctypes.data, valid.ctypes.data, obs.ctypes.data,
+                                             nrow * obs[0].nbytes, self._stream()), "azsp_dropin_step")
+        return st.copy(), q.copy(), valid.astype(bool), obs[:nrow].copy()  # copies: eval_func may keep what it is handed (the reference passes fresh arrays)
+
     def get_search(self, slot, ply=0):
         pi = np.zeros(self.A, dtype=np.float64)
         cn = np.zeros(self.A, dtype=np.float32)

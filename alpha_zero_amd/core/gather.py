@@ -18,6 +18,8 @@ def _bit_weights(dev):
 def pack_samples(states, pi, z):
     """states int8[n,C,N,N] of 0/1 planes, pi f32[n,A], z f32[n] -> uint8[n, row_bytes] (bit-packed planes | pi bytes | z bytes)."""
     n = states.shape[0]
+    if n == 0:  # nothing to pack (a rank without a finished game): empty tensors have no byte views
+        return torch.zeros((0, (int(np.prod(states.shape[1:])) + 7) // 8 + 4 * pi.shape[1] + 4), dtype=torch.uint8, device=states.device)
     flat = states.reshape(n, int(np.prod(states.shape[1:]))).to(torch.uint8)
     nb = (flat.shape[1] + 7) // 8
     if flat.shape[1] != nb * 8:
@@ -66,8 +68,10 @@ def gather_samples(states, pi, z, games, dst=0, group=None):
     rows = pack_samples(states, pi, z)
     rb = rows.shape[1]
     buf = torch.zeros((maxn * rb + maxk * 64,), dtype=torch.uint8, device=dev)
-    buf[: rows.numel()] = rows.reshape(-1)
-    buf[maxn * rb: maxn * rb + g_t.numel() * 4] = g_t.contiguous().view(torch.uint8).reshape(-1)
+    if rows.numel():
+        buf[: rows.numel()] = rows.reshape(-1)
+    if g_t.numel():  # (a rank with no finished game in this harvest: an empty [0, 16] tensor has no byte view -- found by the 8-rank gloo test)
+        buf[maxn * rb: maxn * rb + g_t.numel() * 4] = g_t.contiguous().view(torch.uint8).reshape(-1)
     out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst, group=group)
     if rank != dst:

@@ -11,7 +11,6 @@ observation planes the select kernel produced, exactly the arrays the reference 
 import weakref
 
 import numpy as np
-import torch
 
 from .. import _abi
 from ..envs.base import BoardGameEnv
@@ -103,27 +102,25 @@ def _search(env, eval_func, root_node, c_puct_base, c_puct_init, num_simulations
     if root_noise:  # add_dirichlet_noise (mcts_v2.py:259-260): the engine applies the legal mask itself
         noise = np.random.dirichlet(np.ones_like(root_legal) * 0.03)
     eng.begin_move(noise, warm_up=1 if warm_up else 0)
-    eng.select()
+    # The simulation loop (mcts_v2.py:378-421 / :568-625).  One host round trip per leaf batch: azsp_dropin_step uploads eval_func's
+    # outputs, runs expand / backup + the selection of the next leaves, and returns status, valid flags and the leaves' observation
+    # planes from one packed read-back (rounds 1-5 paid eight stream synchronisations per simulation here).
+    pri = np.zeros((eng.rows, A), dtype=np.float32)
+    val = np.zeros(eng.rows, dtype=np.float32)
+    st, q, valid, obs = eng.dropin_step(None, None, s.P)
     for _ in range(1 << 20):
-        st, q = eng.status()
-        valid = eng.valid.cpu().numpy().astype(bool)
         if st[0, 0] == _abi.ST_MOVE_DONE:
             break
         if valid.any():
-            obs = eng.features[: s.P].cpu().numpy()
-            pri = np.zeros((eng.rows, A), dtype=np.float32)
-            val = np.zeros(eng.rows, dtype=np.float32)
             if st[0, 6] or num_parallel == 1:  # root evaluation / uct_search leaves: unbatched call (mcts_v2.py:365, :414, :555)
                 p, v = eval_func(obs[0], False)
                 pri[0], val[0] = np.asarray(p, dtype=np.float32), v
             else:
                 rows = np.flatnonzero(valid)
-                ps, vs = eval_func(np.stack([obs[r] for r in rows], axis=0), True)  # mcts_v2.py:614
+                ps, vs = eval_func(obs[rows], True)  # mcts_v2.py:614
                 for r, p, v in zip(rows, ps, vs):
                     pri[r], val[r] = np.asarray(p, dtype=np.float32), v
-            eng.priors.copy_(torch.from_numpy(pri))
-            eng.values.copy_(torch.from_numpy(val))
-        eng.round()
+        st, q, valid, obs = eng.dropin_step(pri, val, s.P)
     pi64, child_n, _ = eng.get_search(0, 0)
     search_pi = pi64 if env.has_pass_move else pi64.astype(np.float32)  # float64 for Go, float32 for Gomoku
     move = None

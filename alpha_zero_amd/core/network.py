@@ -5,9 +5,13 @@
 `value_head.{0,1,4,6}`) and shipped / learner checkpoints load unchanged.
 
 `InferenceNet` is the leaf evaluator the engine calls every round: eval-mode BatchNorm folded into
-the preceding convolution, channels-last, optional bf16/fp16, softmax over all A actions in fp32
-(priors are never masked or renormalised: pipeline.py:102-117), outputs written straight into the
-engine's priors/values tensors.  MFMA is used here and only here (MIOpen / hipBLASLt kernels).
+the preceding convolution, softmax over all A actions in fp32 (priors are never masked or
+renormalised: pipeline.py:102-117), outputs written straight into the engine's priors/values
+tensors.  The matrix cores are used here and only here -- by libazsp's hand-written MFMA kernels:
+the fp32-class split-precision stem / tower / heads (default: the reference's precision class;
+9x9 x {128, 64}, 13x13 Gomoku x 64), the tiled bf16 / f16 families (opt-in; also 19x19 x 256);
+other shapes fall back to the library's convolutions (MIOpen) + the fused azsp_bias_act epilogue,
+announced by `evaluator_path` and a RuntimeWarning.
 """
 from typing import Tuple
 
@@ -181,6 +185,7 @@ class InferenceNet(nn.Module):
             # fp32-class path: every activation is carried as v * 2^-act_shift (an exact rescaling of a ReLU + skip tower, see set_act_shift)
             self.act_shift, self.act_calibrated, self.act_max_abs = 0, False, 0.0
             self.split_fallback_reason = ""  # set when the fp32-class kernels are given up for this network (library fp32 instead)
+            self.stem_fallback_reason = ""   # set when only the split STEM cannot carry this network (library stem + heads around the split tower)
             if dtype == torch.float32:  # split-precision tower (azsp_conv3x3_split)
                 try:
                     packed = [split_weights_f16(w) for w, _ in convs[1:]]
@@ -212,9 +217,11 @@ class InferenceNet(nn.Module):
                     while wmax * 2.0 ** -k0 > F16_MAX and k0 <= self.MAX_ACT_SHIFT:
                         k0 += 1
                     if k0 > self.MAX_ACT_SHIFT:
-                        self.split_fallback_reason = self.split_fallback_reason or f"folded stem weights reach {wmax:.3g}: beyond the f16-pair format"
+                        # the split STEM cannot carry these weights; the tower's own weights are a separate matter (the library stem in
+                        # front of the split tower never sees stem_wsp): _split_tower_ok is gated on split_fallback_reason only
+                        self.stem_fallback_reason = f"folded stem weights reach {wmax:.3g}: beyond the f16-pair format"
                         k0 = 0
-                    self.stem_wsp = nn.Parameter(split_weights_f16(sw32 * 2.0 ** -k0) if not self.split_fallback_reason
+                    self.stem_wsp = nn.Parameter(split_weights_f16(sw32 * 2.0 ** -k0) if not (self.split_fallback_reason or self.stem_fallback_reason)
                                                  else torch.zeros(2, 9, sw.shape[0], 32, dtype=torch.float16), requires_grad=False)
                     self.stem_b_sp = nn.Parameter(convs[0][1].float().clone().contiguous(), requires_grad=False)
                     self._initial_act_shift = k0
@@ -224,7 +231,7 @@ class InferenceNet(nn.Module):
             self.head_w32 = nn.Parameter(torch.cat([pw, vw], 0).reshape(pw.shape[0] + vw.shape[0], -1).float().contiguous(), requires_grad=False)
             if dtype == torch.float32:  # azsp_head_split reads head_w32 * 2^act_shift (undoes the activation scale exactly)
                 self.head_w_sp = nn.Parameter(self.head_w32.detach().clone(), requires_grad=False)
-                if getattr(self, "_initial_act_shift", 0) and not self.split_fallback_reason:
+                if getattr(self, "_initial_act_shift", 0) and not (self.split_fallback_reason or self.stem_fallback_reason):
                     self.set_act_shift(self._initial_act_shift)
             self.head_b32 = nn.Parameter(torch.cat([pb, vb], 0).float().contiguous(), requires_grad=False)
             # both 1x1 heads share one convolution (2 policy planes + 1 value plane)
@@ -285,7 +292,8 @@ class InferenceNet(nn.Module):
         filters (pad-3 stem, 17x17 planes)."""
         return (self.binding is not None and torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.use_fused_conv
                 and self.use_split_tower and self.use_split_heads and self.stem_ok and self.npol + self.nval == 3
-                and not self.split_fallback_reason and (self.filters, board_size, self.stem_pad) in self.SPLIT_EVAL_SHAPES)
+                and not self.split_fallback_reason and not self.stem_fallback_reason
+                and (self.filters, board_size, self.stem_pad) in self.SPLIT_EVAL_SHAPES)
 
     def _split_buffers(self, B, S, C, device, slot=0, board_size=None):
         """Scratch of the split-precision evaluator per `slot` (the scheme of _tiled_buffers): three rotating tower buffers, the output
@@ -392,8 +400,17 @@ class InferenceNet(nn.Module):
             if planes is not None and self.supports_split_features(planes.shape[2], planes.device):
                 self.set_act_shift(min(self.MAX_ACT_SHIFT, old + 2))
                 self.calibrate_activation_scale(planes.float().contiguous())
+            else:
+                # the split tower behind a library stem / heads (or no batch given): no layer-by-layer calibration pass -- raise the scale
+                # by what the record shows (a lower bound: clamped values hide the true maximum) + 16x, as SelfPlayActor does
+                import math
+
+                k = min(self.MAX_ACT_SHIFT, old + max(2, math.ceil(math.log2(max(mx, F16_MAX) / F16_MAX)) + 4))
+                if k > old:
+                    self.set_act_shift(k)
             what = (f"library fp32 convolutions from now on ({self.split_fallback_reason})" if self.split_fallback_reason
-                    else f"activation scale 2^-{old} -> 2^-{self.act_shift}")
+                    else f"activation scale 2^-{old} -> 2^-{self.act_shift}" if self.act_shift > old
+                    else f"the activation scale is at its limit (2^-{old}): evaluate this network with use_split_tower = False")
             warnings.warn(f"alpha_zero_amd: the fp32-class evaluator clamped {ev} activation lanes beyond f16's range (largest |v| = "
                           f"{mx * 2.0 ** old:.6g}); {what}", RuntimeWarning, stacklevel=2)
         return ev
@@ -415,7 +432,12 @@ class InferenceNet(nn.Module):
             raise ValueError(f"act_shift {k} out of range")
         dn, up = 2.0 ** -k, 2.0 ** k
         if self.stem_ok:
-            self.stem_wsp.copy_(split_weights_f16(self.stem_w32 * dn))
+            if self.split_fallback_reason or self.stem_fallback_reason or float(self.stem_w32.abs().max()) * dn > F16_MAX:
+                # the split stem is out of use (library fallback), or the scaled stem weights do not fit the f16 pairs (a stem that
+                # needed an initial shift, being reset to 0 on the way to the library): nothing may read stem_wsp -- zero it, never raise
+                self.stem_wsp.zero_()
+            else:
+                self.stem_wsp.copy_(split_weights_f16(self.stem_w32 * dn))
             self.stem_b_sp.copy_(self.stem_b32 * dn)
         for d, b in zip(self.b_sp, self.b32):
             d.copy_(b * dn)
@@ -584,12 +606,13 @@ class InferenceNet(nn.Module):
             tower = ("azsp_resblock_split: one launch per ResNetBlock, intermediate activation in LDS; " if fused else "azsp_conv3x3_split: ")
             return (f"fp32 class, hand-written: split-precision stem / tower ({tower}hi + lo f16 pairs, three MFMA products, "
                     "fp32 accumulation) / fp32 heads (libazsp)")
-        if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower:
+        if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower and not self.split_fallback_reason:
             if (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_TOWER_SHAPES:
                 return ("fp32 class: hand-written split-precision tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 "
-                        "accumulation) behind a library fp32 stem and heads")
-        if self.split_fallback_reason:
-            return f"library fp32 convolutions + azsp_bias_act epilogue (fp32-class kernels given up for this network: {self.split_fallback_reason})"
+                        "accumulation) behind a library fp32 stem and heads" + (f" ({self.stem_fallback_reason})" if self.stem_fallback_reason else ""))
+        if self.split_fallback_reason or self.stem_fallback_reason:
+            return ("library fp32 convolutions + azsp_bias_act epilogue (fp32-class kernels given up for this network: "
+                    f"{self.split_fallback_reason or self.stem_fallback_reason})")
         return f"library convolutions + azsp_bias_act epilogue (no hand-written kernel for {self.filters} filters on {board_size}x{board_size}, {self.dtype})"
 
     def supports_tiled_features(self, board_size, device):

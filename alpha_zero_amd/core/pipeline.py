@@ -51,6 +51,40 @@ from .replay import Transition  # noqa: E402
 _FEAT_OF = {torch.float32: _abi.FEAT_F32, torch.bfloat16: _abi.FEAT_BF16, torch.float16: _abi.FEAT_F16}
 
 
+class ClampWindow:
+    """Which games may hold a move that was searched on a CLAMPING fp32-class evaluator (Weak #1).  The range record says
+    that some kernel lane clamped since the last poll, not which board: every game that ran a round inside the window
+    (last clean poll, detecting poll] is suspect -- the games in progress at the detecting poll and the finished games not handed out
+    yet.  The reference's fp32 forward (pipeline.py:102-109) has no such window, so none of their samples may reach the learner
+    unmarked.  Games are identified by the engine's uid = (games finished before in that slot) * G + slot."""
+
+    _NONE_LO, _NONE_HI = np.iinfo(np.int64).max, -1
+
+    def __init__(self, num_games):
+        self.G = int(num_games)
+        self.next_unharvested = np.zeros(self.G, dtype=np.int64)  # per slot: first game index no harvest has handed out yet
+        self.lo = np.full(self.G, self._NONE_LO, dtype=np.int64)   # per slot: suspect game indices [lo, hi]
+        self.hi = np.full(self.G, self._NONE_HI, dtype=np.int64)
+        self.events = 0
+
+    def on_event(self, games_done):
+        """games_done int[G]: azsp_get_status column 5 at the detecting poll (= the index of each slot's game in progress)."""
+        gd = np.asarray(games_done, dtype=np.int64).reshape(self.G)
+        self.lo = np.minimum(self.lo, self.next_unharvested)
+        self.hi = np.maximum(self.hi, gd)
+        self.events += 1
+
+    def mask(self, uids):
+        """bool per harvested game (uids = column 11 of the harvest rows): suspect?  Advances the per-slot harvest front."""
+        u = np.asarray(uids, dtype=np.int64)
+        slot, idx = u % self.G, u // self.G
+        m = (idx >= self.lo[slot]) & (idx <= self.hi[slot])
+        np.maximum.at(self.next_unharvested, slot, idx + 1)
+        spent = self.next_unharvested > self.hi  # intervals wholly behind the harvest front are used up
+        self.lo[spent], self.hi[spent] = self._NONE_LO, self._NONE_HI
+        return m
+
+
 class SelfPlayActor:
     """G concurrent self-play games on one GPU: replaces G `run_selfplay_actor_loop` processes
     (pipeline.py:166-286).  One round = engine kernel (expand/backup of the previous leaf batch, end-of-move
@@ -118,6 +152,10 @@ class SelfPlayActor:
         self.straddled_games = 0  # harvested games that were in progress across a weight hot-swap (see harvest())
         # fp32-class evaluator: clamped out-of-range activations seen so far and the rescalings they triggered (_check_evaluator_range)
         self.range_events, self.range_max_abs, self.range_rescales = 0, 0.0, 0
+        # games that ran a round between a clamp event and its repair (ClampWindow): harvest() marks them `evaluator_clamped` or, with
+        # drop_clamped_games = True (run_selfplay_actor_loop), drops them; harvest_tensors() leaves a bool per game in last_harvest_clamped
+        self.clamp_window = ClampWindow(num_games)
+        self.drop_clamped_games, self.clamped_games, self.last_harvest_clamped = False, 0, np.zeros(0, dtype=bool)
         self.drop_straddling_games = False
         self.set_network(network, training_steps)
 
@@ -131,6 +169,9 @@ class SelfPlayActor:
         self.training_steps = training_steps
         self.engine.set_actor_state(self.resign_threshold, training_steps)  # games that start from now on carry this tag
         self._graph = None
+        if getattr(self, "rounds", 0) and "library stem (tiled features disabled" not in self.evaluator_path:
+            # a hot-swapped network starts uncalibrated at shift 0: drop the previous network's "activations carried x 2^-k" note
+            self.evaluator_path = self.infer.evaluator_path(self.board_size, self.device) + self._widen_note
 
     def set_resign_threshold(self, resign_threshold):
         """var_resign_threshold as the reference actor reads it before EVERY game (pipeline.py:241-242): games that start after this
@@ -143,7 +184,7 @@ class SelfPlayActor:
         if e.features_tiled:
             self.infer.forward_tiled(e.features, e.rows, e.N, e.priors, e.values)
         elif e.features_split:
-            if self.infer.split_fallback_reason:  # calibration gave the fp32-class kernels up for this network: library fp32 convolutions
+            if self.infer.split_fallback_reason or self.infer.stem_fallback_reason:  # the fp32-class kernels (or their stem) were given up for this network
                 self.infer._forward_after_split_fallback(e.features, e.priors, e.values, (e.rows, e.N))
                 return
             if not self.infer.supports_split_features(e.N, self.device):  # (someone switched the split kernels off on the live InferenceNet)
@@ -222,7 +263,16 @@ class SelfPlayActor:
         e.g. an asynchronous learner or a replay insert on another stream)."""
         st, pi, z, games = self.engine.harvest()
         self._check_evaluator_range()
+        self.last_harvest_clamped = self.clamp_window.mask(games[:, 11]) if len(games) else np.zeros(0, dtype=bool)
+        self.clamped_games += int(self.last_harvest_clamped.sum())
         return (st.clone(), pi.clone(), z.clone(), games) if clone else (st, pi, z, games)
+
+    def poll_evaluator_range(self):
+        """Poll the fp32-class evaluator's range record now (two words; synchronises the stream) instead of waiting for the next
+        harvest: an event is repaired at once and the games that ran inside the window are remembered (ClampWindow).  The actor loop
+        calls this every few rounds, which bounds the window by that many rounds.  Returns the events seen so far."""
+        self._check_evaluator_range()
+        return self.range_events
 
     def _check_evaluator_range(self):
         """fp32-class evaluator: its kernels carry values as f16 pairs and clamp what exceeds +-65504 (in units of 2^act_shift) -- the
@@ -230,7 +280,8 @@ class SelfPlayActor:
         (InferenceNet.range_rec; another actor or evaluator in the same process has its own); it is polled here, once per harvest (the
         harvest has synchronised the stream already).  An event is counted, announced and ACTED on: the network is re-calibrated on
         the current leaf batch (a larger exact power-of-two activation scale), or, if the format cannot carry it, handed to the
-        library's fp32 convolutions -- the actor never keeps playing on a clamping evaluator."""
+        library's fp32 convolutions -- the actor never keeps playing on a clamping evaluator PAST THE POLL; what ran
+        between the event and the poll is marked (ClampWindow: harvest() marks or drops those games)."""
         inf = self.infer
         if (self.device.type != "cuda" or self.net_dtype != torch.float32 or inf.binding is None or not inf.use_split_tower
                 or inf.split_fallback_reason or not hasattr(inf, "range_rec")):
@@ -244,6 +295,8 @@ class SelfPlayActor:
         self.range_max_abs = max(self.range_max_abs, mx * 2.0 ** inf.act_shift)
         old_shift = inf.act_shift
         e = self.engine
+        # every game that ran a round since the last clean poll is suspect: the ones in progress now + the finished ones not handed out yet
+        self.clamp_window.on_event(e.status()[0][:, 5])
         if e.features_split and inf.supports_split_features(e.N, self.device):
             inf.act_calibrated = False
             inf.set_act_shift(min(inf.MAX_ACT_SHIFT, old_shift + 2))  # at least 4x more room, then whatever the calibration asks for
@@ -279,12 +332,20 @@ class SelfPlayActor:
         states, pi, z, games = got[:4]
         extra = self.engine.last_extra
         if len(games) == 0:
+            self.last_harvest_clamped = np.zeros(0, dtype=bool)
             return []
         states, pi, z = states.cpu().numpy(), pi.cpu().numpy(), z.cpu().numpy()
         moves = got[4].cpu().numpy() if with_moves else None
         out = []
-        for row, ex in zip(games, extra):
+        self.last_harvest_clamped = self.clamp_window.mask(games[:, 11])
+        for row, ex, clamped in zip(games, extra, self.last_harvest_clamped):
             s0, ln = int(row[0]), int(row[1])
+            if clamped:
+                # the game ran a round between a clamp event of the fp32-class evaluator and its repair: some of its searches may have
+                # used a clamped activation where the reference's fp32 forward (pipeline.py:102-109) carries the value on
+                self.clamped_games += 1
+                if self.drop_clamped_games:
+                    continue
             if int(ex[3]):
                 # The game was in progress across a weight hot-swap -- impossible in the reference, whose actor only reloads between
                 # games (pipeline.py:232-239).  It keeps the tag of the weights that STARTED it (pipeline.py:237 -> :271) and is
@@ -298,6 +359,8 @@ class SelfPlayActor:
             thr = float(np.array([ex[1], ex[2]], dtype=np.int32).view(np.float64)[0])
             stats = game_stats_from_row(row, self.game, self.komi, thr)
             stats["training_steps"] = int(row[12])  # weights in use when the game started (pipeline.py:237, :271, :492)
+            if clamped:
+                stats["evaluator_clamped"] = True  # (only ever present on such a game: the reference's stats keys stay as they are)
             out.append((seq, stats, [int(m) for m in moves[s0:s0 + ln] if m >= 0]) if with_moves else (seq, stats))
         return out
 
@@ -361,6 +424,7 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
                           check_resign_after_steps=check_resign_after_steps, disable_resign_ratio=disable_resign_ratio,
                           resign_threshold=thr, komi=getattr(env, "komi", 7.5), num_to_win=getattr(env, "num_to_win", 5),
                           seed=seed, rank=rank, device=device, net_dtype=net_dtype, training_steps=training_steps, binding=binding)
+    actor.drop_clamped_games = True  # the learner never sees a game that ran on a clamping evaluator (the reference's fp32 has no range)
     writer = None
     if logs_dir:  # per-actor statistics file with the reference's columns (pipeline.py:196, :268-271; logs/go/9x9/actor0.csv)
         from ..utils.csv_writer import CsvWriter
@@ -390,6 +454,7 @@ def run_selfplay_actor_loop(seed, rank, network, device, data_queue, env, num_si
         while done_rounds < harvest_every and not (ckpt_event is not None and ckpt_event.is_set()) and not (stop_event is not None and stop_event.is_set()):
             actor.run_rounds(min(poll, harvest_every - done_rounds))
             done_rounds += poll
+            actor.poll_evaluator_range()  # two words: a clamp event is repaired within `poll` rounds, the games of the window are remembered
         want_sgf = bool(save_sgf_dir) and save_sgf_interval > 0 and os.path.isdir(save_sgf_dir)
         finished = actor.harvest(with_moves=want_sgf)
         now = time.time()

@@ -93,6 +93,13 @@ int d2h(void* d, const void* s, size_t n, void* st) {
 }
 int zero(void* d, size_t n, void* st) { return AZ_HIP(hipMemsetAsync(d, 0, n, (hipStream_t)st)); }
 int sync(void* st) { return AZ_HIP(hipStreamSynchronize((hipStream_t)st)); }
+void* host_alloc(size_t n) {
+    void* p = nullptr;
+    return AZ_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)) ? nullptr : p;
+}
+void host_release(void* p) { (void)hipHostFree(p); }
+int h2d_async(void* d, const void* s, size_t n, void* st) { return AZ_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); }
+int d2h_async(void* d, const void* s, size_t n, void* st) { return AZ_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); }
 int set_device(int dev) {
     int n = 0;
     if (AZ_HIP(hipGetDeviceCount(&n)) || n < 1) return -1;

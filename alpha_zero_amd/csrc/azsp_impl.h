@@ -523,6 +523,8 @@ struct AzHandle {
     int16_t* harvest_moves = nullptr;  // optional per-sample move output of azsp_harvest (azsp_harvest_moves)
     int* d_gextra = nullptr;           // [d_games_cap][4] per-game extras (azsp_harvest_extra)
     int32_t* harvest_extra = nullptr;  // host destination of the extras, optional
+    unsigned char* pin = nullptr;      // page-locked staging of azsp_dropin_step (one packed upload + one packed read-back per call)
+    size_t pin_bytes = 0;
 };
 
 namespace azb {  // implemented by the backend translation unit
@@ -532,6 +534,10 @@ int h2d(void* dst, const void* src, size_t n, void* stream);
 int d2h(void* dst, const void* src, size_t n, void* stream);
 int zero(void* dst, size_t n, void* stream);
 int sync(void* stream);
+void* host_alloc(size_t n);  // page-locked host memory (staging of azsp_dropin_step)
+void host_release(void* p);
+int h2d_async(void* dst, const void* src_pinned, size_t n, void* stream);  // no synchronisation: src must stay untouched until the stream drains
+int d2h_async(void* dst_pinned, const void* src, size_t n, void* stream);
 int set_device(int dev);
 const char* backend_error();
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream, int g0, int g1);  // games [g0, g1)
@@ -759,6 +765,7 @@ int azsp_destroy(void* e) {
     AzHandle* h = (AzHandle*)e;
     azb::sync(nullptr);
     for (void* q : h->allocs) azb::release(q);
+    if (h->pin) azb::host_release(h->pin);
     delete h;
     return AZSP_OK;
 }
@@ -899,6 +906,54 @@ int azsp_get_status(void* e, int32_t* status, double* q, void* stream) {
     if (status && azb::d2h(status, h->d_status, sizeof(int) * 8 * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
     if (q && azb::d2h(q, h->d_q, sizeof(double) * 2 * (size_t)h->cfg.G, stream)) return AZSP_EDEVICE;
     return az_check_engine_fault(h, stream);
+}
+
+int azsp_dropin_step(void* e, const float* priors_host, const float* values_host, float* priors_dev, float* values_dev, void* feat_dev,
+                     uint8_t* valid_dev, int32_t* status_host, double* q_host, uint8_t* valid_host, void* feat_host, int64_t feat_bytes, void* stream) {
+    AzHandle* h = (AzHandle*)e;
+    if (!h || !priors_dev || !values_dev || !feat_dev || !valid_dev || !status_host || !valid_host || feat_bytes < 0 || (feat_bytes > 0 && !feat_host) ||
+        (priors_host == nullptr) != (values_host == nullptr))
+        return AZSP_EINVAL;
+    const size_t G = (size_t)h->cfg.G, rows = G * (size_t)h->cfg.P, A = (size_t)h->A;
+    // staging layout: [priors rows*A f32][values rows f32] | [status G*8 i32][q G*2 f64][err i32 (+pad)][valid rows u8 (padded to 8)][features]
+    const size_t o_val = rows * A * 4, up = o_val + rows * 4, o_st = (up + 15) & ~(size_t)15, o_q = o_st + G * 32, o_err = o_q + G * 16, o_valid = o_err + 8,
+                 o_feat = o_valid + ((rows + 15) & ~(size_t)15), total = o_feat + (size_t)feat_bytes;
+    if (h->pin_bytes < total) {
+        if (h->pin) azb::host_release(h->pin);
+        h->pin = (unsigned char*)azb::host_alloc(total);
+        h->pin_bytes = h->pin ? total : 0;
+        if (!h->pin) return AZSP_ENOMEM;
+    }
+    unsigned char* pin = h->pin;
+    int rc;
+    if (priors_host) {  // Phases 2-3 of the previous leaf batch (core/mcts_v2.py:614-625), then the end-of-search work when the budget is met
+        memcpy(pin, priors_host, rows * A * 4);
+        memcpy(pin + o_val, values_host, rows * 4);
+        if (azb::h2d_async(priors_dev, pin, rows * A * 4, stream) || azb::h2d_async(values_dev, pin + o_val, rows * 4, stream)) return AZSP_EDEVICE;
+        if ((rc = azsp_expand_backup(e, priors_dev, values_dev, stream)) != 0) return rc;
+    }
+    if ((rc = azsp_select(e, feat_dev, valid_dev, stream)) != 0) return rc;  // Phase 1 of the next batch (core/mcts_v2.py:572-611)
+    OpStatus op = {h->d_status, h->d_q};
+    if ((rc = az_run(h, op, stream)) != 0) return rc;
+    if (azb::d2h_async(pin + o_st, h->d_status, G * 32, stream) || azb::d2h_async(pin + o_q, h->d_q, G * 16, stream) ||
+        azb::d2h_async(pin + o_err, h->mem.err, sizeof(int), stream) || azb::d2h_async(pin + o_valid, valid_dev, rows, stream) ||
+        (feat_bytes > 0 && azb::d2h_async(pin + o_feat, feat_dev, (size_t)feat_bytes, stream)) || azb::sync(stream)) {
+        h->err = std::string("copy failed: ") + azb::backend_error();
+        return AZSP_EDEVICE;
+    }
+    memcpy(status_host, pin + o_st, G * 32);
+    if (q_host) memcpy(q_host, pin + o_q, G * 16);
+    memcpy(valid_host, pin + o_valid, rows);
+    if (feat_bytes > 0) memcpy(feat_host, pin + o_feat, (size_t)feat_bytes);
+    int ef;
+    memcpy(&ef, pin + o_err, sizeof(int));
+    if (ef) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "engine fault flags 0x%x (1=node pool exhausted, 2=tree deeper than %d, 4=move sampling, 8=staging full)", ef, AZ_PATH_CAP);
+        h->err = buf;
+        return AZSP_EENGINE;
+    }
+    return AZSP_OK;
 }
 
 int azsp_rng_probe(void* e, int32_t plies, int32_t tries, double* noise_host, double* unif_host, void* stream) {

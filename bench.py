@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
+MFMA_PEAK_CLOCK_GHZ = 2.4  # the clock the 2.5 PF/s dense f16 / bf16 peak is quoted at (256 CUs x 4 SIMDs x 1024 flop / cycle)
 SPLIT_PRODUCTS = 3  # f16 MFMA products per fp32-class multiply-add of the split-precision kernels (w_hi x_hi, w_hi x_lo, w_lo x_hi)
 DTYPE_LABEL = {"fp32": "fp32-class evaluator (f16 hi+lo pairs, 3 MFMA products, fp32 accumulate) / f32-f64 tree",
                "bf16": "bf16 evaluator / f32-f64 tree", "fp16": "fp16 evaluator / f32-f64 tree"}
@@ -348,18 +349,58 @@ def evaluator_range(actor):
             "fallback": inf.split_fallback_reason or None}
 
 
-def power_ceiling(split):
-    """MFMA-only throughput under the package power limit on this kernel's operand mix, from profiles/mfma_power_probe.json (the
-    output of tools/probes/mfma_power_probe.hip on MI355X; nothing is hard-coded here).  None when the file is absent."""
+def mfma_ceilings(split):
+    """What the matrix cores alone sustain with this kernel's instruction form and operand mix, from profiles/mfma_power_probe.json (the
+    output of tools/probes/mfma_power_probe.hip on MI355X; nothing is hard-coded here): `issue_ceiling` = the form with ALL-ZERO operands,
+    where the package power limit cannot bind -- the rate at which the instruction can be issued at all (v_mfma_f32_16x16x32 issues every
+    ~20 cycles for 16 cycles of work: 0.79 of the 2.5 PF/s peak; v_mfma_f32_32x32x16: 0.985); `sustained` = the form on the kernel's own
+    operand mix (real data: the smaller of the issue ceiling and the power limit).  `limit` says which of the two `sustained` is.
+    (Rounds 4-5 published `sustained` of the split mix as "power_limited_mfma_only_tflops": for the 16x16x32 form it is the ISSUE ceiling.)"""
     pth = os.path.join(ROOT, "profiles", "mfma_power_probe.json")
     try:
         pj = json.load(open(pth))
+        cases = {(c["mfma"], c["operands"].split(" (")[0]): c["tflops"] for c in pj["cases"]}
         if split:
-            return {"value": float(pj["split_mix_mfma_only_tflops"]), "source": "from_profiles: profiles/mfma_power_probe.json (split-precision operand mix, f16)"}
-        v = [c["tflops"] for c in pj["cases"] if c["mfma"] == "v_mfma_f32_32x32x16_bf16" and c["operands"].startswith("A dense")]
-        return {"value": float(v[0]), "source": "from_profiles: profiles/mfma_power_probe.json (bf16, A dense, B half zeros)"}
+            form, pipe_cycles = "v_mfma_f32_16x16x32_f16", 16.0
+            issue = float(pj.get("issue_ceiling_16x16x32_tflops", cases[("v_mfma_f32_16x16x32_bf16", "zeros")]))
+            sustained = float(pj["split_mix_mfma_only_tflops"])
+            what = "split-precision operand mix, f16"
+        else:
+            form, pipe_cycles = "v_mfma_f32_32x32x16_bf16", 32.0
+            issue = float(pj.get("issue_ceiling_32x32x16_tflops", cases[("v_mfma_f32_32x32x16_bf16", "zeros")]))
+            sustained = float(cases[("v_mfma_f32_32x32x16_bf16", "A dense, B half zeros")])
+            what = "bf16, A dense, B half zeros"
+        out = {"instruction_form": form, "pipe_cycles_per_mfma_at_peak": pipe_cycles, "issue_ceiling_tflops": issue, "sustained_tflops": sustained,
+               "limit": "issue" if sustained >= 0.97 * issue else "power", "source": f"from_profiles: profiles/mfma_power_probe.json ({what}; all-zero operands for the issue ceiling)"}
+        if split and "split_mix_32x32x16_tflops" in pj:  # the other instruction form on the same operand mix (VERDICT r5 #2)
+            out["other_form"] = {"instruction_form": "v_mfma_f32_32x32x16_f16", "sustained_tflops": float(pj["split_mix_32x32x16_tflops"]),
+                                 "issue_ceiling_tflops": float(pj["split_mix_32x32x16_zero_operands_tflops"])}
+        return out
     except Exception:
         return None
+
+
+def kernel_pmc(cname):
+    """A PMC summary from profiles/ with its freshness: `stale` is True when the summary records the digest of the kernel sources it was
+    measured on and that digest differs from the sources of this tree (the kernel was edited after the counters were collected), None
+    when the summary predates the digest (rounds 1-5: unknown)."""
+    cprof = os.path.join(ROOT, "profiles", cname)
+    if not os.path.exists(cprof):
+        return None, None
+    try:
+        pj = json.load(open(cprof))
+    except Exception:
+        return None, None
+    stale = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_digest import PMC_FILE_FAMILY, kernel_source_digest
+
+        if pj.get("kernel_source_sha256") and cname in PMC_FILE_FAMILY:
+            stale = pj["kernel_source_sha256"] != kernel_source_digest(PMC_FILE_FAMILY[cname])
+    except Exception:
+        stale = None
+    return pj, stale
 
 
 def tower_roofline(conv, args, step_ms):
@@ -377,18 +418,15 @@ def tower_roofline(conv, args, step_ms):
         cname = "split_kernel_pmc.json" if S_t == 9 else ("splitblock17_kernel_pmc.json" if fused else "split17_kernel_pmc.json")
     else:
         cname = "block64_kernel_pmc.json" if fused else {(9, 128): "conv_kernel_pmc.json", (19, 256): "conv19_kernel_pmc.json"}.get((S_t, args.filters), "conv64_kernel_pmc.json")
-    ctraffic, csrc = None, None
-    cprof = os.path.join(ROOT, "profiles", cname)
-    if os.path.exists(cprof):
-        try:
-            pj = json.load(open(cprof))
-            if pj.get("board") == n and pj.get("channels") == args.filters and pj.get("rows"):
-                # per-launch bytes scale with the boards of a launch (every board is read / written once): a pass at another batch
-                # size is scaled linearly and labelled
-                ctraffic = round(pj["hbm_bytes_per_launch"] * rows / pj["rows"])
-                csrc = "from_profiles: profiles/" + cname + " (separate rocprofv3 --pmc pass, not this run" + ("" if pj["rows"] == rows else f"; measured at {pj['rows']} boards per launch, scaled linearly to {rows}") + ")"
-        except Exception:
-            ctraffic = None
+    ctraffic, csrc, cstale = None, None, None
+    pj, cstale = kernel_pmc(cname)
+    if pj is not None and pj.get("board") == n and pj.get("channels") == args.filters and pj.get("rows") and pj.get("hbm_bytes_per_launch"):
+        # per-launch bytes scale with the boards of a launch (every board is read / written once): a pass at another batch
+        # size is scaled linearly and labelled
+        ctraffic = round(pj["hbm_bytes_per_launch"] * rows / pj["rows"])
+        age = {True: "STALE: the kernel sources were edited after this pass -- not evidence for this binary; ", False: "kernel sources unchanged since the pass; ",
+               None: "pass of an earlier round, no source digest recorded; "}[cstale]
+        csrc = "from_profiles: profiles/" + cname + " (" + age + "separate rocprofv3 --pmc pass, not this run" + ("" if pj["rows"] == rows else f"; measured at {pj['rows']} boards per launch, scaled linearly to {rows}") + ")"
     if split:
         # fp32-class arithmetic on the f16 matrix pipe: every multiply-add of the algorithm is SPLIT_PRODUCTS f16 MFMA products (hi x hi, hi x lo,
         # lo x hi).  `achieved` counts the products the kernel has to issue -- that is what the MFMA roofline bounds -- and the
@@ -428,12 +466,102 @@ def tower_roofline(conv, args, step_ms):
                 "avg_launch_ms_residual": round(conv["avg_ms_residual"], 4) if conv["avg_ms_residual"] is not None else None,
                 "launches_per_step": launches_per_step, "share_of_step": round(launches_per_step * conv["avg_ms"] / step_ms, 4),
                 "timed_on": conv.get("data"),
-                # annotation, not a measurement of this run: the MFMA-only ceiling on this kernel's operand mix at the package power limit,
-                # measured by tools/probes/mfma_power_probe.hip and read from its committed output
-                "power_limited_mfma_only_tflops": power_ceiling(split),
-                "frac_of_power_limited_ceiling": (round(tf / power_ceiling(split)["value"], 4) if power_ceiling(split) else None)}
+                "traffic_stale": cstale}
+    # annotations, not measurements of this run: what the matrix cores alone sustain with this instruction form (issue ceiling, all-zero
+    # operands) and on this operand mix, measured by tools/probes/mfma_power_probe.hip and read from its committed output; and the
+    # decomposition of `frac` from the PMC pass: frac ~ instruction_form_ceiling x issue_efficiency x clock_fraction
+    ceil = mfma_ceilings(split)
+    roofline["mfma_ceilings"] = ceil
+    issued_tf = tf
+    roofline["frac_algorithmic"] = round(conv_flops / (conv["avg_ms"] * 1e-3) / 1e12 / peak, 5)  # algorithmic flops / dense peak of the MFMA dtype
+    if ceil:
+        roofline["frac_of_issue_ceiling"] = round(issued_tf / ceil["issue_ceiling_tflops"], 4)
+        roofline["instruction_form_ceiling"] = round(ceil["issue_ceiling_tflops"] / peak, 4)
+        if pj is not None and pj.get("cycles_per_mfma") and pj.get("effective_clock_GHz_mean"):
+            issue_cycles = ceil["pipe_cycles_per_mfma_at_peak"] / (ceil["issue_ceiling_tflops"] / peak)  # cycles between two issues of the form at its ceiling
+            roofline["cycles_per_mfma"] = pj["cycles_per_mfma"]
+            roofline["issue_efficiency"] = round(issue_cycles / pj["cycles_per_mfma"], 4)
+            roofline["clock_fraction"] = round(pj["effective_clock_GHz_mean"] / MFMA_PEAK_CLOCK_GHZ, 4)
+            roofline["decomposition_product"] = round(roofline["instruction_form_ceiling"] * roofline["issue_efficiency"] * roofline["clock_fraction"], 4)
+            roofline["decomposition_source"] = ("from_profiles: profiles/" + cname + " (SQ_INSTS_MFMA, GRBM_GUI_ACTIVE / 8 XCDs and the launch time of the same passes: "
+                                                "cycles per MFMA and the effective clock; " + ("STALE" if cstale else "kernel sources unchanged" if cstale is False else "no source digest") + ")")
     roofline.update(extra)
     return roofline
+
+
+def c1_dropin(seconds=8.0):
+    """BASELINE configs[0] (C1) through the KEPT ENTRY POINT: `alpha_zero_amd.core.mcts_v2.uct_search` (the reference's signature,
+    mcts_v2.py:301-450) in the reference actor's loop shape (pipeline.py:289-346: warm-up temperature for the first 16 moves, root noise,
+    sub-tree reuse) on 13x13 Gomoku, 100 simulations per move, with the reference's shipped trained 10 x 40 checkpoint when the golden
+    copy of its weights travelled (tests/golden/, data), a random network of that shape otherwise.  The tree lives on the GPU engine; the
+    evaluator is the caller's callback: (a) `cpu_eval_func` = the reference's own eval_position (pipeline.py:91-123: fp32 torch-CPU module, one
+    torch thread as training_gomoku.py sets), (b) `device_eval_func` = the product evaluator (InferenceNet, fp32-class kernels) behind the
+    same callback signature.  moves/s of each; one host round trip per simulation (azsp_dropin_step)."""
+    from alpha_zero_amd.core.mcts_v2 import uct_search
+    from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet, widen_for_kernels
+    from alpha_zero_amd.envs.gomoku import GomokuEnv
+    from alpha_zero_amd import _lib
+
+    n, sims = 13, 100
+    net = AlphaZeroNet((17, n, n), n * n, 10, 40, 80, gomoku=True)
+    ck = os.path.join(ROOT, "tests", "golden", "gomoku13_ckpt200000_network.pt")
+    weights = "random init (10 x 40, fc 80)"
+    if os.path.exists(ck):
+        net.load_state_dict(torch.load(ck, map_location="cpu", weights_only=True)["network"], strict=True)
+        weights = "the reference's shipped checkpoint checkpoints/gomoku/13x13/training_steps_200000.ckpt (10 x 40)"
+    net = net.eval()
+
+    @torch.no_grad()
+    def cpu_eval(state, batched=False):  # pipeline.py:91-123
+        x = torch.from_numpy(state if batched else state[None, ...]).to(dtype=torch.float32)
+        logits, v = net(x)
+        pi = torch.softmax(logits, dim=-1).cpu().numpy()
+        v = np.squeeze(v.cpu().numpy(), axis=1).tolist()
+        pi = [pi[i] for i in range(pi.shape[0])]
+        return (pi, v) if batched else (pi[0], v[0])
+
+    wnet, wnote = widen_for_kernels(net, n, torch.float32)  # 40 -> 64 filters, function-preserving: the hand-written fp32-class kernels
+    inf = InferenceNet(wnet, dtype=torch.float32, binding=_lib.load()).cuda()
+
+    @torch.no_grad()
+    def dev_eval(state, batched=False):
+        x = torch.from_numpy(state if batched else state[None, ...]).to(device="cuda", dtype=torch.float32, non_blocking=True)
+        pri, v = inf(x)
+        pri, v = pri.float().cpu().numpy(), v.float().cpu().numpy().tolist()
+        pi = [pri[i] for i in range(pri.shape[0])]
+        return (pi, v) if batched else (pi[0], v[0])
+
+    def play(eval_func, budget):
+        np.random.seed(1)
+        env = GomokuEnv(board_size=n)
+        moves, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            env.reset()
+            root, done = None, False
+            while not done and time.perf_counter() - t0 < budget:
+                mv, pi, rq, cq, root = uct_search(env=env, eval_func=eval_func, root_node=root, c_puct_base=19652.0, c_puct_init=1.25,
+                                                  num_simulations=sims, root_noise=True, warm_up=not (env.steps > 16))
+                _, _, done, _ = env.step(mv)
+                moves += 1
+        return moves / (time.perf_counter() - t0), moves
+
+    nthreads = torch.get_num_threads()
+    out = {"config": "BASELINE C1: 13x13 Gomoku, uct_search (P = 1), 100 sims/move, one game at a time, sub-tree reuse, root noise", "weights": weights,
+           "entry_point": "alpha_zero_amd.core.mcts_v2.uct_search (same signature and return tuple as the reference's mcts_v2.uct_search)",
+           "host_round_trips_per_simulation": 1}
+    try:
+        torch.set_num_threads(1)
+        play(cpu_eval, 0.5)  # engine creation, first launches
+        v, m = play(cpu_eval, seconds)
+        out["cpu_eval_func_moves_per_s"], out["cpu_eval_func_moves"] = round(v, 3), m
+    finally:
+        torch.set_num_threads(nthreads)
+    play(dev_eval, 0.5)
+    v, m = play(dev_eval, seconds)
+    out["device_eval_func_moves_per_s"], out["device_eval_func_moves"] = round(v, 3), m
+    out["device_evaluator"] = inf.evaluator_path(n, torch.device("cuda")) + wnote
+    out["reference_moves_per_s_dev_container"] = 3.1  # BASELINE.md section 2 (the imported reference on this configuration; it cannot travel to the GPU box)
+    return out
 
 
 def main(argv=None):
@@ -622,7 +750,7 @@ def main(argv=None):
                      "note": "same engine / evaluator / workload with sub-tree reuse disabled: the upper-work variant, labelled, never `value`"}
             del af, evf
             torch.cuda.empty_cache()
-        cpu, c1 = None, None
+        cpu, c1, c1d = None, None, None
         if world == 1 and not args.no_cpu_baseline:
             from oracle import baseline
 
@@ -637,6 +765,15 @@ def main(argv=None):
             c1 = baseline.run(1, seconds=min(8.0, args.cpu_seconds), game="gomoku", n=13, sims=100, P=1, blocks=6, filters=64, stagger=0)
             c1["value"], c1["per_core"] = round(c1["value"], 3), round(c1["per_core"], 4)
             c1["config"] = "BASELINE C1: 13x13 Gomoku, uct_search, 1 CPU self-play actor, 100 sims/move (reference path, no GPU)"
+            # the same port on the shape of the checkpoint C1 names (10 x 40), and the kept entry point on the GPU engine beside it
+            c1b = baseline.run(1, seconds=min(8.0, args.cpu_seconds), game="gomoku", n=13, sims=100, P=1, blocks=10, filters=40, stagger=0)
+            try:
+                c1d = c1_dropin(seconds=min(8.0, args.cpu_seconds))
+                c1d["cpu_port_moves_per_s_10x40"] = round(c1b["value"], 3)
+                c1d["cpu_eval_func_over_cpu_port"] = round(c1d["cpu_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
+                c1d["device_eval_func_over_cpu_port"] = round(c1d["device_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
+            except Exception as ex:  # the companion must never take the headline down
+                c1d = {"error": repr(ex)}
             # port vs the imported reference on identical seeded moves, measured in the development container by
             # tools/calibrate_baseline.py (the reference cannot travel to the GPU box): ratio = port moves/s / reference moves/s
             cal = os.path.join(ROOT, "tests", "golden", "cpu_baseline_calibration.json")
@@ -680,7 +817,7 @@ def main(argv=None):
             "speedup_vs_reference_equivalent_cpu": (round(total_moves / elapsed_max / cpu["reference_equivalent_value"], 1)
                                                     if cpu and cpu.get("reference_equivalent_value") else None),
             "roofline": roofline, "engine_roofline": engine_roof, "nn_roofline": nn_roof,
-            "cpu_baseline": cpu if world == 1 else "measured at N=1 only", "c1_cpu_reference_path": c1,
+            "cpu_baseline": cpu if world == 1 else "measured at N=1 only", "c1_cpu_reference_path": c1, "c1_dropin": c1d,
             # fp32-class evaluator: lanes that met a value beyond the f16-pair format's range during pre-roll + warm-up + timed region of
             # THIS run's headline actor (its own range record, read before the kernel replay); must be 0 for the line to be valid
             "evaluator_range_events": erange["events"] if erange else None, "evaluator_range": erange,

@@ -1,4 +1,6 @@
-"""Worker of test_sample_gather_two_ranks_gloo: one process per rank, host-twin engine, gloo backend."""
+"""Worker of test_sample_gather_{two,eight}_ranks_gloo: one process per rank, host-twin engine, gloo backend.  With more than two ranks
+the ranks play different budgets (uneven sample counts per harvest) and every third (rank, iteration) contributes NOTHING to the gather
+(zero count: its finished games stay staged in the engine until its next turn)."""
 import os
 import sys
 
@@ -19,12 +21,16 @@ from alpha_zero_amd.core.pipeline import SelfPlayActor  # noqa: E402
 
 torch.manual_seed(1)
 net = AlphaZeroNet((17, 5, 5), 26, 1, 8, 8)
-a = SelfPlayActor(net, game="go", board_size=5, num_games=4, num_simulations=12, num_parallel=2, warm_up_steps=4, device="cpu",
+a = SelfPlayActor(net, game="go", board_size=5, num_games=4, num_simulations=12 if world <= 2 else 8 + 4 * (rank % 3), num_parallel=2, warm_up_steps=4, device="cpu",
                   net_dtype=torch.float32, use_graph=False, binding=eu.hosttwin_binding(), seed=1, rank=rank)
 acc = None
 for it in range(400):
     a.run_rounds(20)
-    st, pi, z, games = a.harvest_tensors()
+    if world > 2 and (rank + it) % 3 == 0:  # this rank sits the exchange out: zero samples, zero games
+        st, pi, z, games = (torch.empty((0, 17, 5, 5), dtype=torch.int8), torch.empty((0, 26), dtype=torch.float32), torch.empty((0,), dtype=torch.float32),
+                            np.zeros((0, 16), dtype=np.int32))
+    else:
+        st, pi, z, games = a.harvest_tensors()
     np.savez(os.path.join(outdir, f"local{rank}_{it}.npz"), states=st.numpy(), pi=pi.numpy(), z=z.numpy(), games=games)
     res = gather_samples(st.clone(), pi.clone(), z.clone(), games, dst=0)
     flag = torch.tensor([0])
@@ -37,7 +43,7 @@ for it in range(400):
             acc[0].append(res[0].numpy().copy()), acc[1].append(res[1].numpy().copy()), acc[2].append(res[2].numpy().copy()), acc[3].append(g)
             acc[4] += res[0].shape[0]
         ranks_seen = set(int(x) >> 20 for gg in acc[3] for x in gg[:, 15])
-        flag[0] = 1 if ranks_seen == {0, 1} else 0
+        flag[0] = 1 if ranks_seen == set(range(world)) and it >= 5 else 0
     dist.broadcast(flag, 0)
     if flag.item():
         break

@@ -19,6 +19,10 @@ int h2d(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
 int d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
 int zero(void* d, size_t n, void*) { memset(d, 0, n); return 0; }
 int sync(void*) { return 0; }
+void* host_alloc(size_t n) { return calloc(1, n); }
+void host_release(void* p) { free(p); }
+int h2d_async(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
+int d2h_async(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
 int set_device(int) { return 0; }
 const char* backend_error() { return "host twin"; }
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void*, int g0, int g1) {
@@ -94,17 +98,24 @@ struct SpRangeScope {
     explicit SpRangeScope(unsigned* r) { g_sp_range_cur = r ? r : g_sp_range_host; }
     ~SpRangeScope() { g_sp_range_cur = g_sp_range_host; }
 };
-static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
-    if (!(fabsf(v) <= 65504.0f)) {  // (a NaN is an event too, recorded as +inf: sp_range_abs in az_conv_sp.h)
+// range record of one value (a NaN is an event too, recorded as +inf: sp_range_abs in az_conv_sp.h)
+static inline void sp_h_note(float v) {
+    if (!(fabsf(v) <= 65504.0f)) {
         unsigned bits;
         const float a = v != v ? INFINITY : fabsf(v);
         memcpy(&bits, &a, 4);
         g_sp_range_cur[0] += 1u;
         if (bits > g_sp_range_cur[1]) g_sp_range_cur[1] = bits;
     }
+}
+static inline void sp_h_split_quiet(float v, unsigned short& h, unsigned short& l) {  // clamp + split, no record
     v = fminf(fmaxf(v, -65504.0f), 65504.0f);
     h = sp_h_from_f32(v);
     l = sp_h_from_f32((v - sp_h_to_f32(h)) * 2048.0f);
+}
+static inline void sp_h_split(float v, unsigned short& h, unsigned short& l) {
+    sp_h_note(v);
+    sp_h_split_quiet(v, h, l);
 }
 static inline float sp_h_join(unsigned short h, unsigned short l) { return fmaf(sp_h_to_f32(l), 1.0f / 2048.0f, sp_h_to_f32(h)); }
 // split layout [board][plane][C/8][P2][8] f16 <-> channels-last fp32 rows
@@ -154,8 +165,13 @@ static int host_conv_split(const void* x, const void* w, const float* bias, cons
                 }
                 float v = fmaf(corr, 1.0f / 2048.0f, main);
                 if (rs) v += sp_h_join(rs[yo + at(co, p)], rs[yo + yplane + at(co, p)]);
+                // the device epilogues record |v| IN FRONT of the ReLU (one v_max3_f32 |a|, |b| per pair, then ReLU + clamp in one v_med3_f32):
+                // a pre-activation below -65504 counts as a range event although the ReLU zeroes it -- deliberately conservative (the
+                // post-ReLU record would cost one more VALU per pair in the MFMA shadow; a tower whose negative pre-activations leave
+                // the range has positive ones about to).  The twin records at the same place.
+                sp_h_note(v);
                 if (relu && v < 0.0f) v = 0.0f;
-                sp_h_split(v, ys[yo + at(co, p)], ys[yo + yplane + at(co, p)]);
+                sp_h_split_quiet(v, ys[yo + at(co, p)], ys[yo + yplane + at(co, p)]);
             }
     }
     return 0;

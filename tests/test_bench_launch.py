@@ -85,6 +85,31 @@ def test_bench_measurement_flow_two_ranks_gloo(tmp_path):
     assert f0["per_rank"]["harvest_gather_calls"] == 240 // 7 and min(f0["per_rank"]["harvest_gather_ms_mean"]) > 0
 
 
+def test_bench_measurement_flow_eight_ranks_gloo(tmp_path):
+    """The same control flow at the driver's world size (8 gloo ranks, host-twin actors with four different budgets): one common
+    pre-roll exit, no hang in any collective, samples on rank 0 only, totals = sums over the 8 ranks, time = the maximum, the per-rank
+    report identical on every rank with 8 entries -- what `value(8) ~ 8 value(1) (1 - harvest_gather_share)` is computed from."""
+    W, steps = 8, 120
+    script = os.path.join(ROOT, "tests", "bench_flow_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29567", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(W), str(tmp_path), str(steps)], env=env) for r in range(W)]
+    assert all(p.wait(timeout=900) == 0 for p in procs)
+    f = [json.load(open(os.path.join(str(tmp_path), f"flow{r}.json"))) for r in range(W)]
+    assert len({x["preroll"] for x in f}) == 1 and f[0]["preroll"] >= 10
+    assert all(x["total_moves"] == sum(y["local_moves"] for y in f) for x in f) and f[0]["total_moves"] > 0
+    assert all(x["elapsed_max"] == max(y["elapsed"] for y in f) for x in f)
+    assert f[0]["gathered"] > 0 and all(x["gathered"] == 0 for x in f[1:])
+    pr = f[0]["per_rank"]
+    assert all(x["per_rank"] == pr for x in f) and len(pr["moves_per_s"]) == W == len(pr["harvest_gather_ms_mean"])
+    for r, x in enumerate(f):
+        assert abs(pr["moves_per_s"][r] - x["local_moves"] / x["elapsed"]) <= 0.06
+    assert pr["min_moves_per_s"] == min(pr["moves_per_s"]) and pr["max_moves_per_s"] == max(pr["moves_per_s"])
+    assert pr["harvest_gather_calls"] == steps // 7 and 0 < pr["harvest_gather_share_of_time"] < 1
+    # whole-job value = sum of moves / max time: at most the sum of the ranks' own rates, and what the formula in the bench line predicts
+    value = f[0]["total_moves"] / f[0]["elapsed_max"]
+    assert value <= sum(pr["moves_per_s"]) + 1e-6 and value >= W * pr["min_moves_per_s"] * 0.5
+
+
 def test_bench_exports_dmabuf_ipc_mode_for_itself_and_its_ranks(monkeypatch):
     """Multi-process GPU work on this pool needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC; RCCL otherwise fails in hipIpcGetMemHandle):
     bench.py puts it in its own environment at import (before the HSA runtime starts) -- never overriding a caller's choice -- and hands

@@ -29,8 +29,20 @@ def test_tower_roofline_of_the_headline_kernel():
     pj = json.load(open(os.path.join(ROOT, "profiles", "split_kernel_pmc.json")))
     assert r["traffic"] == round(pj["hbm_bytes_per_launch"] * 32768 / pj["rows"]) and "from_profiles" in r["traffic_source"]
     pc = json.load(open(os.path.join(ROOT, "profiles", "mfma_power_probe.json")))
-    assert r["power_limited_mfma_only_tflops"]["value"] == pc["split_mix_mfma_only_tflops"]
-    assert abs(r["frac_of_power_limited_ceiling"] - r["achieved"] / pc["split_mix_mfma_only_tflops"]) < 1e-3
+    # the ceilings: the 16x16x32 form's ISSUE ceiling (all-zero operands: power cannot bind) -- what rounds 4-5 mislabelled "power-limited"
+    c = r["mfma_ceilings"]
+    zeros16 = [x["tflops"] for x in pc["cases"] if x["mfma"] == "v_mfma_f32_16x16x32_bf16" and x["operands"] == "zeros"][0]
+    assert c["instruction_form"] == "v_mfma_f32_16x16x32_f16" and c["issue_ceiling_tflops"] == pc.get("issue_ceiling_16x16x32_tflops", zeros16)
+    assert c["sustained_tflops"] == pc["split_mix_mfma_only_tflops"] and c["limit"] == "issue"  # the split mix runs AT the issue ceiling: not power
+    assert "power_limited_mfma_only_tflops" not in r and "frac_of_power_limited_ceiling" not in r
+    assert abs(r["frac_of_issue_ceiling"] - r["achieved"] / c["issue_ceiling_tflops"]) < 1e-3
+    assert abs(r["instruction_form_ceiling"] - c["issue_ceiling_tflops"] / 2500.0) < 1e-3 and 0.75 < r["instruction_form_ceiling"] < 0.82
+    assert abs(r["frac_algorithmic"] - flops / 1.74e-3 / 1e12 / 2500.0) < 1e-4  # algorithmic flops / dense f16 peak (0.18)
+    assert r["traffic_stale"] in (True, False, None) and ("STALE" in r["traffic_source"]) == (r["traffic_stale"] is True)
+    if pj.get("cycles_per_mfma"):  # a round-6 PMC pass: the decomposition of frac
+        assert abs(r["issue_efficiency"] - (16.0 / r["instruction_form_ceiling"]) / pj["cycles_per_mfma"]) < 2e-3
+        assert abs(r["clock_fraction"] - pj["effective_clock_GHz_mean"] / 2.4) < 1e-3
+        assert abs(r["decomposition_product"] - r["instruction_form_ceiling"] * r["issue_efficiency"] * r["clock_fraction"]) < 1e-3
 
 
 def test_tower_roofline_of_the_fused_gomoku_block():
@@ -46,10 +58,28 @@ def test_tower_roofline_of_the_fused_gomoku_block():
     assert r["traffic"] == pj["hbm_bytes_per_launch"] and pj["hbm_bytes_per_launch"] < 0.55 * pj["two_launch_hbm_bytes_per_block"]
 
 
+def test_a_pmc_summary_of_edited_kernel_sources_is_labelled_stale(tmp_path, monkeypatch):
+    import bench
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_digest
+
+    pj, stale = bench.kernel_pmc("split_kernel_pmc.json")
+    assert pj is not None
+    if pj.get("kernel_source_sha256"):
+        assert stale == (pj["kernel_source_sha256"] != kernel_digest.kernel_source_digest("split9"))
+    monkeypatch.setattr(kernel_digest, "kernel_source_digest", lambda fam: "0" * 64)  # "the header was edited"
+    pj2, stale2 = bench.kernel_pmc("split_kernel_pmc.json")
+    assert stale2 is (True if pj2.get("kernel_source_sha256") else None)
+    assert bench.kernel_pmc("no_such_file.json") == (None, None)
+
+
 def test_net_flops_and_power_ceiling_helpers():
     import bench
 
     f = bench.net_flops_per_eval(9, 82, 10, 128, 128, False)
     assert f == 2 * 17 * 128 * 9 * 81 + 10 * 2 * (2 * 128 * 128 * 9 * 81) + 2 * 128 * 3 * 81 + 2 * (2 * 81) * 82 + 2 * 81 * 128 + 2 * 128
-    assert bench.power_ceiling(True)["value"] > 1500 and bench.power_ceiling(False)["value"] > 1500
-    assert "profiles/mfma_power_probe.json" in bench.power_ceiling(True)["source"]
+    cs, cb = bench.mfma_ceilings(True), bench.mfma_ceilings(False)
+    assert cs["issue_ceiling_tflops"] > 1500 and cb["issue_ceiling_tflops"] > 2200 and cb["sustained_tflops"] > 1500
+    assert cb["limit"] == "power" and cs["limit"] == "issue"  # 32x32x16 on dense data is power-limited; 16x16x32 never gets there
+    assert "profiles/mfma_power_probe.json" in cs["source"]

@@ -192,6 +192,60 @@ def test_gpu_two_actors_in_one_process_each_see_only_their_own_range_events():
 
 
 @pytest.mark.gpu
+def test_gpu_no_unmarked_game_from_a_clamp_window():
+    """VERDICT r5 Weak #1: a clamp event is FORCED mid-run (one tower bias of the live evaluator is overwritten with 1e6 for three rounds: the
+    kernels really clamp) and found by the actor's poll.  Every game that ran a round between the last clean poll and the detecting one
+    -- finished in the window or still in progress -- must come out of the harvest marked; games harvested before, and games that
+    started after the repair, must not.  The repair restores the evaluator (bias back from the unscaled copy, no further events)."""
+    from alpha_zero_amd.core.pipeline import SelfPlayActor
+
+    G = 64
+    a = SelfPlayActor(_loud_net(9, 64, 2, gain=1.0, seed=5), game="go", board_size=9, num_games=G, num_simulations=16, num_parallel=4, seed=7, use_graph=True)
+    rows_seen = []
+
+    def take():
+        st, pi, z, games = a.harvest_tensors()
+        rows_seen.extend((int(r[11]) % G, int(r[11]) // G, bool(m)) for r, m in zip(games, a.last_harvest_clamped))
+
+    for _ in range(6):
+        a.run_rounds(10)
+        take()
+    assert a.poll_evaluator_range() == 0 and rows_seen and not any(m for _, _, m in rows_seen)
+    n_clean = len(rows_seen)
+    done0 = a.engine.status()[0][:, 5].copy()            # the last clean poll: games with index < done0[slot] finished before the window
+    front = a.clamp_window.next_unharvested.copy()
+    good_bias = a.infer.b_sp[1].clone()
+    a.infer.b_sp[1].fill_(1.0e6)                          # in place: the captured graph reads it -- the next forwards clamp
+    a.run_rounds(3)
+    done1 = a.engine.status()[0][:, 5].copy()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert a.poll_evaluator_range() > 0               # the detecting poll: repair + the window is remembered
+    assert [m for m in w if "clamped" in str(m.message)] and a.range_rescales == 1 and a.clamp_window.events == 1
+    assert torch.equal(a.infer.b_sp[1], a.infer.b32[1] * 2.0 ** -a.infer.act_shift)  # the poke is gone: biases rebuilt from the unscaled copy
+    assert a.infer.act_shift > 0 or torch.equal(a.infer.b_sp[1], good_bias)
+    for _ in range(60):
+        a.run_rounds(10)
+        take()
+        if (a.clamp_window.hi == -1).all():
+            break
+    a.run_rounds(30)
+    take()
+    assert (a.clamp_window.hi == -1).all() and a.poll_evaluator_range() == a.range_events  # no further event after the repair
+    later = rows_seen[n_clean:]
+    for slot, idx, marked in later:
+        in_window = done0[slot] <= idx <= done1[slot]       # ran a round inside (last clean poll, detecting poll]
+        if in_window:
+            assert marked, (slot, idx)
+        if idx > done1[slot]:
+            assert not marked, (slot, idx)                  # started after the repair
+        if marked:
+            assert front[slot] <= idx <= done1[slot]
+    assert sum(m for _, _, m in later) >= G and any(not m for _, _, m in later)  # all 64 games in progress were suspect; fresh ones are clean
+    assert a.clamped_games == sum(m for _, _, m in later)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S,C", [(9, 128), (9, 64), (17, 64)])
 def test_gpu_split_conv_residual_aliasing_contract(S, C):
     """include/azsp.h: residual may alias y at 9x9 (each position is read before it is written, once) and must not at 17x17, where the
@@ -298,4 +352,34 @@ def test_calibration_pass_on_the_host_twin():
     assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), None, 1, None) == 0 and ev.value == 0
     assert (p.double() - p64).abs().max().item() <= 2e-4 and (v.double() - v64).abs().max().item() <= 2e-4
     far = InferenceNet(_loud_net(9, 64, 1, gain=3e8), dtype=torch.float32, binding=bnd)
-    assert far.split_fallback_reason and "library fp32" in far.evaluator_path(9, "cpu") and far.act_shift == 0
+    # the STEM's folded weights are beyond the format (the tower's own weights are ordinary: a separate reason)
+    assert far.stem_fallback_reason and not far.split_fallback_reason and "library fp32" in far.evaluator_path(9, "cpu") and far.act_shift == 0
+    assert not far.supports_split_features(9, "cuda") and float(far.stem_wsp.abs().max()) == 0.0
+
+
+def test_loud_stem_weights_fall_back_to_the_library_without_raising_on_the_host_twin():
+    """folded stem weights beyond 65504 start the network at a non-zero activation shift; when the calibration pass
+    then gives the fp32-class kernels up it resets the shift to 0 -- which used to re-pack the UNSCALED stem weights and raise ValueError
+    inside run_round / harvest / poll_range.  The fallback must be silent about the stem (nothing reads stem_wsp any more) and the
+    library forward must be the fp32 module's."""
+    import engine_util as eu
+
+    bnd = eu.hosttwin_binding()
+    torch.manual_seed(2)
+    net = AlphaZeroNet((17, 9, 9), 82, 2, 64, 64).eval()
+    with torch.no_grad():
+        net.conv_block[0].weight.mul_(3e6)       # folded stem weights ~ 1e6: initial shift 4; stem outputs ~ 1e7: beyond shift 9
+        net.policy_head[0].weight.div_(3e6)
+        net.value_head[0].weight.div_(3e6)
+    inf = InferenceNet(net, dtype=torch.float32, binding=bnd)
+    assert inf.act_shift >= 3 and not inf.split_fallback_reason and not inf.stem_fallback_reason, (inf.act_shift, inf.stem_fallback_reason)
+    x = (torch.rand(2, 17, 9, 9, generator=torch.Generator().manual_seed(4)) > 0.6).float()
+    shift, worst = inf.calibrate_activation_scale(x)  # raised ValueError before the fix
+    assert inf.split_fallback_reason and shift == 0 and inf.act_shift == 0 and worst > 65504.0, (shift, worst)  # (a lower bound: saturated passes hide the true maximum)
+    assert float(inf.stem_wsp.abs().max()) == 0.0 and "library fp32" in inf.evaluator_path(9, "cpu")
+    inf.set_act_shift(0)  # idempotent, still no ValueError
+    p, v = inf._forward_after_split_fallback(x, None, None, None)
+    with torch.no_grad():
+        lg, vr = net(x)
+    assert (p - torch.softmax(lg, -1)).abs().max().item() <= 1e-4 and (v - vr.squeeze(1)).abs().max().item() <= 1e-4
+    assert bnd.dll.azsp_split_range_status(None, None, 1, None) == 0

@@ -407,6 +407,47 @@ def test_gpu_split_gomoku_stem_and_heads_vs_fp64(boards):
     assert dp <= 2e-6 and dv <= 4e-6, (boards, dp, dv)
 
 
+def _check_pre_relu_record(bnd, device, S, C):
+    """The convolution epilogues record |v| IN FRONT of the ReLU (include/azsp.h, RANGE: deliberately conservative): a strongly negative
+    bias drives one channel's pre-activation below -65504; the ReLU zeroes the output, and the event is still counted with its
+    magnitude -- by the kernels and by the host twin alike (they disagreed)."""
+    import ctypes
+
+    dll = bnd.dll
+    ev, mx = ctypes.c_uint32(0), ctypes.c_float(0.0)
+    assert dll.azsp_split_range_status(None, None, 1, None) == 0
+    x, r, w, b = _inputs(3, C, S, 21)
+    b = b.clone()
+    b[5] = -1.0e5
+    y, _ = _run_split_conv(bnd, x, None, w, b, 1, device)
+    assert dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 1, None) == 0
+    ref = _ref64(x, None, w, b, 0)  # pre-activations
+    assert ev.value >= 1 and abs(mx.value - ref[:, 5].abs().max().item()) <= 1e-2 * 1e5 and mx.value > 65504.0, (ev.value, mx.value)
+    assert float(y[:, 5].abs().max()) == 0.0 and torch.isfinite(y).all()
+    others = [c for c in range(C) if c != 5]
+    err = (y[:, others].double() - torch.relu(ref[:, others])).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, err
+    # without the ReLU the same value is clamped to -65504 and recorded once more
+    y0, _ = _run_split_conv(bnd, x, None, w, b, 0, device)
+    assert dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 1, None) == 0
+    assert ev.value >= 1 and float(y0[:, 5].min()) == -65504.0
+
+
+@pytest.mark.parametrize("S,C", [(9, 64), (17, 64)])
+def test_split_range_record_is_taken_in_front_of_the_relu_host_twin(S, C):
+    import engine_util as eu
+
+    _check_pre_relu_record(eu.hosttwin_binding(), "cpu", S, C)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C", [(9, 128), (9, 64), (17, 64)])
+def test_gpu_split_range_record_is_taken_in_front_of_the_relu(S, C):
+    from alpha_zero_amd import _lib
+
+    _check_pre_relu_record(_lib.load(), "cuda", S, C)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("S,C", [(9, 128), (9, 64), (17, 64)])
 def test_gpu_split_range_record_trips_and_resets(S, C):

@@ -1,0 +1,83 @@
+"""Turn the text a tools/profile_r06.sh PMC run wrote for one kernel family (sections `== kernel-trace`, `== <counters>` with per-kernel
+means) into the summary bench.py reads from profiles/: HBM bytes per launch (FETCH_SIZE x 2: gfx950 tallies a 128-B request as 64 B,
+profiles/r01_pmc_calibration.txt; WRITE_SIZE x 1), matrix-pipe busy, cycles per MFMA, effective clock, wave-cycle breakdown -- and the
+digest of the kernel sources the pass ran on (tools/kernel_digest.py), so that a later edit of the kernel makes the figures show as stale.
+usage: python tools/pmc_to_json.py <family> <pmc_txt> <out_json> [rows]"""
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_digest import kernel_source_digest  # noqa: E402
+
+GEOM = {"split9": (9, 9, 128, 4, 2.5), "split9_64": (9, 9, 64, 4, 2.5), "splitblock9_64": (9, 9, 64, 4, 2.0), "split17": (13, 17, 64, 4, 2.5),
+        "splitblock17": (13, 17, 64, 4, 2.0), "tiled9": (9, 9, 128, 2, 2.5), "hb19": (19, 19, 256, 2, 2.5)}  # board, planes, channels, bytes/elem, passes
+
+
+def parse(txt):
+    sec, out, trace = None, {}, []
+    for ln in txt.splitlines():
+        if ln.startswith("== "):
+            sec = ln[3:].strip()
+            continue
+        if sec == "kernel-trace":
+            m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\S+)", ln)
+            if m:
+                trace.append({"calls": int(m.group(1)), "avg_us": float(m.group(3)), "name": m.group(5)})
+                continue
+        m = re.match(r"\s+(\S+)\s+(\S+)\s+n=(\d+)\s+mean=([\d.e+-]+)", ln)
+        if m:
+            out.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
+    return trace, out
+
+
+def main():
+    fam, src, dst = sys.argv[1], sys.argv[2], sys.argv[3]
+    rows = int(sys.argv[4]) if len(sys.argv) > 4 else (4096 if fam == "hb19" else 32768)
+    board, planes, ch, elem, passes = GEOM[fam]
+    trace, ctr = parse(open(src).read())
+    kernels = {}
+    for kname, c in ctr.items():
+        t = [r for r in trace if r["name"].startswith(kname[:60])]
+        us = t[0]["avg_us"] if t else None
+        k = {"launch_us_in_the_trace_pass": us}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            k["FETCH_SIZE_KiB"], k["WRITE_SIZE_KiB"] = c["FETCH_SIZE"], c["WRITE_SIZE"]
+            k["hbm_bytes_per_launch"] = round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        if "SQ_INSTS_MFMA" in c and "GRBM_GUI_ACTIVE" in c:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
+            k["SQ_INSTS_MFMA"], k["gpu_cycles_per_launch"] = c["SQ_INSTS_MFMA"], cyc
+            k["cycles_per_mfma"] = round(cyc / (c["SQ_INSTS_MFMA"] / 1024.0), 3)  # 1024 SIMDs, one wave each
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                k["mfma_busy_fraction"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+            if us:
+                k["effective_clock_GHz"] = round(cyc / (us * 1e3), 4)
+        for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+            if n in c:
+                k[n] = c[n]
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
+            k["lds_bank_conflict_fraction"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+        kernels[kname] = k
+    js = json.load(open(dst)) if os.path.exists(dst) else {}
+    hb = [k["hbm_bytes_per_launch"] for k in kernels.values() if "hbm_bytes_per_launch" in k]
+    alg = rows * planes * planes * ch * elem * passes
+    js.update({"rows": rows, "board": board, "planes": planes, "channels": ch, "family": fam,
+               "kernel_source_sha256": kernel_source_digest(fam), "measured_in_round": 6, "per_kernel": kernels})
+    if hb:
+        per_call = sum(hb) if fam == "hb19" and len(hb) > 1 and "one_pass" not in js.get("scheme", "") else sum(hb) / len(hb)
+        js["hbm_bytes_per_launch"] = round(per_call)
+        js["algorithmic_bytes_mean_layer"] = round(alg)
+        js["ratio_to_algorithmic"] = round(per_call / alg, 4)
+    cm = [k["cycles_per_mfma"] for k in kernels.values() if "cycles_per_mfma" in k]
+    if cm:
+        js["cycles_per_mfma"] = round(sum(cm) / len(cm), 3)
+        js["effective_clock_GHz_mean"] = round(sum(k["effective_clock_GHz"] for k in kernels.values() if "effective_clock_GHz" in k) / max(1, len(cm)), 4)
+        js["mfma_busy_fraction_mean"] = round(sum(k.get("mfma_busy_fraction", 0) for k in kernels.values()) / len(cm), 4)
+    js["source_round6"] = ["profiles/" + os.path.basename(src), "profiles/r01_pmc_calibration.txt (FETCH_SIZE x 2)"]
+    json.dump(js, open(dst, "w"), indent=1)
+    print(json.dumps({k: js[k] for k in ("family", "hbm_bytes_per_launch", "ratio_to_algorithmic", "cycles_per_mfma", "effective_clock_GHz_mean", "kernel_source_sha256") if k in js}))
+
+
+if __name__ == "__main__":
+    main()
