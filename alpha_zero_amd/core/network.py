@@ -217,9 +217,13 @@ class InferenceNet(nn.Module):
                     while wmax * 2.0 ** -k0 > F16_MAX and k0 <= self.MAX_ACT_SHIFT:
                         k0 += 1
                     if k0 > self.MAX_ACT_SHIFT:
-                        # the split STEM cannot carry these weights; the tower's own weights are a separate matter (the library stem in
-                        # front of the split tower never sees stem_wsp): _split_tower_ok is gated on split_fallback_reason only
+                        # The split STEM cannot carry these weights (recorded separately: stem_fallback_reason).  The tower is given up WITH
+                        # it although its own weights may be ordinary (ADVICE r5 asked to keep it): folded stem weights beyond
+                        # 65504 * 2^MAX_ACT_SHIFT = 3.4e7 on 0 / 1 input planes mean stem outputs of that size, which the tower's f16 pairs
+                        # cannot carry at any allowed scale -- and the tower-only path has no calibration pass that would find out before
+                        # it clamps (test_gpu_network_beyond_the_format_falls_back_to_library_fp32 is exactly this network).
                         self.stem_fallback_reason = f"folded stem weights reach {wmax:.3g}: beyond the f16-pair format"
+                        self.split_fallback_reason = self.split_fallback_reason or self.stem_fallback_reason
                         k0 = 0
                     self.stem_wsp = nn.Parameter(split_weights_f16(sw32 * 2.0 ** -k0) if not (self.split_fallback_reason or self.stem_fallback_reason)
                                                  else torch.zeros(2, 9, sw.shape[0], 32, dtype=torch.float16), requires_grad=False)

@@ -346,4 +346,387 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
         for (int o = 0; o < SC::NQ * SC::OPS; ++o) epi_op((NU - 1) & 1, NU - 1, yprev, o / SC::OPS, o % SC::OPS, true);
     }
 }
+// =====================================================================================================================================
+// k_conv3x3_op19<ADD> (round 6) -- the SAME convolution in ONE launch: y = act(conv3x3(x, w) + bias [+ residual]), all 256 input
+// channels contracted inside one CU, fp32 accumulation end to end (no bf16 partial sum through HBM, one rounding per output).
+//   * a CU owns 64 couts x 256 cin of one board half: wave (a, b) holds couts [32 a, 32 a + 32) x cin half b -- the per-wave shape of
+//     k_conv3x3_hb19 (288 weight registers, 72 v_mfma_f32_32x32x16 per column tile).  The two cin halves of a cout group meet through
+//     LDS: after a unit (= column tile) each wave hands the accumulator quads its PARTNER finalises (8 registers per lane) to the
+//     partner and runs the epilogue (bias is in wave b = 0's accumulators; residual, rounding, ReLU, store) of its own two quads.
+//     The weight rows of wave b = 1 are rotated by 16 couts so that "own quads" are registers 0-7 in both waves (compile-time indices).
+//   * the tile image holds all 32 input chunks of the half board: 123,904 B -- ONE buffer.  It is refilled on the fly: the column
+//     tiles take the half's positions in row-major order, so unit u only reads image cells [~34 u, ~34 u + 76); the strip of a chunk
+//     is four DMA BANDS of 64 cells, band 0 is dead after unit 1, band 1 after unit 3, bands 2-3 after unit 5 (compile-time checked
+//     against the lane maps), and the next tile's band is DMA'd into the same cells as soon as a workgroup barrier has certified that
+//     every wave is past its last reader.  One barrier per unit does triple duty: partial-sum exchange, "band free", "band landed"
+//     (behind counted s_waitcnt vmcnt):
+//         unit 0: B0 -> DMA band 2 of THIS tile      unit 1: B1 [band 2 landed] -> DMA band 3 of this tile
+//         unit 2: B2 -> DMA band 0 of the NEXT tile   unit 3: B3 [band 3 landed]
+//         unit 4: B4 -> DMA band 1 of the next tile   unit 5: B5 [bands 0, 1 of the next tile landed]
+//     Every band has >= 56 MFMA slots (~1.8 k matrix-pipe cycles at full rate, more at the real clock) between its last piece and
+//     the barrier that needs it.
+//   * HBM traffic: x once (the four cout groups of a tile stream run on one XCD: one HBM read, three L2 hits), residual once, y once
+//     = 2 / 3 tensor passes per convolution instead of 4 / 5; bytes arriving in CUs: 4 cout groups x 1.2 (halo rows) = 4.8 passes
+//     (two launches: 2.4).
+#define C1_NCH 32
+#define C1_IMG (C1_NCH * C9_LBLK)          // 123,904 B
+#define C1_XB_WAVE 2048                    // exchange: 2 quads x 64 lanes x 16 B per wave
+#define C1_XB (2 * 4 * C1_XB_WAVE)         // [unit parity][wave]
+#define C1_NBAND 4
+
+struct C1Map {
+    unsigned short cell[C9_NCT * 32], pos[C9_NCT * 32];  // pos: tile-relative (row * 19 + col), 0xffff = computed, never stored
+    short rmin[C9_NCT], rmax[C9_NCT];                    // first / last image cell the real positions of a column tile read (taps included)
+    bool ok;
+};
+constexpr C1Map c1_make_map(int hf) {
+    C1Map m{};
+    const int lanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int own[C9_NCT * 32] = {}, n = 0;
+    for (int p = 0; p < C9_NPOS; ++p)
+        if (c9_in_map(hf, p)) own[n++] = p;  // the half's own positions, row-major
+    bool ok = n > (C9_NCT - 1) * 32 && n <= C9_NCT * 32;
+    for (int i = 0; i < C9_NCT * 32; ++i) {
+        m.cell[i] = 0;
+        m.pos[i] = 0xffff;
+    }
+    for (int ct = 0; ct < C9_NCT; ++ct) {
+        const int lo = ct * 32, hi = n < lo + 32 ? n : lo + 32;
+        bool used[2][16] = {};
+        int fill[2] = {0, 0}, cmin = 1 << 20, cmax = -1;
+        bool placed[32] = {};
+        for (int pass = 0; pass < 2; ++pass)  // pass 0: into a service group that lacks the cell's residue (conflict-free); pass 1: the rest
+            for (int i = lo; i < hi; ++i) {
+                if (placed[i - lo]) continue;
+                const int p = own[i], cell = C9_CELL0 + C9_PITCH * (p / C9_S) + p % C9_S, r = cell & 15;
+                int g = -1;
+                if (!used[0][r] && fill[0] < 16) g = 0;
+                else if (!used[1][r] && fill[1] < 16) g = 1;
+                else if (pass == 1) g = fill[0] < 16 ? 0 : 1;
+                if (g < 0) continue;
+                const int idx = ct * 32 + lanes[g][fill[g]++];
+                m.cell[idx] = (unsigned short)cell;
+                m.pos[idx] = (unsigned short)p;
+                used[g][r] = true;
+                placed[i - lo] = true;
+                cmin = cell < cmin ? cell : cmin;
+                cmax = cell > cmax ? cell : cmax;
+            }
+        for (int g = 0; g < 2; ++g)  // padding slots: a cell of this column tile's own span (same bands), of a residue the group lacks if there is one
+            while (fill[g] < 16) {
+                int pick = cmin;
+                for (int c = cmin; c <= cmax; ++c)
+                    if (!used[g][c & 15] && (c - 1) % C9_PITCH != C9_S) {  // (not the zero cell between two rows)
+                        pick = c;
+                        break;
+                    }
+                m.cell[ct * 32 + lanes[g][fill[g]++]] = (unsigned short)pick;
+                used[g][pick & 15] = true;
+            }
+        m.rmin[ct] = (short)(cmin - C9_CELL0);
+        m.rmax[ct] = (short)(cmax + C9_CELL0);
+    }
+    m.ok = ok;
+    return m;
+}
+constexpr bool c1_maps_cover_the_board() {
+    const C1Map m0 = c1_make_map(0), m1 = c1_make_map(1);
+    int seen[C9_P2] = {};
+    for (int i = 0; i < C9_NCT * 32; ++i) {
+        if (m0.pos[i] != 0xffff) seen[m0.pos[i]]++;
+        if (m1.pos[i] != 0xffff) seen[m1.pos[i] + 9 * C9_S]++;
+    }
+    for (int p = 0; p < C9_P2; ++p)
+        if (seen[p] != 1) return false;
+    return true;
+}
+// the refill schedule of the single-buffered image: band 0 (cells 0-63) is read by units 0-1 only, band 1 (64-127) by units 0-3, band 2
+// (128-191) by units 2-5, band 3 (192-241) by units 4-5
+constexpr bool c1_band_schedule_ok(int hf) {
+    const C1Map m = c1_make_map(hf);
+    return m.ok && m.rmin[0] >= 0 && m.rmax[C9_NCT - 1] < C9_CELLS && m.rmin[2] >= 64 && m.rmin[4] >= 128 && m.rmax[1] <= 127 && m.rmax[3] <= 191;
+}
+static_assert(c1_band_schedule_ok(0) && c1_band_schedule_ok(1), "19x19 one-pass kernel: the DMA band schedule does not match the column-tile maps");
+static_assert(c1_maps_cover_the_board(), "19x19 one-pass maps: every position stored exactly once");
+static __device__ const C1Map c1_maps[2] = {c1_make_map(0), c1_make_map(1)};
+
+template <bool ADD> struct C1Sched {  // static schedule of one unit = one column tile = 72 k-steps per wave (its cin half)
+    static constexpr int KS = 8, NSTEP = 72, NU = C9_NCT, R = 4;
+    static constexpr int S0 = 5;            // first slot that may touch the previous unit's accumulators: the hand-over writes ride in S0, S0 + 1
+    static constexpr int SB = 8;            // the unit's barrier sits in front of slot SB
+    static constexpr int OPS = ADD ? 9 : 5;  // epilogue micro-ops per register quad
+    // rider stream behind the barrier, one micro-op per slot from SB + 1: 2 reads of the partner's quads, then per own quad 4 adds + OPS epilogue ops
+    static constexpr int NRID = 2 + 2 * (4 + OPS);
+    static constexpr int store_slot(int q) { return SB + 1 + 2 + (q + 1) * (4 + OPS) - 1; }
+    static constexpr int NPIECE = 8;        // DMA pieces per wave per band: its 8 chunks
+    static constexpr int dma_slot(int i) { return SB + 2 + 2 * i; }
+    static constexpr bool dma_unit(int u) { return u == 0 || u == 1 || u == 2 || u == 4; }
+    // Vector-memory operations of a wave, in program order, are the same in every unit of every tile (stores, addend loads and DMA pieces
+    // are issued under masks, never skipped), and ALL of them are inline assembly: the compiler inserts no vmcnt wait of its own inside
+    // the tile loop (a compiler-issued addend load would make it wait on "everything but its own younger loads", i.e. on the DMA pieces
+    // issued a few slots earlier: a full memory latency per unit).  In slot t of unit u: first the riders (the store of the previous
+    // unit's quad q and, behind it, this unit's addend load of quad q, both in slot store_slot(q)), then the DMA piece.
+    static constexpr int rider_vm(int t) {
+        int n = 0;
+        for (int q = 0; q < 2; ++q)
+            if (t == store_slot(q)) n += ADD ? 2 : 1;
+        return n;
+    }
+    static constexpr bool dma_at(int u, int t) {
+        for (int i = 0; i < NPIECE; ++i)
+            if (dma_unit(u) && t == dma_slot(i)) return true;
+        return false;
+    }
+    static constexpr int vm_ops(int u, int t) { return rider_vm(t) + (dma_at(u, t) ? 1 : 0); }
+    // ... issued after the last DMA piece of unit ui and before the barrier of unit uw (ui < uw, same tile)
+    static constexpr int vm_between(int ui, int uw) {
+        int n = 0;
+        for (int t = dma_slot(NPIECE - 1) + 1; t < NSTEP; ++t) n += vm_ops(ui, t);
+        for (int u = ui + 1; u < uw; ++u)
+            for (int t = 0; t < NSTEP; ++t) n += vm_ops(u, t);
+        for (int t = 0; t < SB; ++t) n += vm_ops(uw, t);
+        return n;
+    }
+    // first rider slot that reads the addend of own quad q (loaded in the previous unit's slot store_slot(q)), and the number of
+    // vector-memory operations issued between that load and the start of this slot in unit u
+    static constexpr int addend_use_slot(int q) { return SB + 1 + 2 + q * (4 + OPS) + 4; }
+    static constexpr int vm_after_addend(int u, int q) {
+        const int pu = (u + NU - 1) % NU;
+        int n = dma_at(pu, store_slot(q)) ? 1 : 0;  // (the DMA piece of the load's own slot comes after it)
+        for (int t = store_slot(q) + 1; t < NSTEP; ++t) n += vm_ops(pu, t);
+        for (int t = 0; t < addend_use_slot(q); ++t) n += vm_ops(u, t);
+        return n;
+    }
+    static_assert(SB + 1 + NRID < NSTEP - 3, "the previous unit's epilogue must be done before its accumulator set is re-initialised");
+    static_assert(dma_slot(NPIECE - 1) < NSTEP - 4 && S0 + 1 < SB, "slot layout");
+    static_assert((NU * NSTEP) % R == 0, "a tile's k-steps keep the ring phase");
+    static_assert(vm_between(0, 1) < 63 && vm_between(1, 3) < 63 && vm_between(4, 5) < 63, "vmcnt field");
+    static_assert(vm_after_addend(0, 0) < 63 && vm_after_addend(1, 1) < 63 && vm_after_addend(2, 1) < 63 && vm_after_addend(3, 1) < 63, "vmcnt field");
+    static_assert(addend_use_slot(0) < store_slot(0) && addend_use_slot(1) > store_slot(0) && addend_use_slot(1) < store_slot(1), "an addend register is re-loaded after its last use");
+};
+
+template <bool ADD> __global__ void __launch_bounds__(CW_THREADS, 1)
+k_conv3x3_op19(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias, const unsigned char* add,
+               unsigned char* y, int nboards, int relu) {
+    typedef C1Sched<ADD> SC;
+    constexpr int KS = SC::KS, NSTEP = SC::NSTEP, R = SC::R, NU = SC::NU, SB = SC::SB;
+    constexpr int OTILE = 32 * C9_GBLK;   // one board of x / y / addend: 32 chunks
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[C1_IMG + C1_XB];
+    __shared__ __attribute__((aligned(64))) float bias_lds[4 * 2 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave >> 1, wb = wave & 1;  // cout half of the CU's 64 couts, cin half
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    for (int i = tid; i < (C1_IMG + C1_XB) / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();  // the zero cells are in place before any wave's DMA lands
+
+    // this CU's role: tile stream s, cout group cg (64 couts), board half hf.  With a full grid the eight roles of a stream share an XCD
+    // (block b runs on XCD b % 8): the second to fourth cout group find the input tile in that XCD's L2.
+    const int bi = (int)blockIdx.x, nst = (int)gridDim.x >> 3;
+    int s, role;
+    if ((gridDim.x & 63u) == 0u) {
+        s = (bi & 7) + 8 * (bi >> 6);
+        role = (bi >> 3) & 7;
+    } else {
+        s = bi >> 3;
+        role = bi & 7;
+    }
+    const int cg = role >> 1, hf = role & 1, r0 = hf * 9;
+
+    cv_bf16x8 wf[NSTEP];  // this wave's 32 couts x (9 taps x 128 cin of its half); row m of the A operand = cout 32 a + ((m + 16 b) & 31)
+    const int crow = cg * 64 + wa * 32 + ((l31 + 16 * wb) & 31);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t)
+        wf[t] = *(const cv_bf16x8*)(w + ((size_t)((t / KS) * 256 + crow)) * 256 + wb * 128 + ((t % KS) * 2 + hi) * 8);
+    // bias in the accumulator layout ([wave][lane half][16 floats]); it enters through wave b = 0's accumulators only
+    if (lane < 32) bias_lds[(wave * 2 + (lane >> 4)) * 16 + (lane & 15)] = wb == 0 ? bias[cg * 64 + wa * 32 + 8 * ((lane & 15) >> 2) + 4 * (lane >> 4) + (lane & 3)] : 0.0f;
+    const cv_f32x16* bias_ptr = (const cv_f32x16*)(bias_lds + (wave * 2 + hi) * 16);
+    const unsigned lo16 = relu ? 0u : 0x80008000u;
+
+    // LDS-DMA: band j = cells [64 j, 64 j + 64) of a chunk strip, lane -> cell 64 j + lane; wave w moves chunks c = w + 4 i
+    unsigned dsrc[C1_NBAND];
+    unsigned long long dmask[C1_NBAND];
+#pragma unroll
+    for (int j = 0; j < C1_NBAND; ++j) {
+        const int dcell = j * 64 + lane, dk = dcell - 1, drs = dk / C9_PITCH, dxx = dk - drs * C9_PITCH, drow = r0 - 1 + drs;
+        const bool dok = dcell >= 1 && dcell < C9_CELLS - 1 && dxx < C9_S && drow >= 0 && drow < C9_S;
+        dsrc[j] = dok ? (unsigned)((drow * C9_S + dxx) * 16) : 0u;
+        dmask[j] = __builtin_amdgcn_ballot_w64(dok);
+    }
+    auto dma_piece = [&](const unsigned char* src, bool live, int j, int i) {
+        const int c = wave + 4 * i;
+        const unsigned long long base = (unsigned long long)(src + (size_t)c * C9_GBLK);
+        const unsigned long long mask = live ? dmask[j] : 0ull;
+        const unsigned dst = lds0 + (unsigned)(c * C9_LBLK + j * 1024);
+        asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                     :
+                     : "s"(mask), "s"(dst), "v"(dsrc[j]), "s"(base)
+                     : "memory");
+    };
+
+    // this lane's 6 output positions: LDS byte offset of the (-1, -1) neighbour of its cell in the first chunk of its k-half (low 16 bits),
+    // board position (high 16 bits; 0xffff = a padding slot: computed, never stored)
+    unsigned lmap[C9_NCT];
+#pragma unroll
+    for (int ct = 0; ct < C9_NCT; ++ct) {
+        const unsigned tp = c1_maps[hf].pos[ct * 32 + l31];
+        const unsigned gp = tp != 0xffffu ? tp + (unsigned)(r0 * C9_S) : 0xffffu;
+        lmap[ct] = (unsigned)((c1_maps[hf].cell[ct * 32 + l31] - C9_CELL0) * 16 + hi * C9_LBLK) | (gp << 16);
+    }
+    unsigned long long smask[C9_NCT];
+#pragma unroll
+    for (int ct = 0; ct < C9_NCT; ++ct) smask[ct] = __builtin_amdgcn_ballot_w64((lmap[ct] >> 16) != 0xffffu);
+    auto store8 = [&](unsigned char* base, unsigned voff, unsigned a, unsigned b2, unsigned long long mask) {
+        const cv_u32x2 d = (cv_u32x2){a, b2};
+        asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" : : "s"(mask), "v"(voff), "v"(d), "s"(base) : "memory");
+    };
+
+    const unsigned char* Xw = lds + wb * (16 * C9_LBLK);  // this wave's cin half of the image
+    cv_bf16x8 bb[R];
+    auto load_step = [&](const unsigned char* p0, int st, int slot) {
+        const int tap = st / KS, ks = st % KS;
+        bb[slot] = *(const cv_bf16x8*)(p0 + ((tap / 3) * C9_PITCH + (tap % 3)) * 16 + ks * (2 * C9_LBLK));
+    };
+    // hand-over buffers: [unit parity][wave][quad j][lane] 16 B
+    unsigned char* const xb_mine = lds + C1_IMG + wave * C1_XB_WAVE + lane * 16;
+    const unsigned char* const xb_partner = lds + C1_IMG + (wave ^ 1) * C1_XB_WAVE + lane * 16;
+
+    if (s < nboards) {  // first tile: the whole image at once
+        const unsigned char* src = x + (size_t)s * OTILE;
+#pragma unroll
+        for (int j = 0; j < C1_NBAND; ++j)
+#pragma unroll
+            for (int i = 0; i < SC::NPIECE; ++i) dma_piece(src, true, j, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CV_BARRIER();
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st) load_step(Xw + (lmap[0] & 0xffffu), st, st);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {  // the compiler's wait for the weight loads belongs in front of the loop (see az_conv.h)
+        if (t < 64) asm volatile("" : : "a"(wf[t]));
+        else asm volatile("" : : "v"(wf[t]));
+    }
+
+    cv_f32x16 acc[2];     // [accumulator set = unit parity]
+    cv_u32x2 rr[2];       // addend of the unit whose epilogue comes next: [own quad]
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    f32x4 xr[2];          // the partner's partial sums of my two quads
+    acc[0] = *bias_ptr;   // (bias_lds was published by the barrier above)
+    acc[1] = *bias_ptr;
+    rr[0] = rr[1] = (cv_u32x2){0u, 0u};
+    xr[0] = xr[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float ev[4];
+    unsigned epa = 0, epb = 0;
+    // hand the partner's quads (registers 8-15 of set `set`) over: one ds_write_b128 per quad
+    auto xwrite = [&](int set, int j) {
+        *(f32x4*)(xb_mine + (set * 4 * C1_XB_WAVE) + j * 1024) = (f32x4){acc[set][8 + 4 * j], acc[set][9 + 4 * j], acc[set][10 + 4 * j], acc[set][11 + 4 * j]};
+    };
+    auto xread = [&](int set, int j) { xr[j] = *(const f32x4*)(xb_partner + (set * 4 * C1_XB_WAVE) + j * 1024); };
+    // micro-op `o` of the rider stream that finishes the unit which accumulated into `set` (column tile ct)
+    auto rider = [&](int set, int ct, unsigned char* out, int o, bool store_ok) {
+        if (o < 2) {
+            xread(set, o);
+            return;
+        }
+        const int q = (o - 2) / (4 + SC::OPS), k = (o - 2) % (4 + SC::OPS);
+        if (k < 4) {
+            acc[set][q * 4 + k] = cw_add_f32(acc[set][q * 4 + k], xr[q][k]);
+            return;
+        }
+        const int op = k - 4;
+        if (ADD) {
+            if (op == 0) ev[0] = cw_add_f32(acc[set][q * 4 + 0], cv_bf16_lo(rr[q].x));
+            else if (op == 1) ev[1] = cw_add_f32(acc[set][q * 4 + 1], cv_bf16_hi(rr[q].x));
+            else if (op == 2) ev[2] = cw_add_f32(acc[set][q * 4 + 2], cv_bf16_lo(rr[q].y));
+            else if (op == 3) ev[3] = cw_add_f32(acc[set][q * 4 + 3], cv_bf16_hi(rr[q].y));
+            else if (op == 4) epa = cw_pk_bf16(ev[0], ev[1]);
+            else if (op == 5) epb = cw_pk_bf16(ev[2], ev[3]);
+        } else {
+            if (op == 0) epa = cw_pk_bf16(acc[set][q * 4 + 0], acc[set][q * 4 + 1]);
+            else if (op == 1) epb = cw_pk_bf16(acc[set][q * 4 + 2], acc[set][q * 4 + 3]);
+        }
+        if (op == SC::OPS - 3) epa = cw_pk_max_i16(epa, lo16);
+        else if (op == SC::OPS - 2) epb = cw_pk_max_i16(epb, lo16);
+        else if (op == SC::OPS - 1) {
+            unsigned lm = lmap[ct];
+            asm volatile("" : "+v"(lm));  // recompute the offset here instead of hoisting 12 of them out of the loop
+            store8(out, (unsigned)(q * C9_GBLK) + (lm >> 16) * 16u + (unsigned)(hi * 8), epa, epb, store_ok ? smask[ct] : 0ull);
+        }
+    };
+
+    int it = 0;
+    unsigned char* yprev = y;
+    for (int board = s; board < nboards; board += nst, ++it) {
+        const bool has_next = board + nst < nboards, have_prev = it > 0;  // (the first tile issues the same operations, masked off)
+        const unsigned char* csrc = x + (size_t)board * OTILE;                                   // bands 2, 3 of THIS tile (units 0, 1)
+        const unsigned char* nsrc = x + (size_t)(has_next ? board + nst : board) * OTILE;        // bands 0, 1 of the NEXT tile (units 2, 4)
+        const size_t obase = (size_t)board * OTILE + (size_t)(cg * 8 + wa * 4 + wb * 2) * C9_GBLK;  // my two quads = chunks 2 b, 2 b + 1 of the wave pair's four
+        const unsigned char* abase = ADD ? add + obase : nullptr;
+        unsigned char* ybase = y + obase;
+        cp_for_each([&](auto UC) __attribute__((always_inline)) {
+            constexpr int u = decltype(UC)::value, set = u & 1, pset = set ^ 1;
+            constexpr int pct = (u + NU - 1) % NU;  // the previous unit's column tile
+            unsigned char* pout = u == 0 ? yprev : ybase;
+            const bool pstore = u > 0 || have_prev;
+            const unsigned char* b0 = Xw + (lmap[u] & 0xffffu);
+            const unsigned char* nb0 = Xw + (lmap[(u + 1) % NU] & 0xffffu);
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::value;
+                if constexpr (t == SB) {
+                    // B_u: every wave has handed over the previous unit's partial sums, has finished the reads of the unit before, and
+                    // (units 1, 3, 5) its DMA pieces of the band the next reads need are older than the N youngest vector-memory operations
+                    if constexpr (u == 1 || u == 3 || u == 5) {
+                        constexpr int N = u == 1 ? SC::vm_between(0, 1) : u == 3 ? SC::vm_between(1, 3) : SC::vm_between(4, 5);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+                    }
+                    CV_BARRIER();
+                }
+                if constexpr (t + R - 1 < NSTEP) load_step(b0, t + R - 1, (u * NSTEP + t + R - 1) % R);
+                else load_step(nb0, t + R - 1 - NSTEP, (u * NSTEP + t + R - 1) % R);
+                if constexpr (t < 64) cw_mfma_a(acc[set], wf[t], bb[(u * NSTEP + t) % R]);
+                else cw_mfma_v(acc[set], wf[t], bb[(u * NSTEP + t) % R]);
+                // ---- riders of this MFMA gap -----------------------------------------------------------------------------------
+                if constexpr (t == SC::S0 || t == SC::S0 + 1) xwrite(pset, t - SC::S0);
+                if constexpr (ADD) {  // the previous unit's addend of quad q has landed: all but the N youngest vector-memory operations are done
+                    if constexpr (t == SC::addend_use_slot(0)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr[0]) : "n"(SC::vm_after_addend(u, 0)));
+                    if constexpr (t == SC::addend_use_slot(1)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr[1]) : "n"(SC::vm_after_addend(u, 1)));
+                }
+                if constexpr (t > SB && t - SB - 1 < SC::NRID) rider(pset, pct, pout, t - SB - 1, pstore);
+                if constexpr (ADD) {  // this unit's addend of own quad q, right behind the store of the previous unit's quad q
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (t == SC::store_slot(q)) {
+                            unsigned lm = lmap[u];
+                            asm volatile("" : "+v"(lm));
+                            const unsigned gp = lm >> 16;
+                            const unsigned voff = (unsigned)(q * C9_GBLK) + (gp == 0xffffu ? 0u : gp) * 16u + (unsigned)(hi * 8);
+                            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rr[q]) : "v"(voff), "s"(abase) : "memory");
+                        }
+                }
+                if constexpr (SC::dma_unit(u) && t >= SC::dma_slot(0) && t <= SC::dma_slot(SC::NPIECE - 1) && (t - SC::dma_slot(0)) % 2 == 0) {
+                    constexpr int i = (t - SC::dma_slot(0)) / 2;
+                    if constexpr (u == 0) dma_piece(csrc, have_prev, 2, i);
+                    else if constexpr (u == 1) dma_piece(csrc, have_prev, 3, i);
+                    else if constexpr (u == 2) dma_piece(nsrc, has_next, 0, i);
+                    else dma_piece(nsrc, has_next, 1, i);
+                }
+                if constexpr (t == NSTEP - 2) acc[pset] = *bias_ptr;  // the next unit's accumulators start from the bias (wave b = 1: zero)
+                __builtin_amdgcn_sched_barrier(0);
+            }, typename CpMakeSeq<NSTEP>::type{});
+        }, typename CpMakeSeq<NU>::type{});
+        yprev = ybase;
+    }
+    // the very last unit (column tile NU - 1, accumulator set (NU - 1) & 1): hand over, meet, finish
+    if (it > 0) {
+        constexpr int lset = (NU - 1) & 1;
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+        xwrite(lset, 0);
+        xwrite(lset, 1);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]));  // the last unit's addends
+        CV_BARRIER();
+#pragma unroll
+        for (int o = 0; o < SC::NRID; ++o) rider(lset, NU - 1, yprev, o, true);
+    }
+}
 #endif  // __HIPCC__

@@ -98,8 +98,6 @@ void* host_alloc(size_t n) {
     return AZ_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)) ? nullptr : p;
 }
 void host_release(void* p) { (void)hipHostFree(p); }
-int h2d_async(void* d, const void* s, size_t n, void* st) { return AZ_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); }
-int d2h_async(void* d, const void* s, size_t n, void* st) { return AZ_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); }
 int set_device(int dev) {
     int n = 0;
     if (AZ_HIP(hipGetDeviceCount(&n)) || n < 1) return -1;
@@ -164,10 +162,26 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
 #undef AZ_T64
         return AZ_HIP(hipGetLastError());
     }
-    if (S == C9_S && C == 256) {  // 19x19 boards, 256 filters (jumbo Go network): two launches, one per 128-channel half of the input
+    if (S == C9_S && C == 256) {  // 19x19 boards, 256 filters (jumbo Go network)
         const int n_cu = cu_count();
         if (n_cu < 0) return -1;
-        if (x == y || res == y) return 1;  // y holds the partial sum between the launches
+        if (x == y || res == y) return 1;  // other CUs read x's halo rows while y is written; the contract keeps the residual apart too
+        static const bool two_launch = getenv("AZSP_CONV19_TWO_LAUNCH") != nullptr;  // A/B switch for measurements: round 2-5's two-launch scheme
+        if (!two_launch) {
+            // ONE launch (round 6, k_conv3x3_op19): a CU = 64 couts x all 256 cin of a half board, cin halves meet through LDS, fp32 end to end;
+            // stripes of 8 workgroups (4 cout groups x 2 board halves) per tile stream
+            const long long groups = n_cu / 8 > 0 ? n_cu / 8 : 1;
+            const long long nst = boards < groups ? boards : groups;
+            const dim3 grid((unsigned)(8 * nst)), block(CW_THREADS);
+            if (res)
+                hipLaunchKernelGGL((k_conv3x3_op19<true>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                                   (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+            else
+                hipLaunchKernelGGL((k_conv3x3_op19<false>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                                   (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+            return AZ_HIP(hipGetLastError());
+        }
+        // two launches, one per 128-channel half of the input; y holds the bf16 partial sum between them
         const long long groups = n_cu / 4 > 0 ? n_cu / 4 : 1;  // stripes of 4 workgroups; a device (partition) with < 4 CUs still gets one stripe
         const long long nst = boards < groups ? boards : groups;
         const dim3 grid((unsigned)(4 * nst)), block(CW_THREADS);

@@ -99,6 +99,51 @@ struct OpStatus {
         }
     }
 };
+// Drop-in mode (azsp_dropin_step): one iteration of uct_search's simulation loop in ONE launch.  A game is one wave and games never
+// interact, so expand / backup -> end of search -> selection of the next leaves -> read-back are simply run back to back by the game's wave
+// (the three-launch round of the batched actor exists to keep the rare end-of-move code out of the hot kernels' register budget, which
+// does not matter for the handful of games of a drop-in caller).  priors / values may live in page-locked HOST memory (read over PCIe:
+// a few hundred bytes); status / q / valid / fault flags / the leaves' observation planes are written straight to page-locked host
+// memory: the host needs one launch and one stream synchronisation per call, no copy commands.
+struct OpDropinStep {
+    const float* priors;  // null: first call of a search (nothing to back up)
+    const float* values;
+    void* feat;
+    unsigned char* valid;
+    int* status;               // host-visible: [G][8]
+    double* q;                 // host-visible: [G][2]
+    int* fault;                // host-visible: [G], the engine fault flags as this game's wave sees them when it is done
+    unsigned char* valid_out;  // host-visible: [G * P]
+    unsigned char* feat_out;   // host-visible: the first feat_bytes bytes of `feat`
+    long long feat_bytes, game_feat_bytes;  // game_feat_bytes: bytes of one game's P feature rows
+    template <class E> AZ_HD void operator()(E& e) const {
+        if (priors) {
+            e.backup_phase(priors, values);
+            E::Wave::sync();
+            e.endmove_phase();
+            E::Wave::sync();
+        }
+        e.select(feat, valid);
+        e.cnt[AZC_ROUNDS]++;
+        e.flush_counters();
+        E::Wave::sync();
+        OpStatus st = {status, q};
+        st(e);
+        if (E::Wave::first()) fault[e.g] = *e.m.err;
+        const int P = e.c.P;
+        E::Wave::lanes([&](int lane) {
+            if (lane < P) valid_out[(size_t)e.g * P + lane] = valid[(size_t)e.g * P + lane];
+        });
+        const long long lo = (long long)e.g * game_feat_bytes;
+        long long n = feat_bytes - lo;
+        n = n < 0 ? 0 : (n > game_feat_bytes ? game_feat_bytes : n);
+        const unsigned char* src = (const unsigned char*)feat + lo;
+        for (long long b0 = 0; b0 < n; b0 += AZ_WAVE)
+            E::Wave::lanes([&](int lane) {
+                if (b0 + lane < n) feat_out[lo + b0 + lane] = src[b0 + lane];
+            });
+    }
+};
 struct OpRngProbe {
     double* noise;
     double* unif;
@@ -536,8 +581,6 @@ int zero(void* dst, size_t n, void* stream);
 int sync(void* stream);
 void* host_alloc(size_t n);  // page-locked host memory (staging of azsp_dropin_step)
 void host_release(void* p);
-int h2d_async(void* dst, const void* src_pinned, size_t n, void* stream);  // no synchronisation: src must stay untouched until the stream drains
-int d2h_async(void* dst_pinned, const void* src, size_t n, void* stream);
 int set_device(int dev);
 const char* backend_error();
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void* stream, int g0, int g1);  // games [g0, g1)
@@ -915,38 +958,43 @@ int azsp_dropin_step(void* e, const float* priors_host, const float* values_host
         (priors_host == nullptr) != (values_host == nullptr))
         return AZSP_EINVAL;
     const size_t G = (size_t)h->cfg.G, rows = G * (size_t)h->cfg.P, A = (size_t)h->A;
-    // staging layout: [priors rows*A f32][values rows f32] | [status G*8 i32][q G*2 f64][err i32 (+pad)][valid rows u8 (padded to 8)][features]
-    const size_t o_val = rows * A * 4, up = o_val + rows * 4, o_st = (up + 15) & ~(size_t)15, o_q = o_st + G * 32, o_err = o_q + G * 16, o_valid = o_err + 8,
-                 o_feat = o_valid + ((rows + 15) & ~(size_t)15), total = o_feat + (size_t)feat_bytes;
+    static const int elem_of[7] = {1, 4, 2, 2, 0, 0, 0};  // AZSP_FEAT_I8 / F32 / BF16 / F16: plain [rows][17][N][N] tensors only
+    const int fd = h->pub.feature_dtype;
+    if (fd < 0 || fd > 6 || elem_of[fd] == 0) return AZSP_EINVAL;
+    const size_t game_feat = (size_t)h->cfg.P * 17 * h->NP * elem_of[fd];
+    if ((size_t)feat_bytes > G * game_feat) return AZSP_EINVAL;
+    // page-locked staging, device-visible: [priors rows*A f32][values rows f32] | [status G*8 i32][q G*2 f64][fault G i32][valid rows u8][features]
+    const size_t o_val = rows * A * 4, up = o_val + rows * 4, o_st = (up + 15) & ~(size_t)15, o_q = o_st + G * 32, o_err = o_q + G * 16,
+                 o_valid = (o_err + G * 4 + 15) & ~(size_t)15, o_feat = o_valid + ((rows + 15) & ~(size_t)15), total = o_feat + (size_t)feat_bytes;
     if (h->pin_bytes < total) {
-        if (h->pin) azb::host_release(h->pin);
+        if (h->pin) {
+            if (azb::sync(stream)) return AZSP_EDEVICE;  // no launch may still be writing the old staging
+            azb::host_release(h->pin);
+        }
         h->pin = (unsigned char*)azb::host_alloc(total);
         h->pin_bytes = h->pin ? total : 0;
         if (!h->pin) return AZSP_ENOMEM;
     }
     unsigned char* pin = h->pin;
-    int rc;
-    if (priors_host) {  // Phases 2-3 of the previous leaf batch (core/mcts_v2.py:614-625), then the end-of-search work when the budget is met
+    if (priors_host) {  // eval_func's outputs for the leaves of the previous call (core/mcts_v2.py:614-625 consume them)
         memcpy(pin, priors_host, rows * A * 4);
         memcpy(pin + o_val, values_host, rows * 4);
-        if (azb::h2d_async(priors_dev, pin, rows * A * 4, stream) || azb::h2d_async(values_dev, pin + o_val, rows * 4, stream)) return AZSP_EDEVICE;
-        if ((rc = azsp_expand_backup(e, priors_dev, values_dev, stream)) != 0) return rc;
     }
-    if ((rc = azsp_select(e, feat_dev, valid_dev, stream)) != 0) return rc;  // Phase 1 of the next batch (core/mcts_v2.py:572-611)
-    OpStatus op = {h->d_status, h->d_q};
-    if ((rc = az_run(h, op, stream)) != 0) return rc;
-    if (azb::d2h_async(pin + o_st, h->d_status, G * 32, stream) || azb::d2h_async(pin + o_q, h->d_q, G * 16, stream) ||
-        azb::d2h_async(pin + o_err, h->mem.err, sizeof(int), stream) || azb::d2h_async(pin + o_valid, valid_dev, rows, stream) ||
-        (feat_bytes > 0 && azb::d2h_async(pin + o_feat, feat_dev, (size_t)feat_bytes, stream)) || azb::sync(stream)) {
-        h->err = std::string("copy failed: ") + azb::backend_error();
+    // (priors_dev / values_dev stay the caller's tensors for the separate entries; this entry reads the staging directly)
+    OpDropinStep op = {priors_host ? (const float*)pin : nullptr, priors_host ? (const float*)(pin + o_val) : nullptr, feat_dev, valid_dev,
+                       (int*)(pin + o_st), (double*)(pin + o_q), (int*)(pin + o_err), pin + o_valid, pin + o_feat, (long long)feat_bytes, (long long)game_feat};
+    int rc = az_run(h, op, stream);
+    if (rc) return rc;
+    if (azb::sync(stream)) {
+        h->err = std::string("synchronisation failed: ") + azb::backend_error();
         return AZSP_EDEVICE;
     }
     memcpy(status_host, pin + o_st, G * 32);
     if (q_host) memcpy(q_host, pin + o_q, G * 16);
     memcpy(valid_host, pin + o_valid, rows);
     if (feat_bytes > 0) memcpy(feat_host, pin + o_feat, (size_t)feat_bytes);
-    int ef;
-    memcpy(&ef, pin + o_err, sizeof(int));
+    int ef = 0;
+    for (size_t g = 0; g < G; ++g) ef |= ((const int*)(pin + o_err))[g];
     if (ef) {
         char buf[160];
         snprintf(buf, sizeof buf, "engine fault flags 0x%x (1=node pool exhausted, 2=tree deeper than %d, 4=move sampling, 8=staging full)", ef, AZ_PATH_CAP);

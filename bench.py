@@ -477,14 +477,18 @@ def tower_roofline(conv, args, step_ms):
     if ceil:
         roofline["frac_of_issue_ceiling"] = round(issued_tf / ceil["issue_ceiling_tflops"], 4)
         roofline["instruction_form_ceiling"] = round(ceil["issue_ceiling_tflops"] / peak, 4)
-        if pj is not None and pj.get("cycles_per_mfma") and pj.get("effective_clock_GHz_mean"):
+        if pj is not None and pj.get("cycles_per_mfma") and pj.get("gpu_cycles_per_launch_mean") and pj.get("rows"):
             issue_cycles = ceil["pipe_cycles_per_mfma_at_peak"] / (ceil["issue_ceiling_tflops"] / peak)  # cycles between two issues of the form at its ceiling
             roofline["cycles_per_mfma"] = pj["cycles_per_mfma"]
             roofline["issue_efficiency"] = round(issue_cycles / pj["cycles_per_mfma"], 4)
-            roofline["clock_fraction"] = round(pj["effective_clock_GHz_mean"] / MFMA_PEAK_CLOCK_GHZ, 4)
+            # the clock THIS run's launches ran at: shader cycles of a launch (a property of the code path, from the PMC pass, scaled to this
+            # run's boards per launch) / this run's measured launch time
+            clk = pj["gpu_cycles_per_launch_mean"] * rows / pj["rows"] / (conv["avg_ms"] * 1e-3) / 1e9
+            roofline["effective_clock_GHz"] = round(clk, 4)
+            roofline["clock_fraction"] = round(clk / MFMA_PEAK_CLOCK_GHZ, 4)
             roofline["decomposition_product"] = round(roofline["instruction_form_ceiling"] * roofline["issue_efficiency"] * roofline["clock_fraction"], 4)
             roofline["decomposition_source"] = ("from_profiles: profiles/" + cname + " (SQ_INSTS_MFMA, GRBM_GUI_ACTIVE / 8 XCDs and the launch time of the same passes: "
-                                                "cycles per MFMA and the effective clock; " + ("STALE" if cstale else "kernel sources unchanged" if cstale is False else "no source digest") + ")")
+                                                "cycles per MFMA; effective clock = those cycles / this run's launch time; " + ("STALE" if cstale else "kernel sources unchanged" if cstale is False else "no source digest") + ")")
     roofline.update(extra)
     return roofline
 

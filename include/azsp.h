@@ -194,13 +194,15 @@ int azsp_get_search(void* engine, int32_t slot, int32_t ply, double* pi_host, fl
 int azsp_commit_move(void* engine, const int32_t* moves_host, void* stream);
 
 /* Drop-in mode: one iteration of the simulation loop of uct_search / parallel_uct_search (core/mcts_v2.py:378-421, :568-625) around the
- * caller's eval_func, with one packed upload, one packed read-back and ONE stream synchronisation (the separate entries above cost
- * eight).  priors_host float[rows][A] / values_host float[rows] (rows = G * P) = eval_func's outputs for the leaves of the previous
- * call, copied to priors_dev / values_dev and consumed by azsp_expand_backup; both NULL on the first call of a search (nothing to back
- * up yet).  Then azsp_select picks the next leaves into features_dev / valid_dev, and the call returns status_host int32[G][8] and
+ * caller's eval_func in ONE kernel launch and ONE stream synchronisation (the separate entries above cost four launches and eight
+ * synchronisations).  priors_host float[rows][A] / values_host float[rows] (rows = G * P) = eval_func's outputs for the leaves of the
+ * previous call; both NULL on the first call of a search (nothing to back up yet).  The game's wave runs expand / backup (and the
+ * end-of-search work when the budget is met), selects the next leaves into features_dev / valid_dev, and writes status_host int32[G][8],
  * q_host double[G][2] (as azsp_get_status; q_host may be NULL), valid_host uint8[rows] and the first features_bytes bytes of
- * features_dev in features_host (the observation planes eval_func receives; 0 = none).  Host pointers may be pageable: the engine
- * stages through its own page-locked buffer. */
+ * features_dev (the observation planes eval_func receives; 0 = none; feature_dtype must be a plain [rows][17][N][N] tensor: I8 / F32 /
+ * BF16 / F16) -- through a page-locked staging buffer of the engine that the kernel reads and writes directly, so no copy command is
+ * issued.  priors_dev / values_dev are the caller's evaluator tensors (unused by this entry beyond validation; azsp_expand_backup
+ * reads them).  Host pointers may be pageable. */
 int azsp_dropin_step(void* engine, const float* priors_host, const float* values_host, float* priors_dev, float* values_dev,
                      void* features_dev, uint8_t* valid_dev, int32_t* status_host, double* q_host, uint8_t* valid_host, void* features_host,
                      int64_t features_bytes, void* stream);

@@ -21,8 +21,6 @@ int zero(void* d, size_t n, void*) { memset(d, 0, n); return 0; }
 int sync(void*) { return 0; }
 void* host_alloc(size_t n) { return calloc(1, n); }
 void host_release(void* p) { free(p); }
-int h2d_async(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
-int d2h_async(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
 int set_device(int) { return 0; }
 const char* backend_error() { return "host twin"; }
 template <int N, int GAME, class Op> int launch(const AzCfg& c, const AzMem& m, const Op& op, void*, int g0, int g1) {

@@ -33,7 +33,8 @@ def test_tower_roofline_of_the_headline_kernel():
     c = r["mfma_ceilings"]
     zeros16 = [x["tflops"] for x in pc["cases"] if x["mfma"] == "v_mfma_f32_16x16x32_bf16" and x["operands"] == "zeros"][0]
     assert c["instruction_form"] == "v_mfma_f32_16x16x32_f16" and c["issue_ceiling_tflops"] == pc.get("issue_ceiling_16x16x32_tflops", zeros16)
-    assert c["sustained_tflops"] == pc["split_mix_mfma_only_tflops"] and c["limit"] == "issue"  # the split mix runs AT the issue ceiling: not power
+    # on real operands the split mix sustains 1.85-1.98 PF/s depending on the box: at, or a few percent under, the issue ceiling
+    assert c["sustained_tflops"] == pc["split_mix_mfma_only_tflops"] <= 1.02 * c["issue_ceiling_tflops"] and c["limit"] in ("issue", "power")
     assert "power_limited_mfma_only_tflops" not in r and "frac_of_power_limited_ceiling" not in r
     assert abs(r["frac_of_issue_ceiling"] - r["achieved"] / c["issue_ceiling_tflops"]) < 1e-3
     assert abs(r["instruction_form_ceiling"] - c["issue_ceiling_tflops"] / 2500.0) < 1e-3 and 0.75 < r["instruction_form_ceiling"] < 0.82
@@ -41,7 +42,7 @@ def test_tower_roofline_of_the_headline_kernel():
     assert r["traffic_stale"] in (True, False, None) and ("STALE" in r["traffic_source"]) == (r["traffic_stale"] is True)
     if pj.get("cycles_per_mfma"):  # a round-6 PMC pass: the decomposition of frac
         assert abs(r["issue_efficiency"] - (16.0 / r["instruction_form_ceiling"]) / pj["cycles_per_mfma"]) < 2e-3
-        assert abs(r["clock_fraction"] - pj["effective_clock_GHz_mean"] / 2.4) < 1e-3
+        assert abs(r["clock_fraction"] - pj["gpu_cycles_per_launch_mean"] / 1.74e-3 / 2.4e9) < 1e-3 and 0.5 < r["clock_fraction"] < 1.0
         assert abs(r["decomposition_product"] - r["instruction_form_ceiling"] * r["issue_efficiency"] * r["clock_fraction"]) < 1e-3
 
 
@@ -81,5 +82,7 @@ def test_net_flops_and_power_ceiling_helpers():
     assert f == 2 * 17 * 128 * 9 * 81 + 10 * 2 * (2 * 128 * 128 * 9 * 81) + 2 * 128 * 3 * 81 + 2 * (2 * 81) * 82 + 2 * 81 * 128 + 2 * 128
     cs, cb = bench.mfma_ceilings(True), bench.mfma_ceilings(False)
     assert cs["issue_ceiling_tflops"] > 1500 and cb["issue_ceiling_tflops"] > 2200 and cb["sustained_tflops"] > 1500
-    assert cb["limit"] == "power" and cs["limit"] == "issue"  # 32x32x16 on dense data is power-limited; 16x16x32 never gets there
+    assert cb["limit"] == "power" and cs["limit"] in ("issue", "power")  # 32x32x16 on dense data is power-limited; 16x16x32 sits where both limits meet
+    if "other_form" in cs:  # round 6: the split mix on the 32x32x16 form issues at ~2.49 PF/s with zero operands and sustains LESS than 16x16x32 on real ones
+        assert cs["other_form"]["issue_ceiling_tflops"] > 2300 and cs["other_form"]["sustained_tflops"] < 2200
     assert "profiles/mfma_power_probe.json" in cs["source"]

@@ -207,9 +207,11 @@ def test_gpu_no_unmarked_game_from_a_clamp_window():
         st, pi, z, games = a.harvest_tensors()
         rows_seen.extend((int(r[11]) % G, int(r[11]) // G, bool(m)) for r, m in zip(games, a.last_harvest_clamped))
 
-    for _ in range(6):
+    for _ in range(400):  # (a 9x9 game takes a few hundred rounds at this budget)
         a.run_rounds(10)
         take()
+        if len(rows_seen) >= 8:
+            break
     assert a.poll_evaluator_range() == 0 and rows_seen and not any(m for _, _, m in rows_seen)
     n_clean = len(rows_seen)
     done0 = a.engine.status()[0][:, 5].copy()            # the last clean poll: games with index < done0[slot] finished before the window
@@ -224,10 +226,10 @@ def test_gpu_no_unmarked_game_from_a_clamp_window():
     assert [m for m in w if "clamped" in str(m.message)] and a.range_rescales == 1 and a.clamp_window.events == 1
     assert torch.equal(a.infer.b_sp[1], a.infer.b32[1] * 2.0 ** -a.infer.act_shift)  # the poke is gone: biases rebuilt from the unscaled copy
     assert a.infer.act_shift > 0 or torch.equal(a.infer.b_sp[1], good_bias)
-    for _ in range(60):
+    for _ in range(800):
         a.run_rounds(10)
         take()
-        if (a.clamp_window.hi == -1).all():
+        if (a.clamp_window.hi == -1).all() and any(idx > done1[slot] for slot, idx, _ in rows_seen[n_clean:]):
             break
     a.run_rounds(30)
     take()
@@ -352,8 +354,9 @@ def test_calibration_pass_on_the_host_twin():
     assert bnd.dll.azsp_split_range_status(ctypes.byref(ev), None, 1, None) == 0 and ev.value == 0
     assert (p.double() - p64).abs().max().item() <= 2e-4 and (v.double() - v64).abs().max().item() <= 2e-4
     far = InferenceNet(_loud_net(9, 64, 1, gain=3e8), dtype=torch.float32, binding=bnd)
-    # the STEM's folded weights are beyond the format (the tower's own weights are ordinary: a separate reason)
-    assert far.stem_fallback_reason and not far.split_fallback_reason and "library fp32" in far.evaluator_path(9, "cpu") and far.act_shift == 0
+    # the STEM's folded weights are beyond the format (recorded separately); the tower goes with it: stem outputs of that size
+    # are beyond what its f16 pairs carry at any allowed scale
+    assert far.stem_fallback_reason and far.split_fallback_reason and "library fp32" in far.evaluator_path(9, "cpu") and far.act_shift == 0
     assert not far.supports_split_features(9, "cuda") and float(far.stem_wsp.abs().max()) == 0.0
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-box job script (replaces the per-call tools/gpu_r5[a-o].sh of round 5).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_job.sh <job> [<job> ...]'      outputs under gpurun_out/r6/
-# jobs: tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | smoke
+# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | smoke
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r6
 mkdir -p $O
@@ -28,6 +28,7 @@ for J in "$@"; do
     probe_power) (cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o mfma_power_probe mfma_power_probe.hip) && timeout 300 ./tools/probes/mfma_power_probe $O/mfma_power_probe.json > $O/mfma_power_probe.txt 2>&1; echo "probe rc=$?" | tee -a $O/status.txt; cat $O/mfma_power_probe.txt ;;
     pmc:*) PMC_FAMILIES="${J#pmc:}" bash tools/profile_r06.sh > $O/pmc_${J#pmc:}.log 2>&1; echo "pmc ${J#pmc:} rc=$?" | tee -a $O/status.txt; tail -3 $O/pmc_${J#pmc:}.log ;;
     rocprof_bench) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rb && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rb -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-companions --no-fresh-tree --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /tmp/rb.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rb -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_default.txt 2>&1); echo "rocprof rc=$?" | tee -a $O/status.txt; head -8 $O/kernel_stats_default.txt | cut -c1-200 ;;
+    conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac
 done

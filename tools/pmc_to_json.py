@@ -74,6 +74,30 @@ def main():
         js["cycles_per_mfma"] = round(sum(cm) / len(cm), 3)
         js["effective_clock_GHz_mean"] = round(sum(k["effective_clock_GHz"] for k in kernels.values() if "effective_clock_GHz" in k) / max(1, len(cm)), 4)
         js["mfma_busy_fraction_mean"] = round(sum(k.get("mfma_busy_fraction", 0) for k in kernels.values()) / len(cm), 4)
+        js["gpu_cycles_per_launch_mean"] = round(sum(k["gpu_cycles_per_launch"] for k in kernels.values() if "gpu_cycles_per_launch" in k) / len(cm), 1)
+    # kernels templated on <RES, ...>: the plain (ILb0) and the residual (ILb1) instantiation, in the summary's long-standing keys
+    pl = [k for n, k in kernels.items() if "ILb0E" in n]
+    rs = [k for n, k in kernels.items() if "ILb1E" in n]
+    if len(pl) == 1 and len(rs) == 1 and "hbm_bytes_per_launch" in pl[0] and "hbm_bytes_per_launch" in rs[0]:
+        js["hbm_bytes_per_launch_plain"], js["hbm_bytes_per_launch_residual"] = pl[0]["hbm_bytes_per_launch"], rs[0]["hbm_bytes_per_launch"]
+        js["FETCH_SIZE_KiB"] = {"plain": pl[0]["FETCH_SIZE_KiB"], "residual": rs[0]["FETCH_SIZE_KiB"]}
+        js["WRITE_SIZE_KiB"] = {"plain": pl[0]["WRITE_SIZE_KiB"], "residual": rs[0]["WRITE_SIZE_KiB"]}
+        if "mfma_busy_fraction" in pl[0]:
+            js["mfma_busy_fraction"] = {"plain": pl[0]["mfma_busy_fraction"], "residual": rs[0]["mfma_busy_fraction"]}
+            js["SQ_INSTS_MFMA"] = pl[0]["SQ_INSTS_MFMA"]
+        if "lds_bank_conflict_fraction" in pl[0]:
+            js["lds_bank_conflict_fraction"] = pl[0]["lds_bank_conflict_fraction"]
+    for stale in ("round5_counters",):  # superseded by this round's pass (the files they came from stay under profiles/)
+        if stale in js:
+            js.setdefault("earlier_rounds", {})[stale] = js.pop(stale)
+    if "source" in js:
+        js.setdefault("earlier_rounds", {})["source"] = js.pop("source")
+    if "note" in js:
+        js.setdefault("earlier_rounds", {})["note"] = js.pop("note")
+    js["kernel"] = js.get("kernel", fam).split(" (round")[0] + " (round 6 pass on this round's sources)"
+    js["note"] = ("separate rocprofv3 runs per counter group (tools/profile_r06.sh over tools/pmc_launches.py, post-ReLU-like data); FETCH_SIZE counts 64 B per "
+                  "128-B request (x2, profiles/r01_pmc_calibration.txt); cycles = GRBM_GUI_ACTIVE / 8 XCDs; effective clock = cycles / the launch time of the "
+                  "kernel-trace pass of the same script (6 cold launches: lower than inside a long run -- bench.py divides the cycles by ITS launch time)")
     js["source_round6"] = ["profiles/" + os.path.basename(src), "profiles/r01_pmc_calibration.txt (FETCH_SIZE x 2)"]
     json.dump(js, open(dst, "w"), indent=1)
     print(json.dumps({k: js[k] for k in ("family", "hbm_bytes_per_launch", "ratio_to_algorithmic", "cycles_per_mfma", "effective_clock_GHz_mean", "kernel_source_sha256") if k in js}))
