@@ -373,6 +373,7 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
 #define C1_XB_WAVE 2048                    // exchange: 2 quads x 64 lanes x 16 B per wave
 #define C1_XB (2 * 4 * C1_XB_WAVE)         // [unit parity][wave]
 #define C1_NBAND 4
+#define C1_VARIANT 0
 
 struct C1Map {
     unsigned short cell[C9_NCT * 32], pos[C9_NCT * 32];  // pos: tile-relative (row * 19 + col), 0xffff = computed, never stored
@@ -450,10 +451,16 @@ static_assert(c1_band_schedule_ok(0) && c1_band_schedule_ok(1), "19x19 one-pass 
 static_assert(c1_maps_cover_the_board(), "19x19 one-pass maps: every position stored exactly once");
 static __device__ const C1Map c1_maps[2] = {c1_make_map(0), c1_make_map(1)};
 
-template <bool ADD> struct C1Sched {  // static schedule of one unit = one column tile = 72 k-steps per wave (its cin half)
-    static constexpr int KS = 8, NSTEP = 72, NU = C9_NCT, R = 4;
+// V: build variant (bit 0: 6 ring slots instead of 4; bit 1: the barrier waits for the hand-over writes only -- a counted lgkmcnt -- instead
+// of draining the fragment ring; bit 2: barrier in front of slot 12 instead of 8).  The product launches C1_VARIANT; the others exist
+// for same-box A/B runs (AZSP_OP19_VARIANT, read once per process).
+template <bool ADD, int V> struct C1Sched {  // static schedule of one unit = one column tile = 72 k-steps per wave (its cin half)
+    static constexpr int KS = 8, NSTEP = 72, NU = C9_NCT, R = (V & 1) ? 6 : 4;
+    static constexpr bool LGKM_COUNTED = (V & 2) != 0;
     static constexpr int S0 = 5;            // first slot that may touch the previous unit's accumulators: the hand-over writes ride in S0, S0 + 1
-    static constexpr int SB = 8;            // the unit's barrier sits in front of slot SB
+    static constexpr int SB = (V & 4) ? 12 : 8;  // the unit's barrier sits in front of slot SB
+    // LDS operations this wave issues between its second hand-over write (rider of slot S0 + 1) and the barrier: one fragment read per slot
+    static constexpr int LGKM_AFTER_XWRITE = SB - (S0 + 1) - 1;
     static constexpr int OPS = ADD ? 9 : 5;  // epilogue micro-ops per register quad
     // rider stream behind the barrier, one micro-op per slot from SB + 1: 2 reads of the partner's quads, then per own quad 4 adds + OPS epilogue ops
     static constexpr int NRID = 2 + 2 * (4 + OPS);
@@ -505,10 +512,10 @@ template <bool ADD> struct C1Sched {  // static schedule of one unit = one colum
     static_assert(addend_use_slot(0) < store_slot(0) && addend_use_slot(1) > store_slot(0) && addend_use_slot(1) < store_slot(1), "an addend register is re-loaded after its last use");
 };
 
-template <bool ADD> __global__ void __launch_bounds__(CW_THREADS, 1)
+template <bool ADD, int V> __global__ void __launch_bounds__(CW_THREADS, 1)
 k_conv3x3_op19(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias, const unsigned char* add,
                unsigned char* y, int nboards, int relu) {
-    typedef C1Sched<ADD> SC;
+    typedef C1Sched<ADD, V> SC;
     constexpr int KS = SC::KS, NSTEP = SC::NSTEP, R = SC::R, NU = SC::NU, SB = SC::SB;
     constexpr int OTILE = 32 * C9_GBLK;   // one board of x / y / addend: 32 chunks
     __shared__ __attribute__((aligned(1024))) unsigned char lds[C1_IMG + C1_XB];
@@ -680,7 +687,10 @@ k_conv3x3_op19(const unsigned char* __restrict__ x, const unsigned short* __rest
                         constexpr int N = u == 1 ? SC::vm_between(0, 1) : u == 3 ? SC::vm_between(1, 3) : SC::vm_between(4, 5);
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
                     }
-                    CV_BARRIER();
+                    // LDS completes a wave's operations in order and the tile loop issues no scalar loads: "all but the N youngest" covers the
+                    // hand-over writes and leaves the fragment ring's look-ahead reads in flight
+                    if constexpr (SC::LGKM_COUNTED) asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(SC::LGKM_AFTER_XWRITE) : "memory");
+                    else CV_BARRIER();
                 }
                 if constexpr (t + R - 1 < NSTEP) load_step(b0, t + R - 1, (u * NSTEP + t + R - 1) % R);
                 else load_step(nb0, t + R - 1 - NSTEP, (u * NSTEP + t + R - 1) % R);

@@ -173,12 +173,21 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
             const long long groups = n_cu / 8 > 0 ? n_cu / 8 : 1;
             const long long nst = boards < groups ? boards : groups;
             const dim3 grid((unsigned)(8 * nst)), block(CW_THREADS);
-            if (res)
-                hipLaunchKernelGGL((k_conv3x3_op19<true>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
-                                   (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
-            else
-                hipLaunchKernelGGL((k_conv3x3_op19<false>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
-                                   (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+            static const int variant = getenv("AZSP_OP19_VARIANT") ? atoi(getenv("AZSP_OP19_VARIANT")) : C1_VARIANT;  // A/B switch, see C1Sched
+#define AZ_OP19(VV)                                                                                                                          \
+    case VV:                                                                                                                                 \
+        if (res)                                                                                                                             \
+            hipLaunchKernelGGL((k_conv3x3_op19<true, VV>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, \
+                               bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);                                     \
+        else                                                                                                                                 \
+            hipLaunchKernelGGL((k_conv3x3_op19<false, VV>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, \
+                               bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);                                 \
+        break;
+            switch (variant) {
+                AZ_OP19(0) AZ_OP19(6)  // 6: counted lgkmcnt + later barrier, +0.5 % in profiles/r06_conv19_ab.txt (kept for A/B runs)
+                default: return 1;
+            }
+#undef AZ_OP19
             return AZ_HIP(hipGetLastError());
         }
         // two launches, one per 128-channel half of the input; y holds the bf16 partial sum between them

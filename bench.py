@@ -454,9 +454,9 @@ def tower_roofline(conv, args, step_ms):
             passes = 2.0   # x in, y out
         else:
             kname = {(9, 128): "k_conv3x3_tiled", (17, 64): "k_conv3x3_t64", (9, 64): "k_conv3x3_t64",
-                     (19, 256): "k_conv3x3_hb19 (two launches per convolution, timed together)"}.get((S_t, args.filters), "conv3x3")
+                     (19, 256): "k_conv3x3_op19 (one launch per convolution: 64 couts x 256 cin per CU, cin halves meet through LDS)"}.get((S_t, args.filters), "conv3x3")
             kname += f" (weight-stationary MFMA 3x3 convolution of the residual tower, {'f16' if args.net_dtype == 'fp16' else 'bf16'})"
-            passes = 4.5 if S_t == 19 else 2.5
+            passes = 2.5  # x in, y out, residual on every second layer (19x19 x 256 since round 6 too: one pass)
         elem = 2
         extra = {"alg_flops_per_launch": conv_flops}
     roofline = {"kernel": kname, "bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 5),
@@ -493,18 +493,19 @@ def tower_roofline(conv, args, step_ms):
     return roofline
 
 
-def c1_dropin(seconds=8.0):
-    """BASELINE configs[0] (C1) through the KEPT ENTRY POINT: `alpha_zero_amd.core.mcts_v2.uct_search` (the reference's signature,
-    mcts_v2.py:301-450) in the reference actor's loop shape (pipeline.py:289-346: warm-up temperature for the first 16 moves, root noise,
-    sub-tree reuse) on 13x13 Gomoku, 100 simulations per move, with the reference's shipped trained 10 x 40 checkpoint when the golden
-    copy of its weights travelled (tests/golden/, data), a random network of that shape otherwise.  The tree lives on the GPU engine; the
-    evaluator is the caller's callback: (a) `cpu_eval_func` = the reference's own eval_position (pipeline.py:91-123: fp32 torch-CPU module, one
-    torch thread as training_gomoku.py sets), (b) `device_eval_func` = the product evaluator (InferenceNet, fp32-class kernels) behind the
-    same callback signature.  moves/s of each; one host round trip per simulation (azsp_dropin_step)."""
+def _c1_dropin_worker(args):
+    """One measurement of c1_dropin in its own process -- like every reference actor (training_gomoku.py:8-17 exports OMP_NUM_THREADS=1
+    before torch is imported, one process per actor) and like the CPU port it is compared with (oracle/baseline.py)."""
+    kind, seconds = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import numpy as np
+    import torch
+
+    torch.set_num_threads(1)
+    from alpha_zero_amd import _lib
     from alpha_zero_amd.core.mcts_v2 import uct_search
     from alpha_zero_amd.core.network import AlphaZeroNet, InferenceNet, widen_for_kernels
     from alpha_zero_amd.envs.gomoku import GomokuEnv
-    from alpha_zero_amd import _lib
 
     n, sims = 13, 100
     net = AlphaZeroNet((17, n, n), n * n, 10, 40, 80, gomoku=True)
@@ -514,28 +515,30 @@ def c1_dropin(seconds=8.0):
         net.load_state_dict(torch.load(ck, map_location="cpu", weights_only=True)["network"], strict=True)
         weights = "the reference's shipped checkpoint checkpoints/gomoku/13x13/training_steps_200000.ckpt (10 x 40)"
     net = net.eval()
+    note = ""
+    if kind == "cpu":
+        @torch.no_grad()
+        def eval_func(state, batched=False):  # pipeline.py:91-123
+            x = torch.from_numpy(state if batched else state[None, ...]).to(dtype=torch.float32)
+            logits, v = net(x)
+            pi = torch.softmax(logits, dim=-1).cpu().numpy()
+            v = np.squeeze(v.cpu().numpy(), axis=1).tolist()
+            pi = [pi[i] for i in range(pi.shape[0])]
+            return (pi, v) if batched else (pi[0], v[0])
+    else:
+        wnet, wnote = widen_for_kernels(net, n, torch.float32)  # 40 -> 64 filters, function-preserving: the hand-written fp32-class kernels
+        inf = InferenceNet(wnet, dtype=torch.float32, binding=_lib.load()).cuda()
+        note = inf.evaluator_path(n, torch.device("cuda")) + wnote
 
-    @torch.no_grad()
-    def cpu_eval(state, batched=False):  # pipeline.py:91-123
-        x = torch.from_numpy(state if batched else state[None, ...]).to(dtype=torch.float32)
-        logits, v = net(x)
-        pi = torch.softmax(logits, dim=-1).cpu().numpy()
-        v = np.squeeze(v.cpu().numpy(), axis=1).tolist()
-        pi = [pi[i] for i in range(pi.shape[0])]
-        return (pi, v) if batched else (pi[0], v[0])
+        @torch.no_grad()
+        def eval_func(state, batched=False):
+            x = torch.from_numpy(state if batched else state[None, ...]).to(device="cuda", dtype=torch.float32, non_blocking=True)
+            pri, v = inf(x)
+            pri, v = pri.float().cpu().numpy(), v.float().cpu().numpy().tolist()
+            pi = [pri[i] for i in range(pri.shape[0])]
+            return (pi, v) if batched else (pi[0], v[0])
 
-    wnet, wnote = widen_for_kernels(net, n, torch.float32)  # 40 -> 64 filters, function-preserving: the hand-written fp32-class kernels
-    inf = InferenceNet(wnet, dtype=torch.float32, binding=_lib.load()).cuda()
-
-    @torch.no_grad()
-    def dev_eval(state, batched=False):
-        x = torch.from_numpy(state if batched else state[None, ...]).to(device="cuda", dtype=torch.float32, non_blocking=True)
-        pri, v = inf(x)
-        pri, v = pri.float().cpu().numpy(), v.float().cpu().numpy().tolist()
-        pi = [pri[i] for i in range(pri.shape[0])]
-        return (pi, v) if batched else (pi[0], v[0])
-
-    def play(eval_func, budget):
+    def play(budget):
         np.random.seed(1)
         env = GomokuEnv(board_size=n)
         moves, t0 = 0, time.perf_counter()
@@ -549,21 +552,32 @@ def c1_dropin(seconds=8.0):
                 moves += 1
         return moves / (time.perf_counter() - t0), moves
 
-    nthreads = torch.get_num_threads()
-    out = {"config": "BASELINE C1: 13x13 Gomoku, uct_search (P = 1), 100 sims/move, one game at a time, sub-tree reuse, root noise", "weights": weights,
+    play(0.5)  # engine creation, first launches
+    v, m = play(seconds)
+    return v, m, weights, note
+
+
+def c1_dropin(seconds=8.0):
+    """BASELINE configs[0] (C1) through the KEPT ENTRY POINT: `alpha_zero_amd.core.mcts_v2.uct_search` (the reference's signature,
+    mcts_v2.py:301-450) in the reference actor's loop shape (pipeline.py:289-346: warm-up temperature for the first 16 moves, root noise,
+    sub-tree reuse) on 13x13 Gomoku, 100 simulations per move, with the reference's shipped trained 10 x 40 checkpoint when the golden
+    copy of its weights travelled (tests/golden/, data), a random network of that shape otherwise.  The tree lives on the GPU engine; the
+    evaluator is the caller's callback: (a) `cpu_eval_func` = the reference's own eval_position (pipeline.py:91-123: fp32 torch-CPU module, one
+    torch thread in a process of its own, as training_gomoku.py runs its actors), (b) `device_eval_func` = the product evaluator (InferenceNet,
+    fp32-class kernels) behind the same callback signature.  moves/s of each; one launch + one stream synchronisation per simulation
+    (azsp_dropin_step).  Each measurement runs in a spawned process, like the CPU port it stands beside."""
+    import multiprocessing as mp
+
+    out = {"config": "BASELINE C1: 13x13 Gomoku, uct_search (P = 1), 100 sims/move, one game at a time, sub-tree reuse, root noise",
            "entry_point": "alpha_zero_amd.core.mcts_v2.uct_search (same signature and return tuple as the reference's mcts_v2.uct_search)",
            "host_round_trips_per_simulation": 1}
-    try:
-        torch.set_num_threads(1)
-        play(cpu_eval, 0.5)  # engine creation, first launches
-        v, m = play(cpu_eval, seconds)
-        out["cpu_eval_func_moves_per_s"], out["cpu_eval_func_moves"] = round(v, 3), m
-    finally:
-        torch.set_num_threads(nthreads)
-    play(dev_eval, 0.5)
-    v, m = play(dev_eval, seconds)
-    out["device_eval_func_moves_per_s"], out["device_eval_func_moves"] = round(v, 3), m
-    out["device_evaluator"] = inf.evaluator_path(n, torch.device("cuda")) + wnote
+    ctx = mp.get_context("spawn")
+    for kind in ("cpu", "device"):
+        with ctx.Pool(1) as pool:
+            v, m, weights, note = pool.map(_c1_dropin_worker, [(kind, seconds)])[0]
+        out[f"{kind}_eval_func_moves_per_s"], out[f"{kind}_eval_func_moves"], out["weights"] = round(v, 3), m, weights
+        if note:
+            out["device_evaluator"] = note
     out["reference_moves_per_s_dev_container"] = 3.1  # BASELINE.md section 2 (the imported reference on this configuration; it cannot travel to the GPU box)
     return out
 

@@ -59,8 +59,9 @@ if __name__ == "__main__":
         one(B)
     else:
         for rep in range(2):
-            for label, extra in (("one pass (k_conv3x3_op19)", {}), ("two launches (k_conv3x3_hb19)", {"AZSP_CONV19_TWO_LAUNCH": "1"})):
+            variants = [("one pass (k_conv3x3_op19)" + (f", variant {v}" if v else ""), ({"AZSP_OP19_VARIANT": v} if v else {})) for v in os.environ.get("CONV19_AB_VARIANTS", "").split(",")]
+            for label, extra in variants + [("two launches (k_conv3x3_hb19)", {"AZSP_CONV19_TWO_LAUNCH": "1"})]:
                 print(f"{label}, {B} boards, run {rep}:", flush=True)
-                env = dict(os.environ, CONV19_AB_CHILD="1", **extra)
-                env.pop("AZSP_CONV19_TWO_LAUNCH", None) if not extra else None
+                env = {k: v for k, v in os.environ.items() if k not in ("AZSP_CONV19_TWO_LAUNCH", "AZSP_OP19_VARIANT")}
+                env.update(CONV19_AB_CHILD="1", **extra)
                 subprocess.run([sys.executable, os.path.abspath(__file__), str(B)], env=env, check=False)

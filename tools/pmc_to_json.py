@@ -22,13 +22,13 @@ def parse(txt):
             sec = ln[3:].strip()
             continue
         if sec == "kernel-trace":
-            m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\S+)", ln)
+            m = re.match(r"\s*(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(\S.*)$", ln)
             if m:
-                trace.append({"calls": int(m.group(1)), "avg_us": float(m.group(3)), "name": m.group(5)})
+                trace.append({"calls": int(m.group(1)), "avg_us": float(m.group(3)), "name": m.group(5).strip()})
                 continue
-        m = re.match(r"\s+(\S+)\s+(\S+)\s+n=(\d+)\s+mean=([\d.e+-]+)", ln)
+        m = re.match(r"\s+(\S.*?)\s+([A-Z][A-Z_0-9]+)\s+n=(\d+)\s+mean=([\d.e+-]+)", ln)  # (demangled kernel names contain blanks)
         if m:
-            out.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
+            out.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(4))
     return trace, out
 
 
@@ -60,6 +60,10 @@ def main():
             k["lds_bank_conflict_fraction"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
         kernels[kname] = k
     js = json.load(open(dst)) if os.path.exists(dst) else {}
+    if any("op19" in n for n in kernels):
+        js["scheme"] = "one_pass (k_conv3x3_op19, round 6)"
+        for k in [k for k in js if k.startswith(("hbm_bytes_per_convolution", "algorithmic_bytes_two", "ratio_to_two", "hbm_bytes_per_half", "mfma_busy_fraction_round4", "lds_bank_conflict_fraction_round4"))]:
+            js.setdefault("earlier_rounds", {})[k] = js.pop(k)
     hb = [k["hbm_bytes_per_launch"] for k in kernels.values() if "hbm_bytes_per_launch" in k]
     alg = rows * planes * planes * ch * elem * passes
     js.update({"rows": rows, "board": board, "planes": planes, "channels": ch, "family": fam,
@@ -76,8 +80,8 @@ def main():
         js["mfma_busy_fraction_mean"] = round(sum(k.get("mfma_busy_fraction", 0) for k in kernels.values()) / len(cm), 4)
         js["gpu_cycles_per_launch_mean"] = round(sum(k["gpu_cycles_per_launch"] for k in kernels.values() if "gpu_cycles_per_launch" in k) / len(cm), 1)
     # kernels templated on <RES, ...>: the plain (ILb0) and the residual (ILb1) instantiation, in the summary's long-standing keys
-    pl = [k for n, k in kernels.items() if "ILb0E" in n]
-    rs = [k for n, k in kernels.items() if "ILb1E" in n]
+    pl = [k for n, k in kernels.items() if "ILb0E" in n or "<false" in n]
+    rs = [k for n, k in kernels.items() if "ILb1E" in n or "<true" in n]
     if len(pl) == 1 and len(rs) == 1 and "hbm_bytes_per_launch" in pl[0] and "hbm_bytes_per_launch" in rs[0]:
         js["hbm_bytes_per_launch_plain"], js["hbm_bytes_per_launch_residual"] = pl[0]["hbm_bytes_per_launch"], rs[0]["hbm_bytes_per_launch"]
         js["FETCH_SIZE_KiB"] = {"plain": pl[0]["FETCH_SIZE_KiB"], "residual": rs[0]["FETCH_SIZE_KiB"]}
