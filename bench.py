@@ -516,7 +516,12 @@ def _c1_dropin_worker(args):
         weights = "the reference's shipped checkpoint checkpoints/gomoku/13x13/training_steps_200000.ckpt (10 x 40)"
     net = net.eval()
     note = ""
-    if kind == "cpu":
+    if kind == "null":  # no evaluator at all: what one simulation costs in the engine + the host round trip (uniform priors, value 0)
+        uni = np.full(n * n, 1.0 / (n * n), dtype=np.float32)
+
+        def eval_func(state, batched=False):
+            return ([uni] * state.shape[0], [0.0] * state.shape[0]) if batched else (uni, 0.0)
+    elif kind == "cpu":
         @torch.no_grad()
         def eval_func(state, batched=False):  # pipeline.py:91-123
             x = torch.from_numpy(state if batched else state[None, ...]).to(dtype=torch.float32)
@@ -572,12 +577,14 @@ def c1_dropin(seconds=8.0):
            "entry_point": "alpha_zero_amd.core.mcts_v2.uct_search (same signature and return tuple as the reference's mcts_v2.uct_search)",
            "host_round_trips_per_simulation": 1}
     ctx = mp.get_context("spawn")
-    for kind in ("cpu", "device"):
+    for kind in ("cpu", "device", "null"):
         with ctx.Pool(1) as pool:
-            v, m, weights, note = pool.map(_c1_dropin_worker, [(kind, seconds)])[0]
+            v, m, weights, note = pool.map(_c1_dropin_worker, [(kind, seconds if kind != "null" else min(seconds, 3.0))])[0]
         out[f"{kind}_eval_func_moves_per_s"], out[f"{kind}_eval_func_moves"], out["weights"] = round(v, 3), m, weights
         if note:
             out["device_evaluator"] = note
+    # a search of 100 simulations with sub-tree reuse runs ~70-100 new simulations: an upper bound of the engine + round-trip cost per simulation
+    out["engine_step_us_per_simulation_upper_bound"] = round(1e6 / max(out["null_eval_func_moves_per_s"], 1e-9) / 100.0, 1)
     out["reference_moves_per_s_dev_container"] = 3.1  # BASELINE.md section 2 (the imported reference on this configuration; it cannot travel to the GPU box)
     return out
 

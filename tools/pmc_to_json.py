@@ -62,7 +62,7 @@ def main():
     js = json.load(open(dst)) if os.path.exists(dst) else {}
     if any("op19" in n for n in kernels):
         js["scheme"] = "one_pass (k_conv3x3_op19, round 6)"
-        for k in [k for k in js if k.startswith(("hbm_bytes_per_convolution", "algorithmic_bytes_two", "ratio_to_two", "hbm_bytes_per_half", "mfma_busy_fraction_round4", "lds_bank_conflict_fraction_round4"))]:
+        for k in [k for k in js if k.startswith(("hbm_bytes_per_convolution", "algorithmic_bytes_two", "ratio_to_two", "ratio_to_one_pass", "hbm_bytes_per_half", "mfma_busy_fraction_round4", "lds_bank_conflict_fraction_round4"))]:
             js.setdefault("earlier_rounds", {})[k] = js.pop(k)
     hb = [k["hbm_bytes_per_launch"] for k in kernels.values() if "hbm_bytes_per_launch" in k]
     alg = rows * planes * planes * ch * elem * passes
