@@ -11,10 +11,17 @@
 //       phase A  conv1 on the x image in LDS (13 image rows) -> the m rows the tile's conv2 needs (rows 0-9 / 8-16: one halo row is
 //                recomputed per half: 21 + 19 = 40 column tiles of 16 positions per board against 38 unfused, + 5 % MFMAs), bias + ReLU +
 //                range record + split into hi / lo, written straight into the m image in LDS (ds_write_b64);
-//       barrier; phase B  conv2 on the m image, the skip from x in global memory (read by this CU's LDS-DMA a moment ago: an L2 hit),
-//                epilogue as in k_conv3x3_sp17<RES>, y to global memory; the NEXT tile's x image arrives by LDS-DMA under phase B's
-//                first MFMAs (the x buffer is free from the barrier on); barrier.
+//       barrier; phase B  conv2 on the m image, the skip from the x IMAGE IN LDS (round 6; round 5 re-read x from global memory, and a
+//                third of those re-reads missed the L2: HBM reads x 1.59 of x), epilogue as in k_conv3x3_sp17<RES>, y to global memory;
+//                the NEXT tile's x image arrives by LDS-DMA during phase B, each 64-cell piece as soon as the last skip read of its
+//                cells is done (below); barrier.
 //     HBM per block: x once (rows 7-10 twice, the second time from L2) + y once = 2 passes instead of 5.
+//   * skip from LDS without a second x buffer: wave q's skip values (its 16 couts = input channels 16 q .. 16 q + 15, both planes) live in
+//     exactly four strips of the x image -- (plane, chunk) = (0, 2q), (0, 2q + 1), (1, 2q), (1, 2q + 1) -- and wave q is the wave that
+//     DMAs exactly these four strips for the next tile: whether a cell may be overwritten is a matter of ONE wave's program order, no
+//     barrier.  The units of phase B walk the board top-down, so piece pc (cells 64 pc ..) of the wave's strips is issued right after
+//     the last unit whose skip reads touch it (compile-time checked against the lane maps: SbSkip); the skip of the LAST unit is
+//     fetched one unit early (8 registers), so that every piece is on its way >= 19 k-steps before the tile-end barrier needs it.
 //   * LDS: x image 16 strips (plane, chunk) x 256 cells x 16 B = 64 KB, m image 16 x 240 cells = 60 KB, one buffer each (the phases
 //     alternate between them, nothing is double-buffered), + a 20 KB lane table = 144 KB.  Image rows: cell(ri, x) = 1 + 19 ri + x with two
 //     zero cells between rows; the two halves use shifted row windows so that the zero rows they need (above the board / below it)
@@ -63,7 +70,7 @@ static_assert(Sb17::seg_seq0(3) + Sb17::seg_nu(3) == Sb17::NSEQ && Sb17::seg_til
 static_assert(Sb17::NSEQ % 3 == 0, "the rotating lane-table registers keep their phase from board to board");
 
 // (segment, column tile, lane & 15) -> position: column tile k of a segment takes the k-th position of every residue class (base cell
-// mod 16); unfilled slots repeat the first position of a residue class the tile still lacks (the repeats compute and store the same value).
+// mod 16); unfilled slots repeat the last position of a residue class the tile still lacks (the repeats compute and store the same value).
 struct Sb17Map {
     unsigned short pos[Sb17::NTILE * 16];
     bool ok;
@@ -92,8 +99,10 @@ constexpr Sb17Map sb17_make_map() {
             for (int res = 0; res < 16 && fill[k] < 16; ++res) {
                 if (used[k][res]) continue;
                 bool found = false;
-                for (int r = r0; r < r1 && !found; ++r)
-                    for (int x = 0; x < G::S && !found; ++x)
+                // (round 6: the LAST position of the class, i.e. a cell near the ones the late column tiles read anyway -- the skip of a
+                // padding slot is read from the x image like everyone's, and the early rows' cells are overwritten by then)
+                for (int r = r1 - 1; r >= r0 && !found; --r)
+                    for (int x = G::S - 1; x >= 0 && !found; --x)
                         if (((G::PITCH * (r - rb) + x) & 15) == res) {
                             m.pos[(t0 + k) * 16 + fill[k]++] = (unsigned short)(r * G::S + x);
                             used[k][res] = true;
@@ -121,6 +130,58 @@ constexpr Sb17Map sb17_make_map() {
 }
 static_assert(sb17_make_map().ok, "column-tile maps of the fused 17x17 block: every position of every segment covered, conflict-free lane groups");
 static __device__ const Sb17Map sb17_map = sb17_make_map();
+// The skip of phase B comes from the x image: x-image cell of position (r, x) in half h (the rows window of Sb17::x_src_row).
+struct SbSkip {
+    typedef Sb17 G;
+    static constexpr int xcell(int h, int r, int x) { return 1 + G::PITCH * (h ? r - 5 : r + 1) + x; }
+    // x-image cell of a phase-B position = its B-fragment base cell (m image) + this
+    static constexpr int xcell_of_base(int h) { return h ? 1 + G::PITCH * 2 : 1 + G::PITCH; }
+    // unit IN WHICH the skip values of unit u of phase-B segment g are read: its own (k-step 0), except the last unit's: one unit early
+    static constexpr int read_unit(int g, int u) { return u == G::seg_nu(g) - 1 ? u - 1 : u; }
+    // last unit of segment g (1 or 3) in which a skip read touches DMA piece pc (cells 64 pc .. 64 pc + 63); -1: never
+    static constexpr int last_read_unit(int g, int pc) {
+        const Sb17Map m = sb17_make_map();
+        int last = -1;
+        for (int u = 0; u < G::seg_nu(g); ++u)
+            for (int j = 0; j < G::unit_nj(g, u); ++j)
+                for (int s = 0; s < 16; ++s) {
+                    const int p = m.pos[(G::seg_tile0(g) + 2 * u + j) * 16 + s];
+                    if (xcell(G::seg_h(g), p / G::S, p % G::S) / 64 == pc && read_unit(g, u) > last) last = read_unit(g, u);
+                }
+        return last;
+    }
+    // the DMA schedule of the NEXT tile's x image inside phase B of half h: piece pc is issued in unit dma_unit(h, pc) from k-step dma_t0(h, pc)
+    // on, two DMA instructions per k-step (4 strips per wave: 2 k-steps).  A skip read issued in k-step t of a unit has returned when the
+    // MFMAs of k-step t + R + 1 issue (the compiler's wait for the fragments requested in k-step t + 1 covers every older LDS read): reads of
+    // k-step 0 -> pieces from k-step 8; the early fetch of the last unit's skip rides in k-step 4 -> pieces from k-step 13.
+    static constexpr int dma_unit(int h, int pc) { return h == 0 ? (pc == 3 ? 0 : pc == 0 ? 1 : 3) : (pc == 0 ? 0 : pc == 1 ? 1 : 3); }
+    static constexpr int dma_t0(int h, int pc) { return h == 0 ? (pc == 3 ? 1 : pc == 2 ? 13 : 8) : (pc == 0 ? 1 : pc == 3 ? 13 : 8); }
+    static constexpr bool ok(int h) {
+        const int g = 2 * h + 1;
+        if (G::seg_nu(g) != 5) return false;
+        for (int pc = 0; pc < 4; ++pc) {
+            const int last = last_read_unit(g, pc);
+            if (last < 0) continue;                                  // never read: any time
+            if (dma_unit(h, pc) < last) return false;
+            if (dma_unit(h, pc) == last) {
+                // read in k-step 0 of `last` (its own skip) or in k-step 4 (the last unit's skip, fetched in unit nu - 2)
+                const bool early_fetch_touches = [&] {
+                    const Sb17Map m = sb17_make_map();
+                    const int u = G::seg_nu(g) - 1;
+                    for (int j = 0; j < G::unit_nj(g, u); ++j)
+                        for (int s = 0; s < 16; ++s) {
+                            const int p = m.pos[(G::seg_tile0(g) + 2 * u + j) * 16 + s];
+                            if (xcell(h, p / G::S, p % G::S) / 64 == pc) return true;
+                        }
+                    return false;
+                }();
+                if (dma_t0(h, pc) < (early_fetch_touches && last == G::seg_nu(g) - 2 ? 13 : 8)) return false;
+            }
+        }
+        return true;
+    }
+};
+static_assert(SbSkip::ok(0) && SbSkip::ok(1), "fused 17x17 block: the x image's DMA pieces would overwrite cells a later skip read needs");
 typedef __attribute__((address_space(1))) unsigned char* sb17_gptr;         // pointers into global memory whose value the compiler must take
 typedef const __attribute__((address_space(1))) unsigned char* sb17_gcptr;  // as given (an opaque scalar base per plane, see the board loop)
 
@@ -166,7 +227,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     constexpr int E1G = sp_epi_e1(true), PAIRG = sp_epi_pair(true), CTG = sp_epi_ct_ops(true);
     constexpr int S0 = 6;                                    // first MFMA slot of a unit that may touch the previous unit's accumulators
     static_assert(KS % R == 0, "every unit starts at ring phase 0");
-    static_assert(NPIECE % 2 == 0 && KS - 2 >= NPIECE / 2, "the next tile's pieces ride in the first unit of phase B, two per k-step");
+    static_assert(SPW == 4 && NP == 4 && KS >= 15, "four strips per wave, four pieces per strip: a piece = 4 DMA instructions = 2 k-steps");
     static_assert((2 * G::PITCH + 2) * 16 + (KSUB - 1) * 4 * XBLK + XPLANE < 65536, "fragment addresses are a per-lane base + a 16-bit immediate");
     static_assert(XBLK % 256 == 0 && MBLK % 256 == 0, "strips are multiples of 256 B: the four 8-channel groups of a fragment share banks");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[TBL0 + TBL];
@@ -210,7 +271,8 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; ++e) bv[0][e] = b1[wave * 16 + 4 * kg + e], bv[1][e] = b2[wave * 16 + 4 * kg + e];
 
-    // LDS-DMA plan per half: a strip is NP pieces of 64 cells; wave q moves strips SPW q .. SPW q + SPW - 1 (strip = plane * NCH + chunk)
+    // LDS-DMA plan per half: a strip is NP pieces of 64 cells; wave q moves the four strips its OWN skip values live in: (plane, chunk) =
+    // (0, 2q), (0, 2q + 1), (1, 2q), (1, 2q + 1) (strip = plane * NCH + chunk): nobody else reads the skip from them (header)
     unsigned dsrc[2][NP];
     unsigned long long dmask[2][NP];
 #pragma unroll
@@ -222,7 +284,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
             dmask[h][i] = __builtin_amdgcn_ballot_w64(p >= 0);
         }
     auto dma_piece = [&](const unsigned char* src, bool live, int h, int i) __attribute__((always_inline)) {
-        const int c = SPW * wave + i / NP, pc = i % NP;
+        const int sx = i / NP, c = (sx >> 1) * NCH + 2 * wave + (sx & 1), pc = i % NP;
         const unsigned long long base = (unsigned long long)(src + (size_t)c * GBLK);
         const unsigned long long mask = live ? dmask[h][pc] : 0ull;
         const unsigned dst = lds0 + (unsigned)(c * XBLK + pc * 1024);
@@ -235,6 +297,9 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     const unsigned char* Ms = lds;                           // (phase B's lane-table offsets carry the m image's offset XBUF)
     unsigned char* Mw = lds + (wave * 2) * MBLK;             // this wave's two chunk strips of the m image (table offsets carry XBUF; lo plane at + MPLANE)
     const unsigned char* tbl = lds + TBL0 + lane * 8;
+    // skip address in the x image = a phase-B B-fragment base (lane table: XBUF + 16 base + kg MBLK) + this + 16 SbSkip::xcell_of_base(H) (+ XPLANE):
+    // chunk 2 wave + (kg >> 1), the lane's half (kg & 1) of the 16-byte cell -- the four channels its accumulators hold
+    const unsigned skc = (unsigned)(-XBUF - kg * MBLK + (kg >> 1) * XBLK + (kg & 1) * 8 + 2 * wave * XBLK);
     cv_u32x2 lm[3][NJM];  // rotating lane-table registers [unit sequence number % 3][column tile of the unit] = {B base offset, output offset}
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -278,6 +343,9 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
 
     c6_f32x4 accm[2][NJM], accc[2][NJM];  // [accumulator set][column tile of the unit]
     cv_u32x2 rr[2][NJM][2];               // skip values of a phase-B unit: [accumulator set][column tile][plane]
+    cv_u32x2 rrx[NJM][2];                 // skip values of the LAST unit of a phase B, fetched one unit early (see SbSkip)
+#pragma unroll
+    for (int j = 0; j < NJM; ++j) rrx[j][0] = (cv_u32x2){0u, 0u}, rrx[j][1] = (cv_u32x2){0u, 0u};
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -329,12 +397,10 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
         const unsigned char* xb = x + (size_t)board * GTILE;
         const unsigned char* xnb = x + (size_t)(has_next ? board + nslot : board) * GTILE;
         const size_t yo = (size_t)board * GTILE + (size_t)(wave * 2) * GBLK;  // uniform: the lane part comes from the lane table
-        const unsigned char* rbase = xb + (size_t)(wave * 2) * GBLK;          // the skip = the block's own input
         // one uniform base per plane, opaque to the compiler (it would otherwise fold base + GPLANE + lane offset into 64-bit VALU adds
-        // per access: GPLANE exceeds the 13-bit immediate): every skip load / y store is scalar base + lane offset
-        unsigned long long rlo = (unsigned long long)rbase + GPLANE, ylo = (unsigned long long)(y + yo) + GPLANE;
-        asm volatile("" : "+s"(rlo), "+s"(ylo));  // (opaque scalars, cast back to GLOBAL-address-space pointers: no flat accesses)
-        const sb17_gcptr rbase_lo = (sb17_gcptr)rlo;
+        // per access: GPLANE exceeds the 13-bit immediate): every y store is scalar base + lane offset
+        unsigned long long ylo = (unsigned long long)(y + yo) + GPLANE;
+        asm volatile("" : "+s"(ylo));  // (an opaque scalar, cast back to a GLOBAL-address-space pointer: no flat accesses)
         unsigned char* ybase = y + yo;
         const sb17_gptr ybase_lo = (sb17_gptr)ylo;
         const bool have_prev = it > 0;
@@ -399,18 +465,28 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                             if constexpr (o < SP::cum(sl)) epi_op(CpInt<RGLOBAL ? 1 : 0>{}, pset, o / CT_OPS, lm[PROT][o / CT_OPS].y, pout, pout_lo, o % CT_OPS, pstore);
                         }, typename CpMakeSeq<SP::MAXPER>::type{});
                     }
-                    if constexpr (PH == 1 && sl < 2 * nj) {  // this unit's skip values (used by its epilogue inside the next unit)
+                    if constexpr (PH == 1 && sl < 2 * nj) {  // this unit's skip values (used by its epilogue inside the next unit): from the x image
                         constexpr int rj = sl >> 1, rp = sl & 1;
-                        if constexpr (rp == 0) rr[set][rj][rp] = *(const cv_u32x2*)(rbase + lm[ROT][rj].y);
-                        else rr[set][rj][rp] = *(const __attribute__((address_space(1))) cv_u32x2*)(rbase_lo + lm[ROT][rj].y);
+                        if constexpr (LAST) rr[set][rj][rp] = rrx[rj][rp];  // (fetched in the unit before: the cells are being overwritten by now)
+                        else rr[set][rj][rp] = *(const cv_u32x2*)(Xs + (lm[ROT][rj].x + skc) + SbSkip::xcell_of_base(H) * 16 + rp * XPLANE);
+                    }
+                    if constexpr (PH == 1 && U == NU - 2 && t == 4 && q < 2 * nnj) {  // the LAST unit's skip values, one unit early (its lane-table registers arrived in k-step 3)
+                        constexpr int rj = q >> 1, rp = q & 1;
+                        rrx[rj][rp] = *(const cv_u32x2*)(Xs + (lm[NROT][rj].x + skc) + SbSkip::xcell_of_base(H) * 16 + rp * XPLANE);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
-                if constexpr (PH == 1 && FIRST && t >= 1 && 2 * (t - 1) < NPIECE) {
-                    // the tile after this one: the lower half of this board, or the upper half of this workgroup's next board; two pieces per
-                    // k-step (same-box A/B, profiles/r05_split_ablation.txt (5): -0.5 % against one per k-step; where in the k-step: no difference)
-                    if constexpr (H == 0) dma_piece(xb, true, 1, 2 * (t - 1)), dma_piece(xb, true, 1, 2 * (t - 1) + 1);
-                    else dma_piece(xnb, has_next, 0, 2 * (t - 1)), dma_piece(xnb, has_next, 0, 2 * (t - 1) + 1);
+                if constexpr (PH == 1) {
+                    // the tile after this one (the lower half of this board, or the upper half of this workgroup's next board) arrives piece by
+                    // piece behind the skip reads (SbSkip): piece pc of this wave's four strips in unit dma_unit(H, pc), k-steps dma_t0 and + 1
+                    cp_for_each([&](auto PC) __attribute__((always_inline)) {
+                        constexpr int pc = decltype(PC)::value;
+                        if constexpr (SbSkip::dma_unit(H, pc) == U && (t == SbSkip::dma_t0(H, pc) || t == SbSkip::dma_t0(H, pc) + 1)) {
+                            constexpr int sx = 2 * (t - SbSkip::dma_t0(H, pc));  // strips sx, sx + 1 of the wave's four
+                            if constexpr (H == 0) dma_piece(xb, true, 1, sx * NP + pc), dma_piece(xb, true, 1, (sx + 1) * NP + pc);
+                            else dma_piece(xnb, has_next, 0, sx * NP + pc), dma_piece(xnb, has_next, 0, (sx + 1) * NP + pc);
+                        }
+                    }, typename CpMakeSeq<NP>::type{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<KS>::type{});
