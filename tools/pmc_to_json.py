@@ -91,6 +91,19 @@ def main():
             js["SQ_INSTS_MFMA"] = pl[0]["SQ_INSTS_MFMA"]
         if "lds_bank_conflict_fraction" in pl[0]:
             js["lds_bank_conflict_fraction"] = pl[0]["lds_bank_conflict_fraction"]
+    if len(kernels) == 1:  # a one-kernel family (the fused blocks): the summary's long-standing scalar keys
+        k1 = list(kernels.values())[0]
+        if "hbm_bytes_per_launch" in k1:
+            js["FETCH_SIZE_KiB"], js["WRITE_SIZE_KiB"] = k1["FETCH_SIZE_KiB"], k1["WRITE_SIZE_KiB"]
+            tensor = rows * planes * planes * ch * elem
+            js["read_ratio_to_x"], js["write_ratio_to_y"] = round(2.0 * k1["FETCH_SIZE_KiB"] * 1024 / tensor, 4), round(k1["WRITE_SIZE_KiB"] * 1024 / tensor, 4)
+        for key in ("mfma_busy_fraction", "effective_clock_GHz", "lds_bank_conflict_fraction", "SQ_INSTS_MFMA"):
+            if key in k1:
+                if isinstance(js.get(key), dict):
+                    js.setdefault("earlier_rounds", {})[key] = js[key]
+                js[key] = k1[key]
+        for key in [k for k in js if k.startswith("wave_cycle_breakdown_")]:
+            js.setdefault("earlier_rounds", {})[key] = js.pop(key)
     for stale in ("round5_counters",):  # superseded by this round's pass (the files they came from stay under profiles/)
         if stale in js:
             js.setdefault("earlier_rounds", {})[stale] = js.pop(stale)
