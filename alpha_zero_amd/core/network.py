@@ -279,7 +279,7 @@ class InferenceNet(nn.Module):
                 and x.is_contiguous(memory_format=torch.channels_last))
 
     SPLIT_TOWER_SHAPES = ((128, 9), (64, 9), (64, 17))          # (filters, tower planes) with an azsp_conv3x3_split kernel
-    SPLIT_FUSED_SHAPES = ((64, 17),)                            # ... with a one-launch-per-block kernel (azsp_resblock_split)
+    SPLIT_FUSED_SHAPES = ((64, 17), (64, 9))                    # ... with a one-launch-per-block kernel (azsp_resblock_split)
     SPLIT_EVAL_SHAPES = ((128, 9, 1), (64, 9, 1), (64, 13, 3))  # (filters, board, stem pad) whose whole evaluator runs on the split kernels
 
     def _split_tower_ok(self, x):
@@ -507,8 +507,9 @@ class InferenceNet(nn.Module):
         """All residual blocks on split-layout buffers; returns the buffer holding the tower output."""
         dll, ck = self.binding.dll, self._ck
         if self.use_fused_block and (C, S) in self.SPLIT_FUSED_SHAPES and probe is None:
-            # 64 filters on 17x17 planes: one launch per ResNetBlock, the intermediate activation stays in LDS (azsp_resblock_split:
-            # two tensor passes through HBM per block instead of five; bit-identical to the two launches below)
+            # 64 filters on 17x17 planes (13x13 Gomoku) or 9x9 planes (9x9 Go, two boards per tile): one launch per ResNetBlock, the intermediate
+            # activation stays in LDS (azsp_resblock_split: two tensor passes through HBM per block instead of five; bit-identical to the
+            # two launches below)
             for i in range(self.n_blocks):
                 ck(dll.azsp_resblock_split(a.data_ptr(), self.wsp[2 * i].data_ptr(), self.b_sp[2 * i].data_ptr(), self.wsp[2 * i + 1].data_ptr(),
                                            self.b_sp[2 * i + 1].data_ptr(), o.data_ptr(), B, S, C, rr, st), "azsp_resblock_split")

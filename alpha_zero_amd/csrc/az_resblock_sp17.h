@@ -36,10 +36,21 @@
 #include "az_conv_sp17.h"
 
 #if defined(__HIPCC__)
+// Geometry of a fused block kernel (k_resblock_sp<G, R>).  A BLOCK is what a persistent workgroup takes per iteration: G::BPB boards, worked off as
+// G::NH tiles of two phases each (segments).  Positions are "virtual": pv = vr * S + x with virtual rows vr = 0 .. VROWS - 1.
+//   Sb17: one 17x17 board = two half-board tiles (the 13x13 Gomoku tower; round 5)
+//   Sb9 : TWO 9x9 boards stacked with one separator row (vr = 9 has no positions) = ONE tile: the zero cells between the boards are exactly
+//         the padding each board's convolutions need, conv1 produces all 162 intermediate positions before conv2 starts, 11 column tiles
+//         per convolution (162 of 176 slots) = 5.5 per board against 5 + 1 / 16 of the unfused kernel's corner trick: + 8.6 % MFMAs
 struct Sb17 {
-    static constexpr int S = 17, P2 = 289, PITCH = 19;
+    static constexpr int S = 17, P2 = 289, PITCH = 19, VROWS = 17, BPB = 1, NH = 2;
     static constexpr int XCELLS = 256, MCELLS = 240;       // 1 + 13 * 19 = 248 / 1 + 12 * 19 = 229, rounded up to multiples of 16 cells
     static constexpr int NSEG = 4, NSEQ = 21, NTILE = 40;  // segments (A,H0) (B,H0) (A,H1) (B,H1); units and column tiles per board
+    static constexpr bool row_has_pos(int) { return true; }
+    static constexpr int gpos_off(int pv) { return pv * 16; }  // byte offset of a virtual position in a (plane, chunk) block of the BLOCK's first board
+    static constexpr int seg_b(int h) { return 2 * h + 1; }    // the phase-B segment of tile kind h
+    static constexpr int xcell_of_base(int h) { return h ? 1 + 2 * PITCH : 1 + PITCH; }  // x-image cell of a phase-B position = its B-fragment base cell (m image) + this
+    static constexpr int xcell(int h, int vr, int x) { return 1 + PITCH * (h ? vr - 5 : vr + 1) + x; }
     static constexpr int seg_ph(int g) { return g & 1; }   // 0 = phase A (conv1: x image -> m image), 1 = phase B (conv2: m image -> y)
     static constexpr int seg_h(int g) { return g >> 1; }
     static constexpr int seg_r0(int g) { return g == 0 ? 0 : g == 1 ? 0 : g == 2 ? 8 : 9; }     // first output row of the segment
@@ -66,26 +77,59 @@ struct Sb17 {
         return r < 0 ? -1 : r * S + xx;
     }
 };
-static_assert(Sb17::seg_seq0(3) + Sb17::seg_nu(3) == Sb17::NSEQ && Sb17::seg_tile0(3) + Sb17::seg_nct(3) == Sb17::NTILE, "unit / tile numbering");
-static_assert(Sb17::NSEQ % 3 == 0, "the rotating lane-table registers keep their phase from board to board");
+struct Sb9 {
+    static constexpr int S = 9, P2 = 81, PITCH = 11, VROWS = 19, BPB = 2, NH = 1;
+    static constexpr int XCELLS = 240, MCELLS = 240;       // 1 + 21 * 11 = 232 (image rows -1 .. 19), rounded up to a multiple of 16 cells
+    static constexpr int NSEG = 2, NSEQ = 12, NTILE = 22;  // segments (A) (B); 6 units and 11 column tiles each
+    static constexpr int GTILEB = 2 * 8 * 81 * 16;         // bytes of one board in the split layout (64 channels)
+    static constexpr bool row_has_pos(int vr) { return vr != 9; }
+    static constexpr int gpos_off(int pv) { return pv / S >= 10 ? GTILEB + ((pv / S - 10) * S + pv % S) * 16 : pv * 16; }
+    static constexpr int seg_b(int) { return 1; }
+    static constexpr int xcell_of_base(int) { return 1 + PITCH; }
+    static constexpr int xcell(int, int vr, int x) { return 1 + PITCH * (vr + 1) + x; }
+    static constexpr int seg_ph(int g) { return g; }
+    static constexpr int seg_h(int) { return 0; }
+    static constexpr int seg_r0(int) { return 0; }
+    static constexpr int seg_nr(int) { return 19; }
+    static constexpr int seg_nct(int) { return 11; }
+    static constexpr int seg_rbase(int) { return 0; }
+    static constexpr int seg_nu(int g) { return (seg_nct(g) + 1) / 2; }
+    static constexpr int seg_tile0(int g) { return 11 * g; }
+    static constexpr int seg_seq0(int g) { return 6 * g; }
+    static constexpr int unit_nj(int g, int u) { return seg_nct(g) - 2 * u >= 2 ? 2 : 1; }
+    static constexpr int m_cell_of_base(int) { return 1 + PITCH; }  // mi = vr + 1 -> 1 + 11 (vr + 1) + x = base + 12
+    static constexpr int x_src_row(int, int ri) { return (ri >= 1 && ri <= 19 && ri != 10) ? ri - 1 : -1; }
+    static constexpr int x_pos_of_cell(int h, int cell) {
+        const int k = cell - 1;
+        if (k < 0) return -1;
+        const int ri = k / PITCH, xx = k % PITCH;
+        if (xx >= S) return -1;
+        const int r = x_src_row(h, ri);
+        return r < 0 ? -1 : r * S + xx;
+    }
+};
+template <class G> constexpr bool sb_numbering_ok() {
+    return G::seg_seq0(G::NSEG - 1) + G::seg_nu(G::NSEG - 1) == G::NSEQ && G::seg_tile0(G::NSEG - 1) + G::seg_nct(G::NSEG - 1) == G::NTILE && G::NSEQ % 3 == 0;
+}
+static_assert(sb_numbering_ok<Sb17>() && sb_numbering_ok<Sb9>(), "unit / tile numbering; the rotating lane-table registers keep their phase from block to block");
 
 // (segment, column tile, lane & 15) -> position: column tile k of a segment takes the k-th position of every residue class (base cell
 // mod 16); unfilled slots repeat the last position of a residue class the tile still lacks (the repeats compute and store the same value).
-struct Sb17Map {
-    unsigned short pos[Sb17::NTILE * 16];
+template <class G> struct SbMap {
+    unsigned short pos[G::NTILE * 16];
     bool ok;
 };
-constexpr Sb17Map sb17_make_map() {
-    typedef Sb17 G;
-    Sb17Map m{};
+template <class G> constexpr SbMap<G> sb_make_map() {
+    SbMap<G> m{};
     bool ok = true;
     for (int g = 0; g < G::NSEG; ++g) {
         int cnt[16] = {}, fill[11] = {};
         bool used[11][16] = {};
-        bool seen_pos[G::P2] = {};
+        bool seen_pos[G::VROWS * G::S] = {};
         const int nct = G::seg_nct(g), t0 = G::seg_tile0(g), r0 = G::seg_r0(g), r1 = r0 + G::seg_nr(g), rb = G::seg_rbase(g);
         for (int r = r0; r < r1; ++r)
             for (int x = 0; x < G::S; ++x) {
+                if (!G::row_has_pos(r)) continue;
                 const int res = (G::PITCH * (r - rb) + x) & 15, k = cnt[res]++;
                 if (k >= nct) {
                     ok = false;
@@ -103,7 +147,7 @@ constexpr Sb17Map sb17_make_map() {
                 // padding slot is read from the x image like everyone's, and the early rows' cells are overwritten by then)
                 for (int r = r1 - 1; r >= r0 && !found; --r)
                     for (int x = G::S - 1; x >= 0 && !found; --x)
-                        if (((G::PITCH * (r - rb) + x) & 15) == res) {
+                        if (G::row_has_pos(r) && ((G::PITCH * (r - rb) + x) & 15) == res) {
                             m.pos[(t0 + k) * 16 + fill[k]++] = (unsigned short)(r * G::S + x);
                             used[k][res] = true;
                             found = true;
@@ -115,7 +159,7 @@ constexpr Sb17Map sb17_make_map() {
             if (fill[k] != 16) ok = false;
             for (int s = 0; s < 16; ++s) {
                 const int p = m.pos[(t0 + k) * 16 + s], r = p / G::S, x = p % G::S;
-                if (r < r0 || r >= r1) ok = false;
+                if (r < r0 || r >= r1 || !G::row_has_pos(r)) ok = false;
                 const int res = (G::PITCH * (r - rb) + x) & 15;
                 if (seen[res]) ok = false;
                 seen[res] = true;
@@ -123,65 +167,65 @@ constexpr Sb17Map sb17_make_map() {
         }
         for (int r = r0; r < r1; ++r)
             for (int x = 0; x < G::S; ++x)
-                if (!seen_pos[r * G::S + x]) ok = false;
+                if (G::row_has_pos(r) && !seen_pos[r * G::S + x]) ok = false;
     }
     m.ok = ok;
     return m;
 }
-static_assert(sb17_make_map().ok, "column-tile maps of the fused 17x17 block: every position of every segment covered, conflict-free lane groups");
-static __device__ const Sb17Map sb17_map = sb17_make_map();
-// The skip of phase B comes from the x image: x-image cell of position (r, x) in half h (the rows window of Sb17::x_src_row).
-struct SbSkip {
-    typedef Sb17 G;
-    static constexpr int xcell(int h, int r, int x) { return 1 + G::PITCH * (h ? r - 5 : r + 1) + x; }
-    // x-image cell of a phase-B position = its B-fragment base cell (m image) + this
-    static constexpr int xcell_of_base(int h) { return h ? 1 + G::PITCH * 2 : 1 + G::PITCH; }
-    // unit IN WHICH the skip values of unit u of phase-B segment g are read: its own (k-step 0), except the last unit's: one unit early
+static_assert(sb_make_map<Sb17>().ok && sb_make_map<Sb9>().ok, "column-tile maps of the fused blocks: every position of every segment covered, conflict-free lane groups");
+template <class G> struct SbMapDev {
+    static __device__ const SbMap<G> map;
+};
+template <class G> __device__ const SbMap<G> SbMapDev<G>::map = sb_make_map<G>();
+// The skip of phase B comes from the x image (G::xcell).  SbSkip<G> derives, from the lane maps, WHEN each 64-cell DMA piece of the next tile's
+// x image may be issued inside phase B of tile kind h: in the last unit in which a skip read touches its cells (unit 0 if none does).
+//   * the skip values of unit u are read in k-step 0 of unit u -- except the LAST unit's, which are fetched in k-step 4 of the unit before
+//     (8 registers), so that no piece has to wait for the last unit;
+//   * a skip read issued in k-step t has returned when the MFMAs of k-step t + R + 1 issue (the compiler's wait for the fragments requested in
+//     k-step t + 1 covers every older LDS read): reads of k-step 0 -> the piece from k-step 8 on, the early fetch (k-step 4) -> from k-step 13;
+//   * a piece = this wave's four strips = 4 DMA instructions, two per k-step.
+template <class G> struct SbSkip {
+    static constexpr int NP = (G::XCELLS + 63) / 64;
+    struct Tab {
+        int unit[2][4], t0[2][4];
+        bool ok;
+    };
     static constexpr int read_unit(int g, int u) { return u == G::seg_nu(g) - 1 ? u - 1 : u; }
-    // last unit of segment g (1 or 3) in which a skip read touches DMA piece pc (cells 64 pc .. 64 pc + 63); -1: never
-    static constexpr int last_read_unit(int g, int pc) {
-        const Sb17Map m = sb17_make_map();
-        int last = -1;
-        for (int u = 0; u < G::seg_nu(g); ++u)
-            for (int j = 0; j < G::unit_nj(g, u); ++j)
-                for (int s = 0; s < 16; ++s) {
-                    const int p = m.pos[(G::seg_tile0(g) + 2 * u + j) * 16 + s];
-                    if (xcell(G::seg_h(g), p / G::S, p % G::S) / 64 == pc && read_unit(g, u) > last) last = read_unit(g, u);
-                }
-        return last;
-    }
-    // the DMA schedule of the NEXT tile's x image inside phase B of half h: piece pc is issued in unit dma_unit(h, pc) from k-step dma_t0(h, pc)
-    // on, two DMA instructions per k-step (4 strips per wave: 2 k-steps).  A skip read issued in k-step t of a unit has returned when the
-    // MFMAs of k-step t + R + 1 issue (the compiler's wait for the fragments requested in k-step t + 1 covers every older LDS read): reads of
-    // k-step 0 -> pieces from k-step 8; the early fetch of the last unit's skip rides in k-step 4 -> pieces from k-step 13.
-    static constexpr int dma_unit(int h, int pc) { return h == 0 ? (pc == 3 ? 0 : pc == 0 ? 1 : 3) : (pc == 0 ? 0 : pc == 1 ? 1 : 3); }
-    static constexpr int dma_t0(int h, int pc) { return h == 0 ? (pc == 3 ? 1 : pc == 2 ? 13 : 8) : (pc == 0 ? 1 : pc == 3 ? 13 : 8); }
-    static constexpr bool ok(int h) {
-        const int g = 2 * h + 1;
-        if (G::seg_nu(g) != 5) return false;
-        for (int pc = 0; pc < 4; ++pc) {
-            const int last = last_read_unit(g, pc);
-            if (last < 0) continue;                                  // never read: any time
-            if (dma_unit(h, pc) < last) return false;
-            if (dma_unit(h, pc) == last) {
-                // read in k-step 0 of `last` (its own skip) or in k-step 4 (the last unit's skip, fetched in unit nu - 2)
-                const bool early_fetch_touches = [&] {
-                    const Sb17Map m = sb17_make_map();
-                    const int u = G::seg_nu(g) - 1;
+    static constexpr Tab make() {
+        Tab tb{};
+        const SbMap<G> m = sb_make_map<G>();
+        bool ok = NP <= 4;
+        for (int h = 0; h < G::NH; ++h) {
+            const int g = G::seg_b(h), nu = G::seg_nu(g);
+            if (nu < 3) ok = false;
+            for (int pc = 0; pc < 4; ++pc) {
+                int last = -1;
+                bool early = false;  // the early fetch (of the last unit's skip, in unit nu - 2) touches the piece
+                for (int u = 0; u < nu; ++u)
                     for (int j = 0; j < G::unit_nj(g, u); ++j)
                         for (int s = 0; s < 16; ++s) {
                             const int p = m.pos[(G::seg_tile0(g) + 2 * u + j) * 16 + s];
-                            if (xcell(h, p / G::S, p % G::S) / 64 == pc) return true;
+                            if (G::xcell(h, p / G::S, p % G::S) / 64 != pc) continue;
+                            if (read_unit(g, u) > last) last = read_unit(g, u);
+                            if (u == nu - 1) early = true;
                         }
-                    return false;
-                }();
-                if (dma_t0(h, pc) < (early_fetch_touches && last == G::seg_nu(g) - 2 ? 13 : 8)) return false;
+                tb.unit[h][pc] = last < 0 ? 0 : last;
+                tb.t0[h][pc] = last < 0 ? 1 : (early && last == nu - 2 ? 13 : 8);
             }
         }
-        return true;
+        tb.ok = ok;
+        return tb;
     }
+    static constexpr Tab tab = make();
+    static constexpr int dma_unit(int h, int pc) { return tab.unit[h][pc]; }
+    static constexpr int dma_t0(int h, int pc) { return tab.t0[h][pc]; }
 };
-static_assert(SbSkip::ok(0) && SbSkip::ok(1), "fused 17x17 block: the x image's DMA pieces would overwrite cells a later skip read needs");
+static_assert(SbSkip<Sb17>::tab.ok && SbSkip<Sb9>::tab.ok, "fused blocks: DMA piece schedule");
+// (round 6's first version hard-coded Sb17's schedule; the derivation reproduces it)
+static_assert(SbSkip<Sb17>::dma_unit(0, 3) == 0 && SbSkip<Sb17>::dma_t0(0, 3) == 1 && SbSkip<Sb17>::dma_unit(0, 0) == 1 && SbSkip<Sb17>::dma_t0(0, 0) == 8 &&
+              SbSkip<Sb17>::dma_unit(0, 1) == 3 && SbSkip<Sb17>::dma_t0(0, 1) == 8 && SbSkip<Sb17>::dma_unit(0, 2) == 3 && SbSkip<Sb17>::dma_t0(0, 2) == 13 &&
+              SbSkip<Sb17>::dma_unit(1, 0) == 0 && SbSkip<Sb17>::dma_unit(1, 1) == 1 && SbSkip<Sb17>::dma_unit(1, 2) == 3 && SbSkip<Sb17>::dma_t0(1, 2) == 8 &&
+              SbSkip<Sb17>::dma_unit(1, 3) == 3 && SbSkip<Sb17>::dma_t0(1, 3) == 13, "Sb17: the derived DMA schedule");
 typedef __attribute__((address_space(1))) unsigned char* sb17_gptr;         // pointers into global memory whose value the compiler must take
 typedef const __attribute__((address_space(1))) unsigned char* sb17_gcptr;  // as given (an opaque scalar base per plane, see the board loop)
 
@@ -205,10 +249,11 @@ __device__ __forceinline__ unsigned sb17_scale_cvt_hi(unsigned lo, float d) {
 
 // w1, w2: [plane: hi, lo][9 taps][64 couts][64 cin] f16 with lo = (w - hi) * 2^11 (the packing of azsp_conv3x3_split); b1, b2 fp32 [64].
 // R = slots of the B-fragment ring (k-steps): a fragment is requested R - 1 k-steps before its MFMAs.
-template <int R> __global__ void __launch_bounds__(CW_THREADS, 1)
-k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__ w1, const float* __restrict__ b1, const _Float16* __restrict__ w2,
-                const float* __restrict__ b2, unsigned char* __restrict__ y, int nboards, unsigned* range) {
-    typedef Sb17 G;
+// nblocks = blocks of G::BPB boards (Sb17: boards; Sb9: PAIRS of boards -- an odd last board is the launcher's business).
+template <class G, int R> __global__ void __launch_bounds__(CW_THREADS, 1)
+k_resblock_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ w1, const float* __restrict__ b1, const _Float16* __restrict__ w2,
+              const float* __restrict__ b2, unsigned char* __restrict__ y, int nblocks, unsigned* range) {
+    typedef SbSkip<G> SK;
     constexpr int C = 64, NCH = 8, CIN = 64, KSUB = 2;
     constexpr int KS = 9 * KSUB;                             // k-steps per unit (one tap x 32 input channels)
     constexpr int NJM = 2;                                   // most column tiles per unit
@@ -216,7 +261,8 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     constexpr int MBLK = G::MCELLS * 16, MPLANE = NCH * MBLK, MBUF = 2 * MPLANE;    // 3840, 30720, 61440
     constexpr int TBL0 = XBUF + MBUF, TBL = G::NTILE * 64 * 8;                      // lane table: [tile][lane] {B base offset, output offset}
     constexpr int GBLK = G::P2 * 16, GPLANE = NCH * GBLK, GTILE = 2 * GPLANE;       // split layout of a board in global memory
-    constexpr int NP = G::XCELLS / 64;                       // DMA pieces of 64 cells per strip
+    constexpr int GBLOCK = G::BPB * GTILE;                                          // ... of a block
+    constexpr int NP = (G::XCELLS + 63) / 64;                // DMA pieces of 64 cells per strip (the last one may reach past the strip: those lanes are masked)
     constexpr int SPW = 2 * NCH / 4, NPIECE = NP * SPW;      // strips and DMA pieces per wave and tile: 4, 16
     constexpr int NFC = 2 * KS, NF = 2 * NFC;                // A fragments per convolution (2 planes x 18 k-steps), in all: 72
     // epilogue micro-ops per column tile (sp_epi_* in az_conv_sp.h).  TO THE M IMAGE (phase A): per element 1 (join), per pair of elements 8
@@ -241,8 +287,8 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     for (int i = tid; i < G::NTILE * 64; i += CW_THREADS) {
         const int tile = i >> 6, ln = i & 63, tl15 = ln & 15, tkg = ln >> 4;
         int g = 0;
-        while (g < 3 && tile >= G::seg_tile0(g + 1)) ++g;
-        const int pos = sb17_map.pos[tile * 16 + tl15], r = pos / G::S, xx = pos % G::S;
+        while (g < G::NSEG - 1 && tile >= G::seg_tile0(g + 1)) ++g;
+        const int pos = SbMapDev<G>::map.pos[tile * 16 + tl15], r = pos / G::S, xx = pos % G::S;
         const int base = G::PITCH * (r - G::seg_rbase(g)) + xx;
         unsigned boff, ooff;
         // B bases are offsets from the start of the LDS block (phase B's include the m image's own offset XBUF): every fragment
@@ -252,12 +298,12 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
             ooff = (unsigned)(XBUF + (base + G::m_cell_of_base(G::seg_h(g))) * 16 + (tkg & 1) * 8 + (tkg >> 1) * MBLK);
         } else {
             boff = (unsigned)(XBUF + base * 16 + tkg * MBLK);
-            ooff = (unsigned)(pos * 16 + (tkg >> 1) * GBLK + (tkg & 1) * 8);
+            ooff = (unsigned)(G::gpos_off(pos) + (tkg >> 1) * GBLK + (tkg & 1) * 8);
         }
         *(cv_u32x2*)(lds + TBL0 + i * 8) = (cv_u32x2){boff, ooff};
     }
     CV_BARRIER();  // the zero cells and the table are final before any LDS-DMA piece can land
-    if (slot >= nboards) return;  // (uniform per workgroup)
+    if (slot >= nblocks) return;  // (uniform per workgroup)
 
     // A fragments: fragment f = conv * NFC + plane * KS + (tap * KSUB + ks): lane (cout = 16 wave + l15, cin = 32 ks + 8 kg .. + 8)
     sp_f16x8 wf[NF];
@@ -273,14 +319,14 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
 
     // LDS-DMA plan per half: a strip is NP pieces of 64 cells; wave q moves the four strips its OWN skip values live in: (plane, chunk) =
     // (0, 2q), (0, 2q + 1), (1, 2q), (1, 2q + 1) (strip = plane * NCH + chunk): nobody else reads the skip from them (header)
-    unsigned dsrc[2][NP];
-    unsigned long long dmask[2][NP];
+    unsigned dsrc[G::NH][NP];
+    unsigned long long dmask[G::NH][NP];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < G::NH; ++h)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int p = G::x_pos_of_cell(h, 64 * i + lane);
-            dsrc[h][i] = (unsigned)((p < 0 ? 0 : p) * 16);
+            dsrc[h][i] = (unsigned)(p < 0 ? 0 : G::gpos_off(p));
             dmask[h][i] = __builtin_amdgcn_ballot_w64(p >= 0);
         }
     auto dma_piece = [&](const unsigned char* src, bool live, int h, int i) __attribute__((always_inline)) {
@@ -297,7 +343,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     const unsigned char* Ms = lds;                           // (phase B's lane-table offsets carry the m image's offset XBUF)
     unsigned char* Mw = lds + (wave * 2) * MBLK;             // this wave's two chunk strips of the m image (table offsets carry XBUF; lo plane at + MPLANE)
     const unsigned char* tbl = lds + TBL0 + lane * 8;
-    // skip address in the x image = a phase-B B-fragment base (lane table: XBUF + 16 base + kg MBLK) + this + 16 SbSkip::xcell_of_base(H) (+ XPLANE):
+    // skip address in the x image = a phase-B B-fragment base (lane table: XBUF + 16 base + kg MBLK) + this + 16 G::xcell_of_base(H) (+ XPLANE):
     // chunk 2 wave + (kg >> 1), the lane's half (kg & 1) of the 16-byte cell -- the four channels its accumulators hold
     const unsigned skc = (unsigned)(-XBUF - kg * MBLK + (kg >> 1) * XBLK + (kg & 1) * 8 + 2 * wave * XBLK);
     cv_u32x2 lm[3][NJM];  // rotating lane-table registers [unit sequence number % 3][column tile of the unit] = {B base offset, output offset}
@@ -325,7 +371,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     };
 
     {   // first tile (upper half of the first board): all pieces at once, then the first lane-table registers and fragments
-        const unsigned char* src = x + (size_t)slot * GTILE;
+        const unsigned char* src = x + (size_t)slot * GBLOCK;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) dma_piece(src, true, 0, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -339,7 +385,7 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
         if (f < 64) asm volatile("" : : "a"(wf[f]));
         else asm volatile("" : : "v"(wf[f]));
     }
-    asm volatile("" : : "v"(bv[0]), "v"(bv[1]), "v"(dsrc[0][0]), "v"(dsrc[1][NP - 1]));
+    asm volatile("" : : "v"(bv[0]), "v"(bv[1]), "v"(dsrc[0][0]), "v"(dsrc[G::NH - 1][NP - 1]));
 
     c6_f32x4 accm[2][NJM], accc[2][NJM];  // [accumulator set][column tile of the unit]
     cv_u32x2 rr[2][NJM][2];               // skip values of a phase-B unit: [accumulator set][column tile][plane]
@@ -392,11 +438,11 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
     int it = 0;
     unsigned char* yprev = y;
     sb17_gptr yprev_lo = (sb17_gptr)(unsigned long long)y;
-    for (int board = slot; board < nboards; board += nslot, ++it) {
-        const bool has_next = board + nslot < nboards;
-        const unsigned char* xb = x + (size_t)board * GTILE;
-        const unsigned char* xnb = x + (size_t)(has_next ? board + nslot : board) * GTILE;
-        const size_t yo = (size_t)board * GTILE + (size_t)(wave * 2) * GBLK;  // uniform: the lane part comes from the lane table
+    for (int board = slot; board < nblocks; board += nslot, ++it) {
+        const bool has_next = board + nslot < nblocks;
+        const unsigned char* xb = x + (size_t)board * GBLOCK;
+        const unsigned char* xnb = x + (size_t)(has_next ? board + nslot : board) * GBLOCK;
+        const size_t yo = (size_t)board * GBLOCK + (size_t)(wave * 2) * GBLK;  // uniform: the lane part comes from the lane table
         // one uniform base per plane, opaque to the compiler (it would otherwise fold base + GPLANE + lane offset into 64-bit VALU adds
         // per access: GPLANE exceeds the 13-bit immediate): every y store is scalar base + lane offset
         unsigned long long ylo = (unsigned long long)(y + yo) + GPLANE;
@@ -413,11 +459,11 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
             constexpr int set = PH == 0 ? (U & 1) : ((U + NU) & 1);                  // phase B: its last unit uses set 1 (phase A starts on set 0)
             constexpr bool LAST = U == NU - 1, FIRST = U == 0;
             // the next unit (the ring and the lane-table registers run one unit ahead)
-            constexpr int NSG = LAST ? (SG + 1) & 3 : SG, NUU = LAST ? 0 : U + 1;
+            constexpr int NSG = LAST ? (SG + 1) % G::NSEG : SG, NUU = LAST ? 0 : U + 1;
             constexpr int nnj = G::unit_nj(NSG, NUU), ntile0 = G::seg_tile0(NSG) + 2 * NUU;
             // the previous unit, whose epilogue rides here: phase A, first unit: the last unit of the previous phase B (global); phase A,
             // later units: the previous unit of this phase (m image); phase B, first unit: nothing (phase A finished exposed); later: global
-            constexpr int PSG = FIRST ? (SG + 3) & 3 : SG, PU = FIRST ? G::seg_nu(PSG) - 1 : U - 1;
+            constexpr int PSG = FIRST ? (SG + G::NSEG - 1) % G::NSEG : SG, PU = FIRST ? G::seg_nu(PSG) - 1 : U - 1;
             constexpr bool RIDE = !(PH == 1 && FIRST);
             constexpr bool RGLOBAL = G::seg_ph(PSG) == 1;
             constexpr int pnj = G::unit_nj(PSG, PU);
@@ -468,11 +514,11 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                     if constexpr (PH == 1 && sl < 2 * nj) {  // this unit's skip values (used by its epilogue inside the next unit): from the x image
                         constexpr int rj = sl >> 1, rp = sl & 1;
                         if constexpr (LAST) rr[set][rj][rp] = rrx[rj][rp];  // (fetched in the unit before: the cells are being overwritten by now)
-                        else rr[set][rj][rp] = *(const cv_u32x2*)(Xs + (lm[ROT][rj].x + skc) + SbSkip::xcell_of_base(H) * 16 + rp * XPLANE);
+                        else rr[set][rj][rp] = *(const cv_u32x2*)(Xs + (lm[ROT][rj].x + skc) + G::xcell_of_base(H) * 16 + rp * XPLANE);
                     }
                     if constexpr (PH == 1 && U == NU - 2 && t == 4 && q < 2 * nnj) {  // the LAST unit's skip values, one unit early (its lane-table registers arrived in k-step 3)
                         constexpr int rj = q >> 1, rp = q & 1;
-                        rrx[rj][rp] = *(const cv_u32x2*)(Xs + (lm[NROT][rj].x + skc) + SbSkip::xcell_of_base(H) * 16 + rp * XPLANE);
+                        rrx[rj][rp] = *(const cv_u32x2*)(Xs + (lm[NROT][rj].x + skc) + G::xcell_of_base(H) * 16 + rp * XPLANE);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }, typename CpMakeSeq<NQ>::type{});
@@ -481,9 +527,10 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
                     // piece behind the skip reads (SbSkip): piece pc of this wave's four strips in unit dma_unit(H, pc), k-steps dma_t0 and + 1
                     cp_for_each([&](auto PC) __attribute__((always_inline)) {
                         constexpr int pc = decltype(PC)::value;
-                        if constexpr (SbSkip::dma_unit(H, pc) == U && (t == SbSkip::dma_t0(H, pc) || t == SbSkip::dma_t0(H, pc) + 1)) {
-                            constexpr int sx = 2 * (t - SbSkip::dma_t0(H, pc));  // strips sx, sx + 1 of the wave's four
-                            if constexpr (H == 0) dma_piece(xb, true, 1, sx * NP + pc), dma_piece(xb, true, 1, (sx + 1) * NP + pc);
+                        if constexpr (SK::dma_unit(H, pc) == U && (t == SK::dma_t0(H, pc) || t == SK::dma_t0(H, pc) + 1)) {
+                            constexpr int sx = 2 * (t - SK::dma_t0(H, pc));  // strips sx, sx + 1 of the wave's four
+                            // the tile after this one: the next tile kind of this block, or tile kind 0 of this workgroup's next block
+                            if constexpr (H + 1 < G::NH) dma_piece(xb, true, H + 1, sx * NP + pc), dma_piece(xb, true, H + 1, (sx + 1) * NP + pc);
                             else dma_piece(xnb, has_next, 0, sx * NP + pc), dma_piece(xnb, has_next, 0, (sx + 1) * NP + pc);
                         }
                     }, typename CpMakeSeq<NP>::type{});
@@ -508,16 +555,13 @@ k_resblock_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict_
             constexpr int SG = decltype(GC)::value;
             cp_for_each([&](auto UC) __attribute__((always_inline)) { unit(CpInt<SG>{}, UC); }, typename CpMakeSeq<G::seg_nu(SG)>::type{});
         };
-        segment(CpInt<0>{});
-        segment(CpInt<1>{});
-        segment(CpInt<2>{});
-        segment(CpInt<3>{});
+        cp_for_each([&](auto GC) __attribute__((always_inline)) { segment(GC); }, typename CpMakeSeq<G::NSEG>::type{});
         yprev = ybase, yprev_lo = ybase_lo;
     }
-    // epilogue of the very last unit (phase B of the lower half, last unit: accumulator set 1, lane-table registers of sequence number 20)
+    // epilogue of the very last unit (the last phase B's last unit: accumulator set 1, lane-table registers of the last sequence number)
     {
-        constexpr int nj = G::unit_nj(3, G::seg_nu(3) - 1), ROT = (G::NSEQ - 1) % 3;
-        static_assert(nj == 1, "the board's last unit holds one column tile");
+        constexpr int LSG = G::NSEG - 1, nj = G::unit_nj(LSG, G::seg_nu(LSG) - 1), ROT = (G::NSEQ - 1) % 3;
+        static_assert(nj == 1 && ((G::seg_nu(LSG) - 1 + G::seg_nu(LSG)) & 1) == 1, "the block's last unit holds one column tile and accumulates into set 1");
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accm[1][0]), "+v"(accc[1][0]));
 #pragma unroll
         for (int j = 0; j < nj; ++j)

@@ -342,11 +342,39 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
     if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st, range);
     return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st, range);
 }
+// scratch for the intermediate activation of ONE 9x9 x 64 board: the odd last board of azsp_resblock_split at 9x9 runs as two unfused
+// launches (the fused kernel takes pairs of boards).  One lazily allocated buffer per device, never freed; calls on different streams of one
+// device that both end in an odd board would share it -- the evaluator runs one stream per network.
+static void* sp9_tail_scratch() {
+    static void* buf[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!buf[dev] && AZ_HIP(hipMalloc(&buf[dev], (size_t)Sb9::GTILEB))) return nullptr;
+    return buf[dev];
+}
 int launch_resblock_split(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
                           void* st, unsigned* range) {
-    if (S != Sb17::S || C != 64) return 1;  // 17x17 planes x 64 filters: the 13x13 Gomoku tower
+    if (C != 64 || (S != Sb17::S && S != Sb9::S)) return 1;  // 17x17 planes (the 13x13 Gomoku tower) or 9x9 planes (9x9 Go, logs/go/9x9_12b64) x 64 filters
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
+    if (S == Sb9::S) {  // blocks of TWO boards; an odd last board: the two unfused convolutions (bit-identical results)
+        const long long pairs = boards / 2;
+        if (pairs > 0) {
+            const long long nslot = pairs < n_cu ? pairs : n_cu;
+            hipLaunchKernelGGL((k_resblock_sp<Sb9, 6>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+                               (const _Float16*)w2, b2, (unsigned char*)y, (int)pairs, range);
+            if (AZ_HIP(hipGetLastError())) return -1;
+        }
+        if (boards & 1) {
+            void* mid = sp9_tail_scratch();
+            if (!mid) return -1;
+            const size_t off = (size_t)(boards - 1) * Sb9::GTILEB;
+            int rc = launch_sp<false, 8, 1>((const unsigned char*)x + off, w1, b1, nullptr, mid, 1, 1, st, range);
+            if (rc) return rc;
+            return launch_sp<true, 8, 1>(mid, w2, b2, (const unsigned char*)x + off, (unsigned char*)y + off, 1, 1, st, range);
+        }
+        return 0;
+    }
     const long long nslot = boards < n_cu ? boards : n_cu;  // one persistent workgroup per CU; a board = two half-board tiles x two phases
     // (the 3-slot ring of the A/B in profiles/r05_pmc_splitblock17_ring3*.txt: build with -DAZSP_EXPERIMENT_RING3 and set AZSP_RB_RING=3)
 #ifdef AZSP_EXPERIMENT_RING3
@@ -355,12 +383,12 @@ int launch_resblock_split(const void* x, const void* w1, const float* b1, const 
         return e && atoi(e) == 3;
     }();
     if (ring3) {
-        hipLaunchKernelGGL(k_resblock_sp17<3>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+        hipLaunchKernelGGL((k_resblock_sp<Sb17, 3>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
                            (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
         return AZ_HIP(hipGetLastError());
     }
 #endif
-    hipLaunchKernelGGL(k_resblock_sp17<6>, dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
+    hipLaunchKernelGGL((k_resblock_sp<Sb17, 6>), dim3((unsigned)nslot), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w1, b1,
                        (const _Float16*)w2, b2, (unsigned char*)y, (int)boards, range);
     return AZ_HIP(hipGetLastError());
 }

@@ -415,7 +415,8 @@ def tower_roofline(conv, args, step_ms):
     # HBM traffic per launch is NOT measured in this run: it comes from a separate `rocprofv3 --pmc` pass (the guide's recipe: counters in
     # their own run) whose summary is committed under profiles/ -- labelled as such in `traffic_source`
     if split:
-        cname = "split_kernel_pmc.json" if S_t == 9 else ("splitblock17_kernel_pmc.json" if fused else "split17_kernel_pmc.json")
+        cname = (("splitblock9_64_kernel_pmc.json" if fused else "split_kernel_pmc.json") if S_t == 9 else
+                 ("splitblock17_kernel_pmc.json" if fused else "split17_kernel_pmc.json"))
     else:
         cname = "block64_kernel_pmc.json" if fused else {(9, 128): "conv_kernel_pmc.json", (19, 256): "conv19_kernel_pmc.json"}.get((S_t, args.filters), "conv64_kernel_pmc.json")
     ctraffic, csrc, cstale = None, None, None
@@ -435,8 +436,8 @@ def tower_roofline(conv, args, step_ms):
         tf = issued / (conv["avg_ms"] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS["fp16"]
         if fused:
-            kname = ("k_resblock_sp17 (one whole split-precision ResNetBlock per launch: both 3x3 convolutions, hi + lo f16 pairs, three f16 MFMA "
-                     "products per multiply, fp32 accumulation; intermediate activation in LDS, skip from the input)")
+            kname = ("k_resblock_sp<" + ("Sb17" if S_t == 17 else "Sb9") + "> (one whole split-precision ResNetBlock per launch: both 3x3 convolutions, hi + lo f16 "
+                     "pairs, three f16 MFMA products per multiply, fp32 accumulation; intermediate activation in LDS, skip from the x image in LDS)")
             elem, passes = 4, 2.0  # x in, y out
         else:
             kname = ("k_conv3x3_sp" if S_t == 9 else "k_conv3x3_sp17") + (" (split-precision 3x3 convolution of the residual tower: hi + lo f16 pairs, "

@@ -316,7 +316,8 @@ int azsp_conv3x3_split(const void* x_dev, const void* w_split_dev, const float* 
  * intermediate activation stays in LDS (half-board tiles, the halo row of each half recomputed), so a block moves two tensor passes
  * through HBM instead of five; results are bit-identical to two azsp_conv3x3_split calls (same MFMA order, same roundings).  w1 / w2 in
  * the packing of azsp_conv3x3_split, b1 / b2 float[64]; y must NOT alias x.  On the device: (S, C) = (17, 64), the 13x13 Gomoku tower
- * (az_resblock_sp17.h); AZSP_EINVAL for other shapes.  range_rec_dev as above. */
+ * (half-board tiles, az_resblock_sp17.h), and (9, 64), the reference's 64-filter 9x9 Go towers (logs/go/9x9_12b64; two boards per tile, an odd
+ * last board runs as the two unfused launches); AZSP_EINVAL for other shapes.  range_rec_dev as above. */
 int azsp_resblock_split(const void* x_dev, const void* w1_split_dev, const float* bias1_dev, const void* w2_split_dev, const float* bias2_dev,
                         void* y_dev, int64_t boards, int32_t board_size, int32_t channels, uint32_t* range_rec_dev, void* stream);
 

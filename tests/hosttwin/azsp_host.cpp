@@ -182,7 +182,7 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
 }
 int launch_resblock_split(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, long long boards, int S, int C,
                           void*, unsigned* range) {
-    if (S != 17 || C != 64) return 1;
+    if ((S != 17 && S != 9) || C != 64) return 1;
     SpRangeScope scope(range);
     std::vector<unsigned short> mid((size_t)boards * 2 * S * S * C);
     if (host_conv_split(x, w1, b1, nullptr, mid.data(), boards, S, C, C, 1)) return 1;

@@ -52,7 +52,7 @@ def test_tower_roofline_of_the_fused_gomoku_block():
     conv = {"launches": 30, "avg_ms": 3.45, "planes": 17, "fused_block": True, "split": True, "avg_ms_plain": None, "avg_ms_residual": None, "data": "real"}
     r = bench.tower_roofline(conv, _args(board=13, game="gomoku", blocks=6, filters=64), step_ms=22.5)
     flops = 2 * 2.0 * 32768 * 289 * 64 * 64 * 9  # two convolutions per launch
-    assert r["alg_flops_per_launch"] == flops and r["launches_per_step"] == 6 and "k_resblock_sp17" in r["kernel"]
+    assert r["alg_flops_per_launch"] == flops and r["launches_per_step"] == 6 and "k_resblock_sp<Sb17>" in r["kernel"]
     assert abs(r["frac"] - 3 * flops / 3.45e-3 / 1e12 / 2500.0) < 1e-4
     assert r["alg_hbm_bytes_per_launch"] == round(32768 * 289 * 64 * 4 * 2.0)  # x in, y out
     pj = json.load(open(os.path.join(ROOT, "profiles", "splitblock17_kernel_pmc.json")))

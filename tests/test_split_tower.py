@@ -524,9 +524,9 @@ def test_gpu_stem_on_engine_written_features_equals_the_general_stem(game, n, fi
 
 
 # ---- fused split-precision ResNetBlock at 17x17 x 64 (az_resblock_sp17.h, azsp_resblock_split) ------------------------------------
-def _resblock_inputs(boards, seed):
+def _resblock_inputs(boards, seed, S=17):
     g = torch.Generator().manual_seed(seed)
-    C, S = 64, 17
+    C = 64
     x = torch.randn(boards, C, S, S, generator=g)
     x = torch.where(torch.rand(boards, C, S, S, generator=g) < 0.5, torch.zeros(()), x.abs())
     x[:, :8] *= 37.0
@@ -571,8 +571,14 @@ def test_split_resblock_abi_host_twin():
     z = torch.zeros(2 * 2 * 17 * 17 * 64, dtype=torch.float16)
     assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 17, 64, None, None) != 0  # y == x
     zo = z.clone()
-    assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 9, 64, None, None) != 0
+    assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 13, 64, None, None) != 0
     assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 17, 128, None, None) != 0
+    assert bnd.dll.azsp_resblock_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 9, 128, None, None) != 0
+    # the 9x9 x 64 shape (round 6) through the ABI on the twin: equals the two launches, 1 - 3 boards
+    for nb in (1, 2, 3):
+        x9, ws9, bs9 = _resblock_inputs(nb, 40 + nb, S=9)
+        yf9, y29, _ = _resblock_both_ways(bnd, x9, ws9, bs9, "cpu")
+        assert torch.equal(yf9, y29)
     assert bnd.dll.azsp_resblock_split(None, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), zo.data_ptr(), 1, 17, 64, None, None) != 0
 
 
@@ -595,6 +601,46 @@ def test_gpu_split_resblock17_bit_identical_to_two_launches(boards):
     mid = torch.relu(F.conv2d(x.double(), ws[0].double(), bs[0].double(), padding=1))
     ref = torch.relu(F.conv2d(mid, ws[1].double(), bs[1].double(), padding=1) + x.double())
     assert ((y.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("boards", [1, 2, 3, 4, 5, 511, 512, 513, 514, 1025, 2181])
+def test_gpu_split_resblock9_bit_identical_to_two_launches(boards):
+    """k_resblock_sp<Sb9> (round 6: the fused fp32-class block for 9x9 x 64, the reference's logs/go/9x9_12b64 shape; TWO boards per tile,
+    stacked with a separator row, the intermediate activation in LDS, the skip from the x image in LDS) gives bit for bit the output of
+    two k_conv3x3_sp launches.  Odd board counts exercise the unfused last board; counts around one / two / four pairs per workgroup
+    slot (256 slots) the first-tile, has-next and last-tile paths.  Also against fp64."""
+    from alpha_zero_amd import _lib
+
+    x, ws, bs = _resblock_inputs(boards, 300 + boards, S=9)
+    yf, y2, y = _resblock_both_ways(_lib.load(), x, ws, bs, "cuda")
+    if not torch.equal(yf, y2):
+        B, C, S = boards, 64, 9
+        d = (yf.view(B, 2, C // 8, S * S, 8) != y2.view(B, 2, C // 8, S * S, 8)).any(dim=4).any(dim=1)  # [B, chunk, pos]
+        bad = d.nonzero()
+        raise AssertionError(f"{len(bad)} (board, chunk, position) cells differ; first {bad[:12].tolist()}; boards {sorted(set(bad[:, 0].tolist()))[:20]}")
+    mid = torch.relu(F.conv2d(x.double(), ws[0].double(), bs[0].double(), padding=1))
+    ref = torch.relu(F.conv2d(mid, ws[1].double(), bs[1].double(), padding=1) + x.double())
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_gpu_split_resblock9_records_intermediate_overflow():
+    """The intermediate activation of the fused 9x9 block is split inside the kernel, too: a value beyond f16's range in m is recorded."""
+    import ctypes
+
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    dll = bnd.dll
+    assert dll.azsp_split_range_status(None, None, 1, None) == 0
+    x, ws, bs = _resblock_inputs(6, 77, S=9)
+    bs[0] = bs[0].clone()
+    bs[0][3] = 3.0e5  # conv1's bias pushes one channel of m beyond 65504
+    yf, y2, _ = _resblock_both_ways(bnd, x, ws, bs, "cuda")
+    ev, mx = ctypes.c_uint32(0), ctypes.c_float(0.0)
+    assert dll.azsp_split_range_status(ctypes.byref(ev), ctypes.byref(mx), 1, None) == 0
+    assert ev.value > 0 and mx.value > 65504.0 and torch.equal(yf, y2)
 
 
 @pytest.mark.gpu

@@ -11,7 +11,7 @@ CSRC = os.path.join(ROOT, "alpha_zero_amd", "csrc")
 FAMILY_SOURCES = {
     "split9": ["az_conv_sp.h", "az_conv.h"],
     "split9_64": ["az_conv_sp.h", "az_conv.h"],
-    "splitblock9_64": ["az_resblock_sp9.h", "az_conv_sp.h", "az_conv.h"],
+    "splitblock9_64": ["az_resblock_sp17.h", "az_conv_sp17.h", "az_conv_sp.h", "az_conv.h"],
     "split17": ["az_conv_sp17.h", "az_conv_sp.h", "az_conv.h"],
     "splitblock17": ["az_resblock_sp17.h", "az_conv_sp17.h", "az_conv_sp.h", "az_conv.h"],
     "tiled9": ["az_conv.h"],

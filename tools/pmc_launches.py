@@ -1,6 +1,6 @@
 """A handful of launches of ONE tower-convolution kernel family on post-ReLU-like data, for `rocprofv3 --pmc ...` / `--kernel-trace` passes.
 usage: python tools/pmc_launches.py <family> [boards]    family: split9 (k_conv3x3_sp, 9x9 x 128), split9_64, split17 (k_conv3x3_sp17,
-17x17 x 64), splitblock17 (k_resblock_sp17: one launch per ResNetBlock, 17x17 x 64), tiled9 (k_conv3x3_tiled bf16, 9x9 x 128), hb19
+17x17 x 64), splitblock17 / splitblock9_64 (k_resblock_sp: one launch per ResNetBlock, 17x17 x 64 / 9x9 x 64), tiled9 (k_conv3x3_tiled bf16, 9x9 x 128), hb19
 (k_conv3x3_hb19 bf16, 19x19 x 256, two launches per convolution).
 Launch i uses a residual when i is odd (the forward alternates plain / residual layers)."""
 import os
@@ -13,7 +13,7 @@ from alpha_zero_amd import _lib
 from alpha_zero_amd.core.network import split_weights_f16
 
 fam = sys.argv[1]
-S, C, split = {"split9": (9, 128, True), "split9_64": (9, 64, True), "split17": (17, 64, True), "splitblock17": (17, 64, True), "tiled9": (9, 128, False),
+S, C, split = {"split9": (9, 128, True), "split9_64": (9, 64, True), "splitblock9_64": (9, 64, True), "split17": (17, 64, True), "splitblock17": (17, 64, True), "tiled9": (9, 128, False),
                "hb19": (19, 256, False)}[fam]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else (4096 if fam == "hb19" else 32768)
 N = int(os.environ.get("PMC_LAUNCHES", "6"))
@@ -36,9 +36,9 @@ if split:
         assert b.dll.azsp_split_layout(t.data_ptr(), dst.data_ptr(), B, S, C, 1, None, None) == 0
         del t
     wp = split_weights_f16(w).cuda()
-    for i in range(N if fam == "splitblock17" else 0):
+    for i in range(N if fam.startswith("splitblock") else 0):
         assert b.dll.azsp_resblock_split(xs.data_ptr(), wp.data_ptr(), bias.data_ptr(), wp.data_ptr(), bias.data_ptr(), ys.data_ptr(), B, S, C, None, None) == 0
-    for i in range(0 if fam == "splitblock17" else N):
+    for i in range(0 if fam.startswith("splitblock") else N):
         assert b.dll.azsp_conv3x3_split(xs.data_ptr(), wp.data_ptr(), bias.data_ptr(), rs.data_ptr() if i % 2 else None, ys.data_ptr(), B, S, C, 1, None, None) == 0
 else:
     n = b.dll.azsp_tiled_bytes(B, S, C) // 2
