@@ -28,6 +28,7 @@ for J in "$@"; do
     probe_power) (cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o mfma_power_probe mfma_power_probe.hip) && timeout 300 ./tools/probes/mfma_power_probe $O/mfma_power_probe.json > $O/mfma_power_probe.txt 2>&1; echo "probe rc=$?" | tee -a $O/status.txt; cat $O/mfma_power_probe.txt ;;
     pmc:*) PMC_FAMILIES="${J#pmc:}" bash tools/profile_r06.sh > $O/pmc_${J#pmc:}.log 2>&1; echo "pmc ${J#pmc:} rc=$?" | tee -a $O/status.txt; tail -3 $O/pmc_${J#pmc:}.log ;;
     rocprof_bench) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rb && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rb -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-companions --no-fresh-tree --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /tmp/rb.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rb -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_default.txt 2>&1); echo "rocprof rc=$?" | tee -a $O/status.txt; head -8 $O/kernel_stats_default.txt | cut -c1-200 ;;
+    resblock_ab:*) timeout 300 python tools/resblock_ab.py ${J#resblock_ab:} 2>&1 | grep -v amdgpu.ids > $O/resblock_ab_${J#resblock_ab:}.txt; echo "resblock_ab rc=$?" | tee -a $O/status.txt; cat $O/resblock_ab_${J#resblock_ab:}.txt ;;
     conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac

@@ -1,7 +1,7 @@
 """Same-box, same-process A/B of the fused fp32-class 17x17 x 64 ResNetBlock (azsp_resblock_split, BASELINE C2's dominant kernel): the
 library in the tree against another build (default tools/probes/libazsp_prev.so = the previous version of az_resblock_sp17.h), timed
 alternately on the same post-ReLU-like activations; checks that both produce bit-identical outputs.
-usage: python tools/resblock17_ab.py [boards] [other_lib]"""
+usage: python tools/resblock17_prev_ab.py [boards] [other_lib]"""
 import ctypes
 import os
 import sys
