@@ -355,7 +355,7 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
 //     partner and runs the epilogue (bias is in wave b = 0's accumulators; residual, rounding, ReLU, store) of its own two quads.
 //     The weight rows of wave b = 1 are rotated by 16 couts so that "own quads" are registers 0-7 in both waves (compile-time indices).
 //   * the tile image holds all 32 input chunks of the half board: 123,904 B -- ONE buffer.  It is refilled on the fly: the column
-//     tiles take the half's positions in row-major order, so unit u only reads image cells [~34 u, ~34 u + 76); the strip of a chunk
+//     tiles take the half's positions in row-major order (conflict-free: C1Map), so unit u only reads image cells [~34 u, ~34 u + 76); the strip of a chunk
 //     is four DMA BANDS of 64 cells, band 0 is dead after unit 1, band 1 after unit 3, bands 2-3 after unit 5 (compile-time checked
 //     against the lane maps), and the next tile's band is DMA'd into the same cells as soon as a workgroup barrier has certified that
 //     every wave is past its last reader.  One barrier per unit does triple duty: partial-sum exchange, "band free", "band landed"
@@ -391,28 +391,37 @@ constexpr C1Map c1_make_map(int hf) {
         m.cell[i] = 0;
         m.pos[i] = 0xffff;
     }
+    // Row-major order, conflict-free: a position goes into the first of the tile's two service groups (16 lanes each) that does not hold its
+    // bank residue (cell mod 16) yet; if both do, it waits for the next column tile (at most a handful do: consecutive cells carry
+    // consecutive residues, only the zero cell at a row end shifts them).  A tile closes when it is full or 6 positions are waiting.
+    int carry[16] = {}, ncarry = 0, next = 0;
     for (int ct = 0; ct < C9_NCT; ++ct) {
-        const int lo = ct * 32, hi = n < lo + 32 ? n : lo + 32;
         bool used[2][16] = {};
         int fill[2] = {0, 0}, cmin = 1 << 20, cmax = -1;
-        bool placed[32] = {};
-        for (int pass = 0; pass < 2; ++pass)  // pass 0: into a service group that lacks the cell's residue (conflict-free); pass 1: the rest
-            for (int i = lo; i < hi; ++i) {
-                if (placed[i - lo]) continue;
-                const int p = own[i], cell = C9_CELL0 + C9_PITCH * (p / C9_S) + p % C9_S, r = cell & 15;
-                int g = -1;
-                if (!used[0][r] && fill[0] < 16) g = 0;
-                else if (!used[1][r] && fill[1] < 16) g = 1;
-                else if (pass == 1) g = fill[0] < 16 ? 0 : 1;
-                if (g < 0) continue;
-                const int idx = ct * 32 + lanes[g][fill[g]++];
-                m.cell[idx] = (unsigned short)cell;
-                m.pos[idx] = (unsigned short)p;
-                used[g][r] = true;
-                placed[i - lo] = true;
-                cmin = cell < cmin ? cell : cmin;
-                cmax = cell > cmax ? cell : cmax;
-            }
+        int wait[16] = {}, nwait = 0;
+        auto place = [&](int p) {
+            const int cell = C9_CELL0 + C9_PITCH * (p / C9_S) + p % C9_S, r = cell & 15;
+            for (int g = 0; g < 2; ++g)
+                if (!used[g][r] && fill[g] < 16) {
+                    const int idx = ct * 32 + lanes[g][fill[g]++];
+                    m.cell[idx] = (unsigned short)cell;
+                    m.pos[idx] = (unsigned short)p;
+                    used[g][r] = true;
+                    cmin = cell < cmin ? cell : cmin;
+                    cmax = cell > cmax ? cell : cmax;
+                    return true;
+                }
+            return false;
+        };
+        for (int i = 0; i < ncarry; ++i)
+            if (!place(carry[i])) wait[nwait++] = carry[i];
+        while (next < n && fill[0] + fill[1] < 32 && nwait <= 6) {
+            const int p = own[next++];
+            if (!place(p)) wait[nwait++] = p;
+        }
+        ncarry = nwait;
+        for (int i = 0; i < nwait; ++i) carry[i] = wait[i];
+        if (ct == C9_NCT - 1 && (ncarry > 0 || next < n)) ok = false;  // every position found a slot
         for (int g = 0; g < 2; ++g)  // padding slots: a cell of this column tile's own span (same bands), of a residue the group lacks if there is one
             while (fill[g] < 16) {
                 int pick = cmin;
@@ -426,6 +435,16 @@ constexpr C1Map c1_make_map(int hf) {
             }
         m.rmin[ct] = (short)(cmin - C9_CELL0);
         m.rmax[ct] = (short)(cmax + C9_CELL0);
+        for (int g = 0; g < 2; ++g) {  // every service group: 16 slots, real positions on 16 distinct bank residues
+            bool seen[16] = {};
+            if (fill[g] != 16) ok = false;
+            for (int i = 0; i < 16; ++i) {
+                const int idx = ct * 32 + lanes[g][i];
+                if (m.pos[idx] == 0xffff) continue;
+                if (seen[m.cell[idx] & 15]) ok = false;
+                seen[m.cell[idx] & 15] = true;
+            }
+        }
     }
     m.ok = ok;
     return m;

@@ -29,6 +29,11 @@ for J in "$@"; do
     pmc:*) PMC_FAMILIES="${J#pmc:}" bash tools/profile_r06.sh > $O/pmc_${J#pmc:}.log 2>&1; echo "pmc ${J#pmc:} rc=$?" | tee -a $O/status.txt; tail -3 $O/pmc_${J#pmc:}.log ;;
     rocprof_bench) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rb && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rb -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-companions --no-fresh-tree --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> /tmp/rb.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rb -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_default.txt 2>&1); echo "rocprof rc=$?" | tee -a $O/status.txt; head -8 $O/kernel_stats_default.txt | cut -c1-200 ;;
     resblock_ab:*) timeout 300 python tools/resblock_ab.py ${J#resblock_ab:} 2>&1 | grep -v amdgpu.ids > $O/resblock_ab_${J#resblock_ab:}.txt; echo "resblock_ab rc=$?" | tee -a $O/status.txt; cat $O/resblock_ab_${J#resblock_ab:}.txt ;;
+    soak) timeout 900 python tools/soak.py 1500 go 9 4096 fp32 > $O/soak_go9_fp32class_1500rounds.json 2> $O/soak_go9.err; echo "soak go9 rc=$?" | tee -a $O/status.txt
+          timeout 900 python tools/soak.py 1500 go 9 4096 fp32 12 64 > $O/soak_go9_12b64_fp32class_1500rounds.json 2> $O/soak_12b64.err; echo "soak 12b64 rc=$?" | tee -a $O/status.txt
+          timeout 900 python tools/soak.py 1200 gomoku 13 4096 fp32 > $O/soak_gomoku13_fp32class_1200rounds.json 2> $O/soak_gomoku.err; echo "soak gomoku rc=$?" | tee -a $O/status.txt
+          timeout 900 python tools/soak.py 600 go 19 1024 bf16 20 256 800 > $O/soak_go19_c5_bf16_600rounds.json 2> $O/soak_go19.err; echo "soak go19 rc=$?" | tee -a $O/status.txt
+          tail -n 1 $O/soak_*.json | cut -c1-600 ;;
     conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac
