@@ -478,7 +478,8 @@ def tower_roofline(conv, args, step_ms):
     if ceil:
         roofline["frac_of_issue_ceiling"] = round(issued_tf / ceil["issue_ceiling_tflops"], 4)
         roofline["instruction_form_ceiling"] = round(ceil["issue_ceiling_tflops"] / peak, 4)
-        if pj is not None and pj.get("cycles_per_mfma") and pj.get("gpu_cycles_per_launch_mean") and pj.get("rows"):
+        if (pj is not None and pj.get("cycles_per_mfma") and pj.get("gpu_cycles_per_launch_mean") and pj.get("rows")
+                and pj.get("board") == n and pj.get("channels") == args.filters):  # (a pass of THIS kernel shape only)
             issue_cycles = ceil["pipe_cycles_per_mfma_at_peak"] / (ceil["issue_ceiling_tflops"] / peak)  # cycles between two issues of the form at its ceiling
             roofline["cycles_per_mfma"] = pj["cycles_per_mfma"]
             roofline["issue_efficiency"] = round(issue_cycles / pj["cycles_per_mfma"], 4)
