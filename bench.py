@@ -488,7 +488,12 @@ def tower_roofline(conv, args, step_ms):
             clk = pj["gpu_cycles_per_launch_mean"] * rows / pj["rows"] / (conv["avg_ms"] * 1e-3) / 1e9
             roofline["effective_clock_GHz"] = round(clk, 4)
             roofline["clock_fraction"] = round(clk / MFMA_PEAK_CLOCK_GHZ, 4)
-            roofline["decomposition_product"] = round(roofline["instruction_form_ceiling"] * roofline["issue_efficiency"] * roofline["clock_fraction"], 4)
+            # MFMAs the kernel issues per MFMA the algorithm needs (halo rows recomputed by the fused 17x17 block, padding slots of the column
+            # tiles): the counters see the former, `frac` counts the latter
+            flop_per_mfma = 2.0 * 16 * 16 * 32  # = 2 * 32 * 32 * 16: both instruction forms
+            over = (pj.get("SQ_INSTS_MFMA") or 0) * rows / pj["rows"] * flop_per_mfma / (issued_tf * conv["avg_ms"] * 1e-3 * 1e12)
+            roofline["issued_over_algorithmic_mfma"] = round(over, 4) if over > 0 else None
+            roofline["decomposition_product"] = round(roofline["instruction_form_ceiling"] * roofline["issue_efficiency"] * roofline["clock_fraction"] / (over if over > 0 else 1.0), 4)
             roofline["decomposition_source"] = ("from_profiles: profiles/" + cname + " (SQ_INSTS_MFMA, GRBM_GUI_ACTIVE / 8 XCDs and the launch time of the same passes: "
                                                 "cycles per MFMA; effective clock = those cycles / this run's launch time; " + ("STALE" if cstale else "kernel sources unchanged" if cstale is False else "no source digest") + ")")
     roofline.update(extra)
