@@ -157,3 +157,43 @@ def check_dihedral(kind):
         T.apply_vertical_flip(torch.zeros(1, 3, 9, 9).to(dev), torch.zeros(1, 80).to(dev), binding=b)
     x, y, z = T.apply_random_transformation(torch.zeros(2, 3, 9, 9).to(dev), torch.zeros(2, 82).to(dev), torch.zeros(2).to(dev), binding=b)
     assert x.shape == (2, 3, 9, 9) and y.shape == (2, 82) and z.shape == (2,)
+
+
+def check_dropin_step_equals_the_separate_entries(kind, G=3, P=4, n=5, sims=24, steps=40):
+    """azsp_dropin_step (one fused launch, page-locked staging) against the separate entries it replaces (azsp_select / azsp_expand_backup /
+    azsp_get_status + tensor copies) on two engines with the same seed and the same evaluator outputs: identical status, Q, valid flags
+    and observation planes after every step, for G > 1 games (per-game packing of the read-back)."""
+    from alpha_zero_amd import _abi
+    from alpha_zero_amd.core.engine import Engine, EngineConfig
+
+    b, dev = eu.backend(kind)
+    mk = lambda: Engine(b, EngineConfig(game="go", board_size=n, num_games=G, num_parallel=P, num_simulations=sims, stop_after_move=True,  # noqa: E731
+                                        feature_dtype=_abi.FEAT_I8, root_noise=False, seed=5), device=dev)
+    ea, eb = mk(), mk()
+    A, rows = ea.A, ea.rows
+    rng = np.random.Generator(np.random.PCG64(11))
+    for e in (ea, eb):
+        e.reset_games()
+        e.begin_move(None, warm_up=1)
+    # reference sequence: select, then per step: status / valid / features read-back, upload, round
+    eb.select()
+    st_a, q_a, valid_a, obs_a = ea.dropin_step(None, None)
+    for it in range(steps):
+        st_b, q_b = eb.status()
+        valid_b = eb.valid.cpu().numpy().astype(bool)
+        obs_b = eb.features.cpu().numpy()
+        assert np.array_equal(st_a, st_b) and np.array_equal(q_a, q_b), (it, st_a, st_b)
+        assert np.array_equal(valid_a, valid_b) and np.array_equal(obs_a, obs_b), it
+        if (st_a[:, 0] == _abi.ST_MOVE_DONE).all():
+            break
+        pri = rng.random((rows, A)).astype(np.float32)
+        pri /= pri.sum(axis=1, keepdims=True)
+        val = (rng.random(rows).astype(np.float32) * 2 - 1)
+        eb.priors.copy_(torch.from_numpy(pri))
+        eb.values.copy_(torch.from_numpy(val))
+        eb.round()
+        st_a, q_a, valid_a, obs_a = ea.dropin_step(pri, val)
+    else:
+        raise AssertionError("the searches did not finish")
+    pa, pb = ea.get_search(1, 0), eb.get_search(1, 0)
+    assert all(np.array_equal(x, y) for x, y in zip(pa, pb))

@@ -20,3 +20,7 @@ def test_search_errors():
 
 def test_dihedral():
     dc.check_dihedral("host")
+
+
+def test_dropin_step_equals_the_separate_entries():
+    dc.check_dropin_step_equals_the_separate_entries("host")

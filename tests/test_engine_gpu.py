@@ -106,6 +106,12 @@ def test_gpu_search_errors():
     dc.check_search_errors("gpu")
 
 
+def test_gpu_dropin_step_equals_the_separate_entries():
+    """azsp_dropin_step on the device: the kernel reads the evaluator outputs from, and writes status / valid flags / observation planes
+    to, page-locked host memory directly -- identical to select / expand_backup / get_status + copies, for three games at once."""
+    dc.check_dropin_step_equals_the_separate_entries("gpu")
+
+
 def test_gpu_dihedral():
     dc.check_dihedral("gpu")
 
