@@ -798,10 +798,13 @@ def main(argv=None):
             c1["value"], c1["per_core"] = round(c1["value"], 3), round(c1["per_core"], 4)
             c1["config"] = "BASELINE C1: 13x13 Gomoku, uct_search, 1 CPU self-play actor, 100 sims/move (reference path, no GPU)"
             # the same port on the shape of the checkpoint C1 names (10 x 40), and the kept entry point on the GPU engine beside it
-            c1b = baseline.run(1, seconds=min(8.0, args.cpu_seconds), game="gomoku", n=13, sims=100, P=1, blocks=10, filters=40, stagger=0)
+            ck = os.path.join(ROOT, "tests", "golden", "gomoku13_ckpt200000_network.pt")  # the same trained weights c1_dropin evaluates
+            c1b = baseline.run(1, seconds=min(8.0, args.cpu_seconds), game="gomoku", n=13, sims=100, P=1, blocks=10, filters=40, stagger=0, fc=80,
+                               ckpt=ck if os.path.exists(ck) else None)
             try:
                 c1d = c1_dropin(seconds=min(8.0, args.cpu_seconds))
                 c1d["cpu_port_moves_per_s_10x40"] = round(c1b["value"], 3)
+                c1d["cpu_port_sample"] = c1b["sample"]
                 c1d["cpu_eval_func_over_cpu_port"] = round(c1d["cpu_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
                 c1d["device_eval_func_over_cpu_port"] = round(c1d["device_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
             except Exception as ex:  # the companion must never take the headline down

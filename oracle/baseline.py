@@ -14,7 +14,7 @@ import time
 
 
 def _worker(args):
-    (idx, game, n, sims, P, blocks, filters, seconds, stagger, seed) = args
+    (idx, game, n, sims, P, blocks, filters, seconds, stagger, seed, fc, ckpt) = args
     os.environ["OMP_NUM_THREADS"] = "1"
     import numpy as np
     import torch
@@ -26,7 +26,9 @@ def _worker(args):
 
     torch.manual_seed(1)
     A = n * n + (1 if game == "go" else 0)
-    net = AlphaZeroNet((17, n, n), A, blocks, filters, filters, gomoku=(game != "go")).eval()
+    net = AlphaZeroNet((17, n, n), A, blocks, filters, fc or filters, gomoku=(game != "go")).eval()
+    if ckpt:  # trained weights (e.g. the golden copy of the reference's shipped checkpoint): the same network the compared run evaluates
+        net.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=True)["network"], strict=True)
     np.random.seed(seed + idx)
     rng = np.random.Generator(np.random.PCG64(seed + idx))
 
@@ -65,12 +67,12 @@ def _worker(args):
     return moves, time.time() - t0
 
 
-def run(cores, seconds=20.0, game="go", n=9, sims=200, P=8, blocks=10, filters=128, stagger=60, seed=1):
+def run(cores, seconds=20.0, game="go", n=9, sims=200, P=8, blocks=10, filters=128, stagger=60, seed=1, fc=None, ckpt=None):
     ctx = mp.get_context("spawn")
-    args = [(i, game, n, sims, P, blocks, filters, seconds, stagger, seed) for i in range(cores)]
+    args = [(i, game, n, sims, P, blocks, filters, seconds, stagger, seed, fc, ckpt) for i in range(cores)]
     with ctx.Pool(cores) as pool:
         res = pool.map(_worker, args)
     total = sum(m / t for m, t in res)
     return dict(value=total, unit="moves/s", cores=cores, kind="port", per_core=total / cores,
                 sample=f"{cores} actor processes x {seconds:.0f}s, {game} {n}x{n}, {sims} sims, P={P}, {blocks}x{filters} fp32 net, "
-                       f"{sum(m for m, _ in res)} moves")
+                       f"{sum(m for m, _ in res)} moves" + (f", weights {os.path.basename(ckpt)}" if ckpt else ", random init"))
