@@ -345,7 +345,7 @@ def evaluator_range(actor):
         return None
     ev, mx = inf.split_range_status(reset=True)
     return {"events": ev + actor.range_events, "largest_abs": max(mx * 2.0 ** inf.act_shift, actor.range_max_abs), "act_shift": inf.act_shift,
-            "calibrated_max_abs": round(inf.act_max_abs, 4), "rescales_during_run": actor.range_rescales,
+            "calibrated_max_abs": round(inf.act_max_abs, 4), "rescales_during_run": actor.range_rescales, "games_in_a_clamp_window": actor.clamped_games,
             "fallback": inf.split_fallback_reason or None}
 
 
