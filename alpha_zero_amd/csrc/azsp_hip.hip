@@ -11,6 +11,7 @@
 #include "az_conv_sp.h"
 #include "az_conv_sp17.h"
 #include "az_resblock_sp17.h"
+#include "az_conv_sp2.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -339,7 +340,25 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
     if (S == Sp17Geo::S && C == 64)  // 17x17 planes x 64 filters: the 13x13 Gomoku tower (half-board tiles)
         return res ? launch_sp17<true, 8>(x, w, bias, res, y, boards, relu, st, range) : launch_sp17<false, 8>(x, w, bias, res, y, boards, relu, st, range);
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
-    if (C == 128) return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st, range);
+    if (C == 128) {
+        // 9x9 x 128: k_conv3x3_sp2, the 2 x 2 split of a CU's work between its waves (round 6, az_conv_sp2.h: half the LDS fragment reads per MFMA);
+        // AZSP_SP1 (read once per process) selects rounds 3-5's k_conv3x3_sp for same-box A/B runs
+        static const bool sp1 = getenv("AZSP_SP1") != nullptr;
+        if (!sp1) {
+            const int n_cu = cu_count();
+            if (n_cu < 0) return -1;
+            long long nslot = n_cu / 2 > 0 ? n_cu / 2 : 1;
+            if (boards < nslot) nslot = boards;
+            if (res)
+                hipLaunchKernelGGL((k_conv3x3_sp2<true>), dim3((unsigned)(nslot * 2)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
+                                   (const unsigned char*)res, (unsigned char*)y, (int)boards, relu, range);
+            else
+                hipLaunchKernelGGL((k_conv3x3_sp2<false>), dim3((unsigned)(nslot * 2)), dim3(CW_THREADS), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
+                                   (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu, range);
+            return AZ_HIP(hipGetLastError());
+        }
+        return res ? launch_sp<true, 16, 2>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 16, 2>(x, w, bias, res, y, boards, relu, st, range);
+    }
     return res ? launch_sp<true, 8, 1>(x, w, bias, res, y, boards, relu, st, range) : launch_sp<false, 8, 1>(x, w, bias, res, y, boards, relu, st, range);
 }
 // scratch for the intermediate activation of ONE 9x9 x 64 board: the odd last board of azsp_resblock_split at 9x9 runs as two unfused

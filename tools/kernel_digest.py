@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, "alpha_zero_amd", "csrc")
 
 # family (tools/pmc_launches.py) -> the headers whose text decides the kernel's code (the shared MFMA / epilogue helpers included)
 FAMILY_SOURCES = {
-    "split9": ["az_conv_sp.h", "az_conv.h"],
+    "split9": ["az_conv_sp2.h", "az_conv_sp.h", "az_conv.h"],
     "split9_64": ["az_conv_sp.h", "az_conv.h"],
     "splitblock9_64": ["az_resblock_sp17.h", "az_conv_sp17.h", "az_conv_sp.h", "az_conv.h"],
     "split17": ["az_conv_sp17.h", "az_conv_sp.h", "az_conv.h"],
