@@ -440,8 +440,9 @@ def tower_roofline(conv, args, step_ms):
                      "pairs, three f16 MFMA products per multiply, fp32 accumulation; intermediate activation in LDS, skip from the x image in LDS)")
             elem, passes = 4, 2.0  # x in, y out
         else:
-            kname = ("k_conv3x3_sp" if S_t == 9 else "k_conv3x3_sp17") + (" (split-precision 3x3 convolution of the residual tower: hi + lo f16 pairs, "
-                                                                         "three f16 MFMA products per multiply, fp32 accumulation; weight-stationary)")
+            kname = (("k_conv3x3_sp2" if args.filters == 128 else "k_conv3x3_sp") if S_t == 9 else "k_conv3x3_sp17") + (
+                " (split-precision 3x3 convolution of the residual tower: hi + lo f16 pairs, three f16 MFMA products per multiply, fp32 accumulation; "
+                "weight-stationary" + ("; 2 x 2 split of a CU's work between its waves: 32 couts x half of cin per wave, fp32 hand-over through LDS)" if S_t == 9 and args.filters == 128 else ")"))
             elem, passes = 4, 2.5  # hi + lo f16 = 4 bytes per activation element; x in, y out, residual on every second layer
         extra = {"mfma_products_per_multiply": SPLIT_PRODUCTS, "alg_flops_per_launch": conv_flops, "issued_f16_mfma_flops_per_launch": issued,
                  "fp32_equivalent_tflops": round(conv_flops / (conv["avg_ms"] * 1e-3) / 1e12, 2), "fp32_mfma_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
