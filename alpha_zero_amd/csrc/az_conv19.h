@@ -373,7 +373,7 @@ k_conv3x3_hb19(const unsigned char* __restrict__ x, const unsigned short* __rest
 #define C1_XB_WAVE 2048                    // exchange: 2 quads x 64 lanes x 16 B per wave
 #define C1_XB (2 * 4 * C1_XB_WAVE)         // [unit parity][wave]
 #define C1_NBAND 4
-#define C1_VARIANT 0
+#define C1_VARIANT 8  // 8 = k_conv3x3_op19q (the four-way cin split, below); 0 = k_conv3x3_op19; 6 = its counted-lgkmcnt / later-barrier build
 
 struct C1Map {
     unsigned short cell[C9_NCT * 32], pos[C9_NCT * 32];  // pos: tile-relative (row * 19 + col), 0xffff = computed, never stored
@@ -753,6 +753,286 @@ k_conv3x3_op19(const unsigned char* __restrict__ x, const unsigned short* __rest
         xwrite(lset, 0);
         xwrite(lset, 1);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]));  // the last unit's addends
+        CV_BARRIER();
+#pragma unroll
+        for (int o = 0; o < SC::NRID; ++o) rider(lset, NU - 1, yprev, o, true);
+    }
+}
+// =====================================================================================================================================
+// k_conv3x3_op19q<ADD> (round 6, second step) -- the one-pass kernel with the CU's 64 couts x 256 cin split FOUR ways along cin: wave w holds
+// all 64 couts (two 32-cout tiles) x the cin QUARTER w.  In k_conv3x3_op19 the waves (0, b) and (1, b) read the same B fragments (one
+// fragment per 32-cycle MFMA); here a fragment is read by one wave and feeds TWO MFMAs: half the LDS fragment reads per flop -- the change
+// that bought the 9x9 x 128 kernel 4 % (k_conv3x3_sp2: at the package power limit the reads that are no longer made come back as clock).
+//   * every output is the sum of four partials: a wave finalises 2 of the 8 register quads (16 couts) and hands the other 6 to their owners
+//     through a single 24 KB buffer [destination wave][source][quad][lane]: 6 ds_write_b128 + 6 ds_read_b128 + 24 v_add_f32 per unit (op19: 2 +
+//     2 + 8).  Weight rows are rotated per wave so that the own quads are registers 0-7 of tile 0 in every wave; the bias enters through the
+//     owner's accumulators only.
+//   * two barriers per unit: F in front of the hand-over writes (every wave is past the previous unit, i.e. past its reads of the previous
+//     hand-over: the buffer is single) and B in front of the reads (= op19's barrier: band free / band landed / partials written).
+//   * a slot is one MFMA (72 per unit), a k-step (one fragment) is two slots; everything else -- image, bands, DMA schedule, lane maps,
+//     counted vector-memory waits -- is k_conv3x3_op19's.
+template <bool ADD> struct C1QSched {
+    static constexpr int NSTEP = 72, NKS = 36, NU = C9_NCT, R = 4;  // MFMA slots / k-steps per unit, ring slots (k-steps)
+    static constexpr int S0 = 5;             // barrier F in front of slot S0, the 6 hand-over writes in the slots S0 .. S0 + 5
+    static constexpr int SB = 12;            // barrier B in front of slot SB
+    static constexpr int OPS = ADD ? 9 : 5;
+    static constexpr int NRID = 3 * 10 + 2 * OPS;  // per source: 2 reads + 8 adds; then per own quad OPS epilogue micro-ops
+    static constexpr int store_slot(int q) { return SB + 1 + 30 + (q + 1) * OPS - 1; }
+    static constexpr int addend_use_slot(int q) { return SB + 1 + 30 + q * OPS; }
+    static constexpr int NPIECE = 8;
+    static constexpr int dma_slot(int i) { return SB + 2 + 2 * i; }
+    static constexpr bool dma_unit(int u) { return u == 0 || u == 1 || u == 2 || u == 4; }
+    static constexpr int rider_vm(int t) {
+        int n = 0;
+        for (int q = 0; q < 2; ++q)
+            if (t == store_slot(q)) n += ADD ? 2 : 1;
+        return n;
+    }
+    static constexpr bool dma_at(int u, int t) {
+        for (int i = 0; i < NPIECE; ++i)
+            if (dma_unit(u) && t == dma_slot(i)) return true;
+        return false;
+    }
+    static constexpr int vm_ops(int u, int t) { return rider_vm(t) + (dma_at(u, t) ? 1 : 0); }
+    static constexpr int vm_between(int ui, int uw) {
+        int n = 0;
+        for (int t = dma_slot(NPIECE - 1) + 1; t < NSTEP; ++t) n += vm_ops(ui, t);
+        for (int u = ui + 1; u < uw; ++u)
+            for (int t = 0; t < NSTEP; ++t) n += vm_ops(u, t);
+        for (int t = 0; t < SB; ++t) n += vm_ops(uw, t);
+        return n;
+    }
+    static constexpr int vm_after_addend(int u, int q) {
+        const int pu = (u + NU - 1) % NU;
+        int n = dma_at(pu, store_slot(q)) ? 1 : 0;
+        for (int t = store_slot(q) + 1; t < NSTEP; ++t) n += vm_ops(pu, t);
+        for (int t = 0; t < addend_use_slot(q); ++t) n += vm_ops(u, t);
+        return n;
+    }
+    static_assert(SB + 1 + NRID < NSTEP - 3 && S0 + 6 < SB && dma_slot(NPIECE - 1) < NSTEP - 4, "slot layout");
+    static_assert((NU * NKS) % R == 0, "a tile's k-steps keep the ring phase");
+    static_assert(vm_between(0, 1) < 63 && vm_between(1, 3) < 63 && vm_between(4, 5) < 63 && vm_after_addend(0, 0) < 63 && vm_after_addend(3, 1) < 63, "vmcnt field");
+    static_assert(addend_use_slot(0) + 3 < store_slot(0) && addend_use_slot(1) + 3 < store_slot(1) && addend_use_slot(1) > store_slot(0), "an addend register is re-loaded after its last use");
+};
+#define C1Q_XB (4 * 3 * 2048)  // hand-over buffer: [destination wave][source 0..2][quad j][lane] 16 B
+
+template <bool ADD> __global__ void __launch_bounds__(CW_THREADS, 1)
+k_conv3x3_op19q(const unsigned char* __restrict__ x, const unsigned short* __restrict__ w, const float* __restrict__ bias, const unsigned char* add,
+                unsigned char* y, int nboards, int relu) {
+    typedef C1QSched<ADD> SC;
+    constexpr int NSTEP = SC::NSTEP, NKS = SC::NKS, R = SC::R, NU = SC::NU, SB = SC::SB;
+    constexpr int OTILE = 32 * C9_GBLK;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[C1_IMG + C1Q_XB];
+    __shared__ __attribute__((aligned(64))) float bias_lds[4 * 2 * 32];  // [wave][lane half][16 floats: own bias in 0-7, zeros in 8-15 | 16 zeros]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    for (int i = tid; i < (C1_IMG + C1Q_XB) / 16; i += CW_THREADS) *(cv_u32x4*)(lds + i * 16) = (cv_u32x4){0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int bi = (int)blockIdx.x, nst = (int)gridDim.x >> 3;
+    int s, role;
+    if ((gridDim.x & 63u) == 0u) {
+        s = (bi & 7) + 8 * (bi >> 6);
+        role = (bi >> 3) & 7;
+    } else {
+        s = bi >> 3;
+        role = bi & 7;
+    }
+    const int cg = role >> 1, hf = role & 1, r0 = hf * 9;
+
+    // A fragments: tile index tt = cout tile (tt + (wave >> 1)) & 1 of the CU's two, rows rotated by 16 (wave & 1): the wave's OWN 16 couts
+    // (64 cg + 16 wave ..) are rows 0-15 of tile index 0; cin quarter `wave`; fragment (tt, k-step ks = tap * 4 + kk) at wf[tt * 36 + ks]
+    cv_bf16x8 wf[NSTEP];
+#pragma unroll
+    for (int f = 0; f < NSTEP; ++f) {
+        const int tt = f / NKS, ks = f % NKS;
+        const int crow = cg * 64 + ((tt + (wave >> 1)) & 1) * 32 + ((l31 + 16 * (wave & 1)) & 31);
+        wf[f] = *(const cv_bf16x8*)(w + ((size_t)((ks / 4) * 256 + crow)) * 256 + wave * 64 + ((ks % 4) * 2 + hi) * 8);
+    }
+    if (lane < 32) {
+        const int i = lane & 15, h = lane >> 4;
+        bias_lds[(wave * 2 + h) * 32 + i] = i < 8 ? bias[cg * 64 + wave * 16 + 8 * (i >> 2) + 4 * h + (i & 3)] : 0.0f;
+        bias_lds[(wave * 2 + h) * 32 + 16 + i] = 0.0f;
+    }
+    const cv_f32x16* bias_ptr = (const cv_f32x16*)(bias_lds + (wave * 2 + hi) * 32);
+    const unsigned lo16 = relu ? 0u : 0x80008000u;
+
+    unsigned dsrc[C1_NBAND];
+    unsigned long long dmask[C1_NBAND];
+#pragma unroll
+    for (int j = 0; j < C1_NBAND; ++j) {
+        const int dcell = j * 64 + lane, dk = dcell - 1, drs = dk / C9_PITCH, dxx = dk - drs * C9_PITCH, drow = r0 - 1 + drs;
+        const bool dok = dcell >= 1 && dcell < C9_CELLS - 1 && dxx < C9_S && drow >= 0 && drow < C9_S;
+        dsrc[j] = dok ? (unsigned)((drow * C9_S + dxx) * 16) : 0u;
+        dmask[j] = __builtin_amdgcn_ballot_w64(dok);
+    }
+    auto dma_piece = [&](const unsigned char* src, bool live, int j, int i) {
+        const int c = wave + 4 * i;
+        const unsigned long long base = (unsigned long long)(src + (size_t)c * C9_GBLK);
+        const unsigned long long mask = live ? dmask[j] : 0ull;
+        const unsigned dst = lds0 + (unsigned)(c * C9_LBLK + j * 1024);
+        asm volatile("s_mov_b64 exec, %0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, -1"
+                     :
+                     : "s"(mask), "s"(dst), "v"(dsrc[j]), "s"(base)
+                     : "memory");
+    };
+    unsigned lmap[C9_NCT];
+#pragma unroll
+    for (int ct = 0; ct < C9_NCT; ++ct) {
+        const unsigned tp = c1_maps[hf].pos[ct * 32 + l31];
+        const unsigned gp = tp != 0xffffu ? tp + (unsigned)(r0 * C9_S) : 0xffffu;
+        lmap[ct] = (unsigned)((c1_maps[hf].cell[ct * 32 + l31] - C9_CELL0) * 16 + hi * C9_LBLK) | (gp << 16);
+    }
+    unsigned long long smask[C9_NCT];
+#pragma unroll
+    for (int ct = 0; ct < C9_NCT; ++ct) smask[ct] = __builtin_amdgcn_ballot_w64((lmap[ct] >> 16) != 0xffffu);
+    auto store8 = [&](unsigned char* base, unsigned voff, unsigned a, unsigned b2, unsigned long long mask) {
+        const cv_u32x2 d = (cv_u32x2){a, b2};
+        asm volatile("s_mov_b64 exec, %0\n\tglobal_store_dwordx2 %1, %2, %3\n\ts_mov_b64 exec, -1" : : "s"(mask), "v"(voff), "v"(d), "s"(base) : "memory");
+    };
+    const unsigned char* Xw = lds + wave * (8 * C9_LBLK);  // this wave's cin quarter of the image: chunks 8 wave .. 8 wave + 7
+    cv_bf16x8 bb[R];
+    auto load_step = [&](const unsigned char* p0, int ks, int slot) {
+        const int tap = ks / 4, kk = ks % 4;
+        bb[slot] = *(const cv_bf16x8*)(p0 + ((tap / 3) * C9_PITCH + (tap % 3)) * 16 + kk * (2 * C9_LBLK));
+    };
+    unsigned char* const xb = lds + C1_IMG + lane * 16;
+
+    if (s < nboards) {
+        const unsigned char* src = x + (size_t)s * OTILE;
+#pragma unroll
+        for (int j = 0; j < C1_NBAND; ++j)
+#pragma unroll
+            for (int i = 0; i < SC::NPIECE; ++i) dma_piece(src, true, j, i);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CV_BARRIER();
+#pragma unroll
+    for (int st = 0; st < R - 1; ++st) load_step(Xw + (lmap[0] & 0xffffu), st, st);
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) {
+        if (t < 64) asm volatile("" : : "a"(wf[t]));
+        else asm volatile("" : : "v"(wf[t]));
+    }
+
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    cv_f32x16 acc[2][2];  // [accumulator set = unit parity][tile index]
+    cv_u32x2 rr[2];
+    f32x4 xr[2];
+    acc[0][0] = acc[1][0] = bias_ptr[0];
+    acc[0][1] = acc[1][1] = bias_ptr[1];
+    rr[0] = rr[1] = (cv_u32x2){0u, 0u};
+    xr[0] = xr[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float ev[4];
+    unsigned epa = 0, epb = 0;
+    // hand-over write o (0..5) of set `set`: destination d = wave ^ (o / 2 + 1), its source slot (d ^ wave) - 1 = o / 2; quad j = o % 2.
+    // to wave ^ 1: tile 0 registers 8-15; to wave ^ 2: tile 1 registers 0-7; to wave ^ 3: tile 1 registers 8-15
+    auto xwrite = [&](int set, int o) {
+        const int sidx = o >> 1, j = o & 1, d = wave ^ (sidx + 1);
+        const int tt = sidx == 0 ? 0 : 1, r8 = (sidx == 1 ? 0 : 8) + 4 * j;
+        *(f32x4*)(xb + d * 6144 + sidx * 2048 + j * 1024) = (f32x4){acc[set][tt][r8 + 0], acc[set][tt][r8 + 1], acc[set][tt][r8 + 2], acc[set][tt][r8 + 3]};
+    };
+    auto rider = [&](int set, int ct, unsigned char* out, int o, bool store_ok) {
+        if (o < 30) {
+            const int sidx = o / 10, k = o % 10;
+            if (k < 2) {
+                xr[k] = *(const f32x4*)(xb + wave * 6144 + sidx * 2048 + k * 1024);
+            } else {
+                const int e = k - 2;
+                acc[set][0][e] = cw_add_f32(acc[set][0][e], xr[e >> 2][e & 3]);
+            }
+            return;
+        }
+        const int q = (o - 30) / SC::OPS, op = (o - 30) % SC::OPS;
+        if (ADD) {
+            if (op == 0) ev[0] = cw_add_f32(acc[set][0][q * 4 + 0], cv_bf16_lo(rr[q].x));
+            else if (op == 1) ev[1] = cw_add_f32(acc[set][0][q * 4 + 1], cv_bf16_hi(rr[q].x));
+            else if (op == 2) ev[2] = cw_add_f32(acc[set][0][q * 4 + 2], cv_bf16_lo(rr[q].y));
+            else if (op == 3) ev[3] = cw_add_f32(acc[set][0][q * 4 + 3], cv_bf16_hi(rr[q].y));
+            else if (op == 4) epa = cw_pk_bf16(ev[0], ev[1]);
+            else if (op == 5) epb = cw_pk_bf16(ev[2], ev[3]);
+        } else {
+            if (op == 0) epa = cw_pk_bf16(acc[set][0][q * 4 + 0], acc[set][0][q * 4 + 1]);
+            else if (op == 1) epb = cw_pk_bf16(acc[set][0][q * 4 + 2], acc[set][0][q * 4 + 3]);
+        }
+        if (op == SC::OPS - 3) epa = cw_pk_max_i16(epa, lo16);
+        else if (op == SC::OPS - 2) epb = cw_pk_max_i16(epb, lo16);
+        else if (op == SC::OPS - 1) {
+            unsigned lm = lmap[ct];
+            asm volatile("" : "+v"(lm));
+            store8(out, (unsigned)(q * C9_GBLK) + (lm >> 16) * 16u + (unsigned)(hi * 8), epa, epb, store_ok ? smask[ct] : 0ull);
+        }
+    };
+
+    int it = 0;
+    unsigned char* yprev = y;
+    for (int board = s; board < nboards; board += nst, ++it) {
+        const bool has_next = board + nst < nboards, have_prev = it > 0;
+        const unsigned char* csrc = x + (size_t)board * OTILE;
+        const unsigned char* nsrc = x + (size_t)(has_next ? board + nst : board) * OTILE;
+        const size_t obase = (size_t)board * OTILE + (size_t)(cg * 8 + wave * 2) * C9_GBLK;  // the own 16 couts = chunks 2 wave, 2 wave + 1 of the CU's eight
+        const unsigned char* abase = ADD ? add + obase : nullptr;
+        unsigned char* ybase = y + obase;
+        cp_for_each([&](auto UC) __attribute__((always_inline)) {
+            constexpr int u = decltype(UC)::value, set = u & 1, pset = set ^ 1;
+            constexpr int pct = (u + NU - 1) % NU;
+            unsigned char* pout = u == 0 ? yprev : ybase;
+            const bool pstore = u > 0 || have_prev;
+            const unsigned char* b0 = Xw + (lmap[u] & 0xffffu);
+            const unsigned char* nb0 = Xw + (lmap[(u + 1) % NU] & 0xffffu);
+            cp_for_each([&](auto TC) __attribute__((always_inline)) {
+                constexpr int t = decltype(TC)::value, ks = t >> 1, tt = t & 1;
+                if constexpr (t == SC::S0) CV_BARRIER();  // F: every wave is past the previous unit and its reads of the previous hand-over
+                if constexpr (t == SB) {
+                    if constexpr (u == 1 || u == 3 || u == 5) {
+                        constexpr int N = u == 1 ? SC::vm_between(0, 1) : u == 3 ? SC::vm_between(1, 3) : SC::vm_between(4, 5);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+                    }
+                    CV_BARRIER();  // B: partials written, band free / landed (k_conv3x3_op19's barrier)
+                }
+                if constexpr (tt == 0) {  // one fragment per k-step, R - 1 k-steps ahead
+                    if constexpr (ks + R - 1 < NKS) load_step(b0, ks + R - 1, (u * NKS + ks + R - 1) % R);
+                    else load_step(nb0, ks + R - 1 - NKS, (u * NKS + ks + R - 1) % R);
+                }
+                if constexpr (tt * NKS + ks < 64) cw_mfma_a(acc[set][tt], wf[tt * NKS + ks], bb[(u * NKS + ks) % R]);
+                else cw_mfma_v(acc[set][tt], wf[tt * NKS + ks], bb[(u * NKS + ks) % R]);
+                if constexpr (t >= SC::S0 && t < SC::S0 + 6) xwrite(pset, t - SC::S0);
+                if constexpr (ADD) {
+                    if constexpr (t == SC::addend_use_slot(0)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr[0]) : "n"(SC::vm_after_addend(u, 0)));
+                    if constexpr (t == SC::addend_use_slot(1)) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rr[1]) : "n"(SC::vm_after_addend(u, 1)));
+                }
+                if constexpr (t > SB && t - SB - 1 < SC::NRID) rider(pset, pct, pout, t - SB - 1, pstore);
+                if constexpr (ADD) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (t == SC::store_slot(q)) {
+                            unsigned lm = lmap[u];
+                            asm volatile("" : "+v"(lm));
+                            const unsigned gp = lm >> 16;
+                            const unsigned voff = (unsigned)(q * C9_GBLK) + (gp == 0xffffu ? 0u : gp) * 16u + (unsigned)(hi * 8);
+                            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(rr[q]) : "v"(voff), "s"(abase) : "memory");
+                        }
+                }
+                if constexpr (SC::dma_unit(u) && t >= SC::dma_slot(0) && t <= SC::dma_slot(SC::NPIECE - 1) && (t - SC::dma_slot(0)) % 2 == 0) {
+                    constexpr int i = (t - SC::dma_slot(0)) / 2;
+                    if constexpr (u == 0) dma_piece(csrc, have_prev, 2, i);
+                    else if constexpr (u == 1) dma_piece(csrc, have_prev, 3, i);
+                    else if constexpr (u == 2) dma_piece(nsrc, has_next, 0, i);
+                    else dma_piece(nsrc, has_next, 1, i);
+                }
+                if constexpr (t == NSTEP - 2) acc[pset][0] = bias_ptr[0], acc[pset][1] = bias_ptr[1];
+                __builtin_amdgcn_sched_barrier(0);
+            }, typename CpMakeSeq<NSTEP>::type{});
+        }, typename CpMakeSeq<NU>::type{});
+        yprev = ybase;
+    }
+    if (it > 0) {
+        constexpr int lset = (NU - 1) & 1;
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[lset][0]), "+v"(acc[lset][1]));
+        CV_BARRIER();
+#pragma unroll
+        for (int o = 0; o < 6; ++o) xwrite(lset, o);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]));
         CV_BARRIER();
 #pragma unroll
         for (int o = 0; o < SC::NRID; ++o) rider(lset, NU - 1, yprev, o, true);

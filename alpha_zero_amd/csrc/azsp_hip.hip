@@ -184,6 +184,15 @@ int launch_conv3x3_tiled(const void* x, const void* w, const float* bias, const 
             hipLaunchKernelGGL((k_conv3x3_op19<false, VV>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, \
                                bias, (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);                                 \
         break;
+            if (variant == 8) {  // the four-way cin split (k_conv3x3_op19q): half the LDS fragment reads per flop
+                if (res)
+                    hipLaunchKernelGGL((k_conv3x3_op19q<true>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                                       (const unsigned char*)res, (unsigned char*)y, (int)boards, relu);
+                else
+                    hipLaunchKernelGGL((k_conv3x3_op19q<false>), grid, block, 0, (hipStream_t)st, (const unsigned char*)x, (const unsigned short*)w, bias,
+                                       (const unsigned char*)nullptr, (unsigned char*)y, (int)boards, relu);
+                return AZ_HIP(hipGetLastError());
+            }
             switch (variant) {
                 AZ_OP19(0) AZ_OP19(6)  // 6: counted lgkmcnt + later barrier, +0.5 % in profiles/r06_conv19_ab.txt (kept for A/B runs)
                 default: return 1;

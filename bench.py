@@ -456,7 +456,7 @@ def tower_roofline(conv, args, step_ms):
             passes = 2.0   # x in, y out
         else:
             kname = {(9, 128): "k_conv3x3_tiled", (17, 64): "k_conv3x3_t64", (9, 64): "k_conv3x3_t64",
-                     (19, 256): "k_conv3x3_op19 (one launch per convolution: 64 couts x 256 cin per CU, cin halves meet through LDS)"}.get((S_t, args.filters), "conv3x3")
+                     (19, 256): "k_conv3x3_op19q (one launch per convolution: 64 couts x 256 cin per CU, four cin quarters meet through LDS)"}.get((S_t, args.filters), "conv3x3")
             kname += f" (weight-stationary MFMA 3x3 convolution of the residual tower, {'f16' if args.net_dtype == 'fp16' else 'bf16'})"
             passes = 2.5  # x in, y out, residual on every second layer (19x19 x 256 since round 6 too: one pass)
         elem = 2

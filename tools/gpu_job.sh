@@ -34,6 +34,8 @@ for J in "$@"; do
           timeout 900 python tools/soak.py 1200 gomoku 13 4096 fp32 > $O/soak_gomoku13_fp32class_1200rounds.json 2> $O/soak_gomoku.err; echo "soak gomoku rc=$?" | tee -a $O/status.txt
           timeout 900 python tools/soak.py 600 go 19 1024 bf16 20 256 800 > $O/soak_go19_c5_bf16_600rounds.json 2> $O/soak_go19.err; echo "soak go19 rc=$?" | tee -a $O/status.txt
           tail -n 1 $O/soak_*.json | cut -c1-600 ;;
+    rocprof_c2) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rb2 && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rb2 -- python $GRAFT_REPO_ROOT/bench.py --game gomoku --board 13 --blocks 6 --filters 64 --steps 100 --warmup 20 --no-companions --no-fresh-tree --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_c2_under_rocprof.json 2> /tmp/rb2.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rb2 -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_gomoku13_c2.txt 2>&1); echo "rocprof c2 rc=$?" | tee -a $O/status.txt; head -6 $O/kernel_stats_gomoku13_c2.txt | cut -c1-160 ;;
+    rocprof_c5) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rb5 && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rb5 -- python $GRAFT_REPO_ROOT/bench.py --board 19 --games 1024 --sims 800 --blocks 20 --filters 256 --net-dtype bf16 --steps 40 --warmup 5 --no-companions --no-fresh-tree --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_c5_under_rocprof.json 2> /tmp/rb5.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rb5 -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_go19_c5.txt 2>&1); echo "rocprof c5 rc=$?" | tee -a $O/status.txt; head -6 $O/kernel_stats_go19_c5.txt | cut -c1-160 ;;
     conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac
