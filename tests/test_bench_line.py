@@ -77,6 +77,38 @@ def test_a_pmc_summary_of_edited_kernel_sources_is_labelled_stale(tmp_path, monk
     assert bench.kernel_pmc("no_such_file.json") == (None, None)
 
 
+def test_every_digest_carrying_pmc_summary_is_fresh_and_labelled_with_the_kernel_it_measured():
+    """a summary whose label names another kernel than the one in its counter rows is a stale label. For each
+    summary that carries a source digest: the digest matches the tree (bench.py would otherwise print `traffic_stale`), the label is the
+    measured kernels' names, the cited counter file exists under profiles/ and names the same kernels, and bench.py's roofline label for
+    that shape names the same kernel."""
+    import bench
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_digest
+    from pmc_to_json import short_name
+
+    seen = 0
+    for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if not fn.endswith("_kernel_pmc.json"):
+            continue
+        pj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        if not pj.get("kernel_source_sha256"):
+            continue
+        seen += 1
+        assert pj["kernel_source_sha256"] == kernel_digest.kernel_source_digest(pj["family"]), fn
+        names = sorted({short_name(n) for n in pj["per_kernel"]})
+        assert pj["kernel"].split(" (round")[0] == " / ".join(names), (fn, pj["kernel"])
+        src = os.path.join(ROOT, pj["source_round6"][0])
+        assert os.path.exists(src), src
+        text = open(src).read()
+        assert all(n.split("<")[0] in text for n in names), (fn, names)
+    assert seen >= 4
+    conv = {"launches": 100, "avg_ms": 1.64, "planes": 9, "fused_block": False, "split": True, "avg_ms_plain": 1.637, "avg_ms_residual": 1.652, "data": "real"}
+    r = bench.tower_roofline(conv, _args(), step_ms=36.0)
+    assert "k_conv3x3_sp2" in r["kernel"] and r.get("traffic_stale") in (False, None)
+
+
 def test_net_flops_and_power_ceiling_helpers():
     import bench
 

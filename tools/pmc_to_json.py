@@ -32,6 +32,14 @@ def parse(txt):
     return trace, out
 
 
+def short_name(n):
+    """`k_conv3x3_sp2`, `k_resblock_sp<Sb17>` ... from a mangled or demangled kernel name: the label names what the pass MEASURED."""
+    m = re.match(r"_Z(\d+)", n)
+    base = n[m.end():m.end() + int(m.group(1))] if m else re.split(r"[<(]", n.replace("void ", ""))[0].strip()
+    g = re.search(r"Sb\d+", n)
+    return base + (f"<{g.group(0)}>" if g else "")
+
+
 def main():
     fam, src, dst = sys.argv[1], sys.argv[2], sys.argv[3]
     rows = int(sys.argv[4]) if len(sys.argv) > 4 else (4096 if fam == "hb19" else 32768)
@@ -111,7 +119,7 @@ def main():
         js.setdefault("earlier_rounds", {})["source"] = js.pop("source")
     if "note" in js:
         js.setdefault("earlier_rounds", {})["note"] = js.pop("note")
-    js["kernel"] = js.get("kernel", fam).split(" (round")[0] + " (round 6 pass on this round's sources)"
+    js["kernel"] = " / ".join(sorted({short_name(n) for n in kernels})) + " (round 6 pass on this round's sources; both instantiations where templated on the residual add)"
     js["note"] = ("separate rocprofv3 runs per counter group (tools/profile_r06.sh over tools/pmc_launches.py, post-ReLU-like data); FETCH_SIZE counts 64 B per "
                   "128-B request (x2, profiles/r01_pmc_calibration.txt); cycles = GRBM_GUI_ACTIVE / 8 XCDs; effective clock = cycles / the launch time of the "
                   "kernel-trace pass of the same script (6 cold launches: lower than inside a long run -- bench.py divides the cycles by ITS launch time)")
