@@ -551,6 +551,15 @@ def _c1_dropin_worker(args):
             pi = [pri[i] for i in range(pri.shape[0])]
             return (pi, v) if batched else (pi[0], v[0])
 
+    cb, inner = [0, 0.0], eval_func  # callback calls, seconds inside the callback: what is left of the wall time is the drop-in itself
+
+    def timed_eval(state, batched=False):
+        tc = time.perf_counter()
+        r = inner(state, batched)
+        cb[0] += 1
+        cb[1] += time.perf_counter() - tc
+        return r
+
     def play(budget):
         np.random.seed(1)
         env = GomokuEnv(board_size=n)
@@ -559,15 +568,18 @@ def _c1_dropin_worker(args):
             env.reset()
             root, done = None, False
             while not done and time.perf_counter() - t0 < budget:
-                mv, pi, rq, cq, root = uct_search(env=env, eval_func=eval_func, root_node=root, c_puct_base=19652.0, c_puct_init=1.25,
+                mv, pi, rq, cq, root = uct_search(env=env, eval_func=timed_eval, root_node=root, c_puct_base=19652.0, c_puct_init=1.25,
                                                   num_simulations=sims, root_noise=True, warm_up=not (env.steps > 16))
                 _, _, done, _ = env.step(mv)
                 moves += 1
-        return moves / (time.perf_counter() - t0), moves
+        return moves / (time.perf_counter() - t0), moves, time.perf_counter() - t0
 
     play(0.5)  # engine creation, first launches
-    v, m = play(seconds)
-    return v, m, weights, note
+    cb[0], cb[1] = 0, 0.0
+    v, m, wall = play(seconds)
+    acct = {"callback_calls": cb[0], "callback_ms_per_call": round(1e3 * cb[1] / max(cb[0], 1), 4),
+            "outside_callback_us_per_call": round(1e6 * (wall - cb[1]) / max(cb[0], 1), 1)}
+    return v, m, weights, note, acct
 
 
 def c1_dropin(seconds=8.0):
@@ -587,8 +599,9 @@ def c1_dropin(seconds=8.0):
     ctx = mp.get_context("spawn")
     for kind in ("cpu", "device", "null"):
         with ctx.Pool(1) as pool:
-            v, m, weights, note = pool.map(_c1_dropin_worker, [(kind, seconds if kind != "null" else min(seconds, 3.0))])[0]
+            v, m, weights, note, acct = pool.map(_c1_dropin_worker, [(kind, seconds if kind != "null" else min(seconds, 3.0))])[0]
         out[f"{kind}_eval_func_moves_per_s"], out[f"{kind}_eval_func_moves"], out["weights"] = round(v, 3), m, weights
+        out[f"{kind}_eval_func_accounting"] = acct  # where a move's time goes: inside the caller's callback vs in the drop-in (engine + round trip)
         if note:
             out["device_evaluator"] = note
     # a search of 100 simulations with sub-tree reuse runs ~70-100 new simulations: an upper bound of the engine + round-trip cost per simulation
@@ -806,6 +819,7 @@ def main(argv=None):
                 c1d = c1_dropin(seconds=min(8.0, args.cpu_seconds))
                 c1d["cpu_port_moves_per_s_10x40"] = round(c1b["value"], 3)
                 c1d["cpu_port_sample"] = c1b["sample"]
+                c1d["cpu_port_accounting"] = {k: c1b[k] for k in ("callback_calls", "callback_ms_per_call", "outside_callback_us_per_call")}
                 c1d["cpu_eval_func_over_cpu_port"] = round(c1d["cpu_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
                 c1d["device_eval_func_over_cpu_port"] = round(c1d["device_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
             except Exception as ex:  # the companion must never take the headline down

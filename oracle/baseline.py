@@ -32,8 +32,11 @@ def _worker(args):
     np.random.seed(seed + idx)
     rng = np.random.Generator(np.random.PCG64(seed + idx))
 
+    cb = [0, 0.0]  # callback calls, seconds inside the callback: what is left of the wall time is the search itself
+
     @torch.no_grad()
     def eval_position(state, batched=False):  # pipeline.py:91-123
+        tc = time.perf_counter()
         if not batched:
             state = state[None, ...]
         x = torch.from_numpy(state).to(dtype=torch.float32)
@@ -41,6 +44,8 @@ def _worker(args):
         pi = torch.softmax(logits, dim=-1).cpu().numpy()
         v = np.squeeze(v.cpu().numpy(), axis=1).tolist()
         pi = [pi[i] for i in range(pi.shape[0])]
+        cb[0] += 1
+        cb[1] += time.perf_counter() - tc
         return (pi, v) if batched else (pi[0], v[0])
 
     moves = 0
@@ -64,7 +69,7 @@ def _worker(args):
                 mv, pi, rq, cq, root = mcts.uct_search(**kw)
             _, _, done, _ = env.step(mv)
             moves += 1
-    return moves, time.time() - t0
+    return moves, time.time() - t0, cb[0], cb[1]
 
 
 def run(cores, seconds=20.0, game="go", n=9, sims=200, P=8, blocks=10, filters=128, stagger=60, seed=1, fc=None, ckpt=None):
@@ -72,7 +77,10 @@ def run(cores, seconds=20.0, game="go", n=9, sims=200, P=8, blocks=10, filters=1
     args = [(i, game, n, sims, P, blocks, filters, seconds, stagger, seed, fc, ckpt) for i in range(cores)]
     with ctx.Pool(cores) as pool:
         res = pool.map(_worker, args)
-    total = sum(m / t for m, t in res)
-    return dict(value=total, unit="moves/s", cores=cores, kind="port", per_core=total / cores,
+    total = sum(m / t for m, t, _, _ in res)
+    calls, inside, wall = sum(r[2] for r in res), sum(r[3] for r in res), sum(r[1] for r in res)
+    return dict(callback_calls=calls, callback_ms_per_call=round(1e3 * inside / max(calls, 1), 4),
+                outside_callback_us_per_call=round(1e6 * (wall - inside) / max(calls, 1), 1),
+                value=total, unit="moves/s", cores=cores, kind="port", per_core=total / cores,
                 sample=f"{cores} actor processes x {seconds:.0f}s, {game} {n}x{n}, {sims} sims, P={P}, {blocks}x{filters} fp32 net, "
-                       f"{sum(m for m, _ in res)} moves" + (f", weights {os.path.basename(ckpt)}" if ckpt else ", random init"))
+                       f"{sum(r[0] for r in res)} moves" + (f", weights {os.path.basename(ckpt)}" if ckpt else ", random init"))
