@@ -491,7 +491,7 @@ def tower_roofline(conv, args, step_ms):
             roofline["clock_fraction"] = round(clk / MFMA_PEAK_CLOCK_GHZ, 4)
             # MFMAs the kernel issues per MFMA the algorithm needs (halo rows recomputed by the fused 17x17 block, padding slots of the column
             # tiles): the counters see the former, `frac` counts the latter
-            flop_per_mfma = 2.0 * 16 * 16 * 32  # = 2 * 32 * 32 * 16: both instruction forms
+            flop_per_mfma = 2.0 * 16 * 16 * 32 * (ceil["pipe_cycles_per_mfma_at_peak"] / 16.0)  # 16x16x32: 16 384 flop in 16 pipe cycles; 32x32x16: 32 768 in 32
             over = (pj.get("SQ_INSTS_MFMA") or 0) * rows / pj["rows"] * flop_per_mfma / (issued_tf * conv["avg_ms"] * 1e-3 * 1e12)
             roofline["issued_over_algorithmic_mfma"] = round(over, 4) if over > 0 else None
             roofline["decomposition_product"] = round(roofline["instruction_form_ceiling"] * roofline["issue_efficiency"] * roofline["clock_fraction"] / (over if over > 0 else 1.0), 4)

@@ -109,6 +109,24 @@ def test_every_digest_carrying_pmc_summary_is_fresh_and_labelled_with_the_kernel
     assert "k_conv3x3_sp2" in r["kernel"] and r.get("traffic_stale") in (False, None)
 
 
+def test_tower_roofline_decomposition_of_the_other_shapes():
+    """The decomposition closes on every shape with a round-6 PMC pass: form x issue x clock / (issued over algorithmic MFMAs) ~ frac.
+    19x19 x 256 runs on v_mfma_f32_32x32x16 (32 768 flop per instruction, twice the 16x16x32 form's): 361 positions in 12 column tiles of
+    32 = x1.064 the algorithm's; the fused 17x17 block recomputes halo rows of its half-board tiles: x1.107."""
+    import bench
+
+    conv = {"launches": 80, "avg_ms": 2.4956, "planes": 19, "fused_block": False, "split": False, "avg_ms_plain": 2.47, "avg_ms_residual": 2.52, "data": "real"}
+    r = bench.tower_roofline(conv, _args(board=19, games=512, blocks=20, filters=256, net_dtype="bf16"), step_ms=101.0)
+    assert "k_conv3x3_op19q" in r["kernel"] and r["mfma_ceilings"]["instruction_form"] == "v_mfma_f32_32x32x16_bf16"
+    assert abs(r["issued_over_algorithmic_mfma"] - 12 * 32 / 361.0) < 0.01 and abs(r["decomposition_product"] - r["frac"]) < 0.03
+    conv = {"launches": 30, "avg_ms": 3.2863, "planes": 17, "fused_block": True, "split": True, "avg_ms_plain": None, "avg_ms_residual": None, "data": "real"}
+    r = bench.tower_roofline(conv, _args(board=13, game="gomoku", blocks=6, filters=64), step_ms=21.4)
+    assert 1.08 < r["issued_over_algorithmic_mfma"] < 1.13 and abs(r["decomposition_product"] - r["frac"]) < 0.03
+    conv = {"launches": 30, "avg_ms": 0.9206, "planes": 9, "fused_block": True, "split": True, "avg_ms_plain": None, "avg_ms_residual": None, "data": "real"}
+    r = bench.tower_roofline(conv, _args(blocks=12, filters=64), step_ms=11.95)
+    assert "k_resblock_sp<Sb9>" in r["kernel"] and 0.99 < r["issued_over_algorithmic_mfma"] < 1.12 and abs(r["decomposition_product"] - r["frac"]) < 0.03
+
+
 def test_net_flops_and_power_ceiling_helpers():
     import bench
 
