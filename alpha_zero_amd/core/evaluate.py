@@ -104,20 +104,69 @@ class DeviceEvaluator:
     (pipeline.py:91-123), so the same object also serves the drop-in searches."""
 
     POLL_EVERY = 32  # leaf batches between two polls of the fp32-class evaluator's range record (a poll synchronises the stream)
+    MAX_GRAPHS = 8   # captured forwards kept (one per engine buffer set and evaluator state)
 
-    def __init__(self, inference_net):
+    def __init__(self, inference_net, use_graph=True):
         self.inf = inference_net
+        self.use_graph = use_graph
         self._calls = 0
+        self._graphs = {}
+
+    def _forward(self, x, priors_out=None, values_out=None):
+        if hasattr(self.inf, "forward_planes"):
+            return self.inf.forward_planes(x, priors_out, values_out)
+        return self.inf(x, priors_out, values_out) if priors_out is not None else self.inf(x)
+
+    def _poll(self, x):
+        self._calls += 1
+        if self._calls % self.POLL_EVERY == 0 and hasattr(self.inf, "poll_range"):
+            self.inf.poll_range(x)  # never silent, never left clamping: warn + rescale (InferenceNet.poll_range)
 
     def device_eval(self, x):
         import torch
 
         with torch.no_grad():
-            pri, v = self.inf.forward_planes(x) if hasattr(self.inf, "forward_planes") else self.inf(x)
-        self._calls += 1
-        if self._calls % self.POLL_EVERY == 0 and hasattr(self.inf, "poll_range"):
-            self.inf.poll_range(x)  # never silent, never left clamping: warn + rescale (InferenceNet.poll_range)
+            pri, v = self._forward(x)
+        self._poll(x)
         return pri.float(), v.float()
+
+    def _state_key(self):
+        i = self.inf  # everything a captured forward bakes in besides the (in-place updated) weight tensors
+        return (id(i), getattr(i, "act_shift", 0), getattr(i, "act_calibrated", True), getattr(i, "split_fallback_reason", None),
+                getattr(i, "stem_fallback_reason", None), getattr(i, "use_split_tower", None), getattr(i, "use_fused_block", None))
+
+    def device_eval_into(self, x, priors_out, values_out):
+        """The evaluator between an engine's own tensors: x = its feature rows, outputs written in place into its priors / values (fp32).
+        On a HIP device the forward is replayed from a hipGraph captured per (buffers, evaluator state): a batch-1 forward of the drop-in
+        searches is ~14 launches of a few microseconds each, i.e. launch-bound from Python (core/mcts_v2.py _simulate_on_device).  A change
+        of the evaluator's state (activation scale, fallback to the library, kernel switches) drops the capture."""
+        import torch
+
+        if not (self.use_graph and x.is_cuda):
+            with torch.no_grad():
+                self._forward(x, priors_out, values_out)
+            self._poll(x)
+            return
+        key = (x.data_ptr(), tuple(x.shape), x.dtype, priors_out.data_ptr(), values_out.data_ptr(), self._state_key())
+        g = self._graphs.get(key)
+        if g is None:
+            with torch.no_grad():
+                side = torch.cuda.Stream(x.device)
+                side.wait_stream(torch.cuda.current_stream(x.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):  # eager first: calibration of the fp32-class activation scale, scratch buffers, library kernel choice
+                        self._forward(x, priors_out, values_out)
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                torch.cuda.synchronize(x.device)
+                key = key[:-1] + (self._state_key(),)  # (the eager calls may have calibrated the scale or given the split kernels up)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._forward(x, priors_out, values_out)
+            if len(self._graphs) >= self.MAX_GRAPHS:
+                self._graphs.clear()
+            self._graphs[key] = g
+        g.replay()
+        self._poll(x)
 
     def __call__(self, state, batched=False):
         import torch

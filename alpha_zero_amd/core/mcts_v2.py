@@ -78,6 +78,63 @@ def _load_position(s, env):
     s.eng.set_state(0, np.asarray(env.board, dtype=np.int8), hist, env.to_play, env.steps, ko, last_pass, caps)
 
 
+def _simulate_with_callback(eng, eval_func, P, num_parallel, A):
+    """The simulation loop (mcts_v2.py:378-421 / :568-625) with the caller's HOST callback.  One host round trip per leaf batch:
+    azsp_dropin_step uploads eval_func's outputs, runs expand / backup + the selection of the next leaves, and returns status, valid
+    flags and the leaves' observation planes from one packed read-back (rounds 1-5 paid eight stream synchronisations per simulation here)."""
+    pri = np.zeros((eng.rows, A), dtype=np.float32)
+    val = np.zeros(eng.rows, dtype=np.float32)
+    st, q, valid, obs = eng.dropin_step(None, None, P)
+    for _ in range(1 << 20):
+        if st[0, 0] == _abi.ST_MOVE_DONE:
+            return
+        if valid.any():
+            if st[0, 6] or num_parallel == 1:  # root evaluation / uct_search leaves: unbatched call (mcts_v2.py:365, :414, :555)
+                p, v = eval_func(obs[0], False)
+                pri[0], val[0] = np.asarray(p, dtype=np.float32), v
+            else:
+                rows = np.flatnonzero(valid)
+                ps, vs = eval_func(obs[rows], True)  # mcts_v2.py:614
+                for r, p, v in zip(rows, ps, vs):
+                    pri[r], val[r] = np.asarray(p, dtype=np.float32), v
+        st, q, valid, obs = eng.dropin_step(pri, val, P)
+    raise RuntimeError("the search did not finish")
+
+
+def _simulate_on_device(eng, evaluator, num_simulations, num_parallel):
+    """The same loop for an evaluator that lives on the engine's device (anything with `device_eval(x) -> (priors, values)` on device
+    tensors, e.g. core/evaluate.py DeviceEvaluator): select writes the leaves' observation planes into `eng.features`, the evaluator reads
+    them there and its outputs go straight into `eng.priors` / `eng.values`, expand / backup reads those -- NO host round trip per
+    simulation.  The host only polls the status words: a search that still owes `left` simulations cannot finish in fewer than
+    left / (simulations one iteration can complete) iterations (1 for uct_search -- a terminal leaf makes select descend again in the
+    same launch, mcts_v2.py:378-411 --, at most 2P attempts for parallel_uct_search, :572), so that many iterations are queued without
+    looking (half of them: a search with terminal leaves needs fewer, and iterations queued after the search is done would be no-ops in the engine -- nothing pending, status
+    MOVE_DONE -- but each still costs a forward).  ~8 polls per 100-simulation move instead of 100 round trips.  Every row is evaluated,
+    valid or not, like the batched actor does: the engine ignores outputs of rows it did not ask for.  Same searches as the callback
+    loop with the same evaluator (tests/dropin_checks.py)."""
+    per_iter = 1 if num_parallel == 1 else 2 * num_parallel
+    into = getattr(evaluator, "device_eval_into", None)
+
+    def iterate(n):
+        for _ in range(n):
+            if into is not None:
+                into(eng.features, eng.priors, eng.values)
+            else:
+                pri, val = evaluator.device_eval(eng.features)
+                eng.priors.copy_(pri.reshape(eng.priors.shape))
+                eng.values.copy_(val.reshape(eng.values.shape))
+            eng.round()
+
+    eng.round()  # nothing to back up yet: selects the first leaf (or asks for the root's evaluation)
+    for _ in range(1 << 20):
+        st, _ = eng.status()
+        if st[0, 0] == _abi.ST_MOVE_DONE:
+            return
+        left = max(num_simulations - int(st[0, 2]), 1)
+        iterate(max(1, (left // 2) // per_iter))
+    raise RuntimeError("the search did not finish")
+
+
 def _search(env, eval_func, root_node, c_puct_base, c_puct_init, num_simulations, num_parallel, root_noise, warm_up, deterministic):
     if not isinstance(env, BoardGameEnv) and not (hasattr(env, "board_deltas") and hasattr(env, "legal_actions")):
         raise ValueError(f"Expect `env` to be a valid BoardGameEnv instance, got {env}")
@@ -102,25 +159,11 @@ def _search(env, eval_func, root_node, c_puct_base, c_puct_init, num_simulations
     if root_noise:  # add_dirichlet_noise (mcts_v2.py:259-260): the engine applies the legal mask itself
         noise = np.random.dirichlet(np.ones_like(root_legal) * 0.03)
     eng.begin_move(noise, warm_up=1 if warm_up else 0)
-    # The simulation loop (mcts_v2.py:378-421 / :568-625).  One host round trip per leaf batch: azsp_dropin_step uploads eval_func's
-    # outputs, runs expand / backup + the selection of the next leaves, and returns status, valid flags and the leaves' observation
-    # planes from one packed read-back (rounds 1-5 paid eight stream synchronisations per simulation here).
-    pri = np.zeros((eng.rows, A), dtype=np.float32)
-    val = np.zeros(eng.rows, dtype=np.float32)
-    st, q, valid, obs = eng.dropin_step(None, None, s.P)
-    for _ in range(1 << 20):
-        if st[0, 0] == _abi.ST_MOVE_DONE:
-            break
-        if valid.any():
-            if st[0, 6] or num_parallel == 1:  # root evaluation / uct_search leaves: unbatched call (mcts_v2.py:365, :414, :555)
-                p, v = eval_func(obs[0], False)
-                pri[0], val[0] = np.asarray(p, dtype=np.float32), v
-            else:
-                rows = np.flatnonzero(valid)
-                ps, vs = eval_func(obs[rows], True)  # mcts_v2.py:614
-                for r, p, v in zip(rows, ps, vs):
-                    pri[r], val[r] = np.asarray(p, dtype=np.float32), v
-        st, q, valid, obs = eng.dropin_step(pri, val, s.P)
+    if getattr(eval_func, "device_eval", None) is not None and not (eng.features_tiled or eng.features_split):
+        # a device-resident evaluator (core/evaluate.py DeviceEvaluator): the leaves never visit the host -- see _simulate_on_device
+        _simulate_on_device(eng, eval_func, num_simulations, num_parallel)
+    else:
+        _simulate_with_callback(eng, eval_func, s.P, num_parallel, A)
     pi64, child_n, _ = eng.get_search(0, 0)
     search_pi = pi64 if env.has_pass_move else pi64.astype(np.float32)  # float64 for Go, float32 for Gomoku
     move = None

@@ -542,6 +542,11 @@ def _c1_dropin_worker(args):
         wnet, wnote = widen_for_kernels(net, n, torch.float32)  # 40 -> 64 filters, function-preserving: the hand-written fp32-class kernels
         inf = InferenceNet(wnet, dtype=torch.float32, binding=_lib.load()).cuda()
         note = inf.evaluator_path(n, torch.device("cuda")) + wnote
+        resident = None
+        if kind == "resident":  # the product's DeviceEvaluator: uct_search keeps the leaves on the device (core/mcts_v2.py _simulate_on_device)
+            from alpha_zero_amd.core.evaluate import DeviceEvaluator
+
+            resident = DeviceEvaluator(inf)
 
         @torch.no_grad()
         def eval_func(state, batched=False):
@@ -560,6 +565,9 @@ def _c1_dropin_worker(args):
         cb[1] += time.perf_counter() - tc
         return r
 
+    if kind == "resident":
+        timed_eval = resident  # (no host callback to account for: the evaluator object itself is handed to uct_search)
+
     def play(budget):
         np.random.seed(1)
         env = GomokuEnv(board_size=n)
@@ -576,9 +584,14 @@ def _c1_dropin_worker(args):
 
     play(0.5)  # engine creation, first launches
     cb[0], cb[1] = 0, 0.0
+    c0 = resident._calls if kind == "resident" else 0
     v, m, wall = play(seconds)
-    acct = {"callback_calls": cb[0], "callback_ms_per_call": round(1e3 * cb[1] / max(cb[0], 1), 4),
-            "outside_callback_us_per_call": round(1e6 * (wall - cb[1]) / max(cb[0], 1), 1)}
+    if kind == "resident":
+        acct = {"forwards": resident._calls - c0, "us_per_forward_all_in": round(1e6 * wall / max(resident._calls - c0, 1), 1),
+                "hip_graph_forward": bool(resident._graphs)}
+    else:
+        acct = {"callback_calls": cb[0], "callback_ms_per_call": round(1e3 * cb[1] / max(cb[0], 1), 4),
+                "outside_callback_us_per_call": round(1e6 * (wall - cb[1]) / max(cb[0], 1), 1)}
     return v, m, weights, note, acct
 
 
@@ -589,15 +602,17 @@ def c1_dropin(seconds=8.0):
     copy of its weights travelled (tests/golden/, data), a random network of that shape otherwise.  The tree lives on the GPU engine; the
     evaluator is the caller's callback: (a) `cpu_eval_func` = the reference's own eval_position (pipeline.py:91-123: fp32 torch-CPU module, one
     torch thread in a process of its own, as training_gomoku.py runs its actors), (b) `device_eval_func` = the product evaluator (InferenceNet,
-    fp32-class kernels) behind the same callback signature.  moves/s of each; one launch + one stream synchronisation per simulation
-    (azsp_dropin_step).  Each measurement runs in a spawned process, like the CPU port it stands beside."""
+    fp32-class kernels) behind the same HOST callback signature: one launch + one stream synchronisation per simulation (azsp_dropin_step)
+    + the callback's own upload / read-back, (c) `resident_eval_func` = the same evaluator handed over as a DeviceEvaluator object
+    (core/evaluate.py): the leaves never leave the device, the forward is a hipGraph between the engine's tensors, the host polls the
+    status ~8 times per move.  moves/s of each.  Each measurement runs in a spawned process, like the CPU port it stands beside."""
     import multiprocessing as mp
 
     out = {"config": "BASELINE C1: 13x13 Gomoku, uct_search (P = 1), 100 sims/move, one game at a time, sub-tree reuse, root noise",
            "entry_point": "alpha_zero_amd.core.mcts_v2.uct_search (same signature and return tuple as the reference's mcts_v2.uct_search)",
            "host_round_trips_per_simulation": 1}
     ctx = mp.get_context("spawn")
-    for kind in ("cpu", "device", "null"):
+    for kind in ("cpu", "device", "resident", "null"):
         with ctx.Pool(1) as pool:
             v, m, weights, note, acct = pool.map(_c1_dropin_worker, [(kind, seconds if kind != "null" else min(seconds, 3.0))])[0]
         out[f"{kind}_eval_func_moves_per_s"], out[f"{kind}_eval_func_moves"], out["weights"] = round(v, 3), m, weights
@@ -822,6 +837,7 @@ def main(argv=None):
                 c1d["cpu_port_accounting"] = {k: c1b[k] for k in ("callback_calls", "callback_ms_per_call", "outside_callback_us_per_call")}
                 c1d["cpu_eval_func_over_cpu_port"] = round(c1d["cpu_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
                 c1d["device_eval_func_over_cpu_port"] = round(c1d["device_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
+                c1d["resident_eval_func_over_cpu_port"] = round(c1d["resident_eval_func_moves_per_s"] / max(c1b["value"], 1e-9), 3)
             except Exception as ex:  # the companion must never take the headline down
                 c1d = {"error": repr(ex)}
             # port vs the imported reference on identical seeded moves, measured in the development container by

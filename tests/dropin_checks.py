@@ -64,15 +64,22 @@ def check_env_surface(kind):
     assert d and r == 1.0 and g.winner == 1 and g.get_result_string() == "B+1.0"
 
 
-def check_dropin_search(kind, name, max_moves=12):
+def check_dropin_search(kind, name, max_moves=12, device_route=False):
     """The reference's own actor loop shape (pipeline.py:289-346) driven by OUR uct_search / envs, with the global NumPy
-    random state replayed from the golden file: moves, pi, Q must equal the reference's outputs."""
+    random state replayed from the golden file: moves, pi, Q must equal the reference's outputs.
+    device_route: the evaluator is an object with `device_eval` (tensors on the engine's device in and out): the searches run the
+    device-resident loop (core/mcts_v2.py _simulate_on_device: no host round trip per simulation, status polled a few times per move,
+    every row evaluated whether asked for or not) and must reproduce the same reference searches."""
     from alpha_zero_amd.core.mcts_v2 import parallel_uct_search, uct_search
 
     G = golden_mcts.MctsGolden(name)
     g, cfg = G.g, G.cfg
     env = make_env(kind, cfg["game"], cfg["n"])
     ef = make_eval_func(G.A)
+    if device_route:
+        from arena_checks import SynthDeviceEvaluator
+
+        ef = SynthDeviceEvaluator(G.A, 2.0)
     real_dir, real_choice = np.random.dirichlet, np.random.choice
     try:
         for gi in range(min(2, cfg["games"])):
@@ -107,6 +114,8 @@ def check_dropin_search(kind, name, max_moves=12):
                 env.step(int(move))
                 if env.is_game_over():
                     break
+        if device_route:  # far fewer evaluator calls than host polls would allow is not asserted; that the route ran is
+            assert ef.calls > 0
     finally:
         np.random.dirichlet, np.random.choice = real_dir, real_choice
 

@@ -14,6 +14,11 @@ def test_uct_search_dropin_matches_reference(name):
     dc.check_dropin_search("host", name)
 
 
+@pytest.mark.parametrize("name", ["go9_p8_s200", "go5_p1_s40", "gomoku13_p1_s100", "gomoku7_p8_s64", "go5_p1_s40_det"])
+def test_uct_search_dropin_with_a_device_resident_evaluator_matches_reference(name):
+    dc.check_dropin_search("host", name, device_route=True)
+
+
 def test_search_errors():
     dc.check_search_errors("host")
 

@@ -102,6 +102,12 @@ def test_gpu_uct_search_dropin_matches_reference(name):
     dc.check_dropin_search("gpu", name, max_moves=8)
 
 
+@pytest.mark.parametrize("name", ["go9_p8_s200", "gomoku13_p1_s100", "go5_p1_s40_det"])
+def test_gpu_uct_search_dropin_with_a_device_resident_evaluator_matches_reference(name):
+    """The device-resident simulation loop (no host round trip per simulation; core/mcts_v2.py _simulate_on_device) on the reference's goldens."""
+    dc.check_dropin_search("gpu", name, max_moves=8, device_route=True)
+
+
 def test_gpu_search_errors():
     dc.check_search_errors("gpu")
 

@@ -69,3 +69,27 @@ def test_gpu_search_with_shipped_checkpoint_fp32_and_bf16(golden_dir):
         f = ssp[key]
         assert f["moves_compared"] == f["moves_in_golden"] >= 40 and f["exact_moves"] == f["moves_compared"], ssp
         assert f["max_dpi"] <= 1e-6 and f["max_dq"] <= 1e-6 and f["max_dcq"] <= 1e-6, ssp
+
+
+@pytest.mark.gpu
+def test_gpu_dropin_search_with_the_device_resident_product_evaluator_reproduces_the_reference_games():
+    """uct_search / parallel_uct_search handed a DeviceEvaluator (core/evaluate.py) around the fp32-class hand-written evaluator with the
+    reference's shipped checkpoint: the leaves stay on the device, the forward is replayed from a hipGraph between the engine's own
+    tensors, the host polls the status a few times per move.  Statement: the same as for the host callback -- EVERY move of the
+    reference's recorded games identical (pi to 1e-6, same sampled move, |Q - ref| <= 1e-6), P = 1 with sub-tree reuse and P = 8."""
+    from alpha_zero_amd import _lib
+    from alpha_zero_amd.core.evaluate import DeviceEvaluator
+    from alpha_zero_amd.core.network import InferenceNet, widen_network
+
+    infsp = InferenceNet(widen_network(rc.load_shipped(), 64), dtype=torch.float32, binding=_lib.load()).cuda()
+    for use_graph in (True, False):
+        ev = DeviceEvaluator(infsp, use_graph=use_graph)
+        for name in ("gomoku13_ckpt200000_p1_s100", "gomoku13_ckpt200000_p8_s200"):
+            infsp._split = None
+            recs, total = rc.run_golden("gpu", name, ev, teacher_forced=False)
+            assert infsp._split is not None, "the split-precision kernels did not run"
+            f = rc.summarize(recs, total)
+            assert f["moves_compared"] == f["moves_in_golden"] >= 40 and f["exact_moves"] == f["moves_compared"], (use_graph, name, f)
+            assert f["max_dpi"] <= 1e-6 and f["max_dq"] <= 1e-6 and f["max_dcq"] <= 1e-6, (use_graph, name, f)
+        assert (len(ev._graphs) >= 1) == use_graph  # (one captured forward per engine buffer set)
+    assert infsp.split_range_status(reset=True)[0] == 0
