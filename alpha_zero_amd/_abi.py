@@ -11,7 +11,7 @@ SYMBOLS = [
     "azsp_create", "azsp_destroy", "azsp_last_error", "azsp_geometry", "azsp_set_tables", "azsp_set_injection",
     "azsp_reset_games", "azsp_env_step", "azsp_set_state", "azsp_begin_move", "azsp_select", "azsp_expand_backup",
     "azsp_round", "azsp_get_status", "azsp_get_search", "azsp_commit_move", "azsp_harvest", "azsp_counters", "azsp_dihedral", "azsp_bias_act",
-    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled", "azsp_replay_gather", "azsp_rng_probe", "azsp_harvest_moves", "azsp_fc_heads", "azsp_harvest_extra", "azsp_set_actor_state", "azsp_resblock_tiled", "azsp_select_range", "azsp_expand_backup_range", "azsp_split_bytes", "azsp_split_layout", "azsp_conv3x3_split", "azsp_split_features", "azsp_stem_split", "azsp_head_split", "azsp_conv3x3_tiled_f16", "azsp_stem_tiled_f16", "azsp_head_tiled_f16", "azsp_fc_heads_f16", "azsp_split_range_status", "azsp_stem_split_exact", "azsp_split_range_read", "azsp_resblock_split", "azsp_dropin_step",
+    "azsp_conv3x3_tiled", "azsp_tile_layout", "azsp_tiled_bytes", "azsp_stem_tiled", "azsp_head_tiled", "azsp_replay_gather", "azsp_rng_probe", "azsp_harvest_moves", "azsp_fc_heads", "azsp_harvest_extra", "azsp_set_actor_state", "azsp_resblock_tiled", "azsp_select_range", "azsp_expand_backup_range", "azsp_split_bytes", "azsp_split_layout", "azsp_conv3x3_split", "azsp_split_features", "azsp_stem_split", "azsp_head_split", "azsp_conv3x3_tiled_f16", "azsp_stem_tiled_f16", "azsp_head_tiled_f16", "azsp_fc_heads_f16", "azsp_split_range_status", "azsp_stem_split_exact", "azsp_split_range_read", "azsp_resblock_split", "azsp_dropin_step", "azsp_small_batch_waves",
 ]
 
 COUNTER_NAMES = ["sims", "node_visits", "backup_edges", "leaves", "dup_leaves", "terminal_hits", "moves", "games", "root_evals",
@@ -72,6 +72,7 @@ class Binding:
             f = getattr(cdll, k)
             f.argtypes, f.restype = a, C.c_int
         cdll.azsp_last_error.argtypes, cdll.azsp_last_error.restype = [V], C.c_char_p
+        cdll.azsp_small_batch_waves.argtypes, cdll.azsp_small_batch_waves.restype = [C.c_int64], C.c_int64
         cdll.azsp_tiled_bytes.argtypes, cdll.azsp_tiled_bytes.restype = [C.c_int64, I, I], C.c_int64
         cdll.azsp_split_bytes.argtypes, cdll.azsp_split_bytes.restype = [C.c_int64, I, I], C.c_int64
 

@@ -278,16 +278,23 @@ class InferenceNet(nn.Module):
                 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in ((128, 9), (64, 17), (64, 9), (256, 19))
                 and x.is_contiguous(memory_format=torch.channels_last))
 
-    SPLIT_TOWER_SHAPES = ((128, 9), (64, 9), (64, 17))          # (filters, tower planes) with an azsp_conv3x3_split kernel
+    SPLIT_TOWER_SHAPES = ((128, 9), (64, 9), (64, 17))          # (filters, tower planes) with a weight-stationary azsp_conv3x3_split kernel
+    SPLIT_TOWER_ANY_PLANES = (64, 128, 256)                     # filters of the wave-per-tile kernel (csrc/az_conv_spg.h): planes 3 .. 64
     SPLIT_FUSED_SHAPES = ((64, 17), (64, 9))                    # ... with a one-launch-per-block kernel (azsp_resblock_split)
     SPLIT_EVAL_SHAPES = ((128, 9, 1), (64, 9, 1), (64, 13, 3))  # (filters, board, stem pad) whose whole evaluator runs on the split kernels
 
+    @classmethod
+    def split_tower_shape(cls, filters, planes):
+        """(filters, tower planes) that azsp_conv3x3_split takes: the weight-stationary shapes, and since round 6 every plane size with
+        64 / 128 / 256 filters (k_conv3x3_spg: the reference's 19x19 x 256 jumbo tower at its own precision, training_go_jumbo.py:46-47)."""
+        return (filters, planes) in cls.SPLIT_TOWER_SHAPES or (filters in cls.SPLIT_TOWER_ANY_PLANES and 3 <= planes <= 64)
+
     def _split_tower_ok(self, x):
-        """fp32 networks on 9x9 planes with 128 or 64 filters and on 17x17 planes with 64 filters (the 13x13 Gomoku tower): the tower
-        runs on azsp_conv3x3_split (include/azsp.h) -- the reference's precision class (pipeline.py:91-123 evaluates in fp32) at the f16
-        MFMA rate."""
+        """fp32 networks with 64 / 128 / 256 filters: the tower runs on azsp_conv3x3_split (include/azsp.h) -- the reference's precision
+        class (pipeline.py:91-123 evaluates in fp32) on the f16 matrix cores: the weight-stationary kernels on 9x9 planes with 128 or
+        64 filters and on 17x17 planes with 64 filters (the 13x13 Gomoku tower), the wave-per-tile kernel on every other plane size."""
         return (self.binding is not None and self.use_fused_conv and self.use_split_tower and x.is_cuda and x.dtype == torch.float32
-                and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and (x.shape[1], x.shape[2]) in self.SPLIT_TOWER_SHAPES
+                and self.dtype == torch.float32 and x.shape[2] == x.shape[3] and self.split_tower_shape(x.shape[1], x.shape[2])
                 and not self.split_fallback_reason and x.is_contiguous(memory_format=torch.channels_last))
 
     def supports_split_features(self, board_size, device):
@@ -612,8 +619,9 @@ class InferenceNet(nn.Module):
             return (f"fp32 class, hand-written: split-precision stem / tower ({tower}hi + lo f16 pairs, three MFMA products, "
                     "fp32 accumulation) / fp32 heads (libazsp)")
         if torch.device(device).type == "cuda" and self.dtype == torch.float32 and self.binding is not None and self.use_split_tower and not self.split_fallback_reason:
-            if (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_TOWER_SHAPES:
-                return ("fp32 class: hand-written split-precision tower (azsp_conv3x3_split: hi + lo f16 pairs, three MFMA products, fp32 "
+            if self.split_tower_shape(self.filters, board_size + 2 * (self.stem_pad - 1)):
+                kern = "" if (self.filters, board_size + 2 * (self.stem_pad - 1)) in self.SPLIT_TOWER_SHAPES else ", wave-per-tile kernel k_conv3x3_spg"
+                return (f"fp32 class: hand-written split-precision tower (azsp_conv3x3_split{kern}: hi + lo f16 pairs, three MFMA products, fp32 "
                         "accumulation) behind a library fp32 stem and heads" + (f" ({self.stem_fallback_reason})" if self.stem_fallback_reason else ""))
         if self.split_fallback_reason or self.stem_fallback_reason:
             return ("library fp32 convolutions + azsp_bias_act epilogue (fp32-class kernels given up for this network: "

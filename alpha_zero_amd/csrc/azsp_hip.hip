@@ -12,6 +12,7 @@
 #include "az_conv_sp17.h"
 #include "az_resblock_sp17.h"
 #include "az_conv_sp2.h"
+#include "az_conv_spg.h"
 
 static hipError_t g_last = hipSuccess;
 #define AZ_HIP(x) ((g_last = (x)) == hipSuccess ? 0 : -1)
@@ -344,8 +345,63 @@ static int launch_sp17(const void* x, const void* w, const float* bias, const vo
                        (const _Float16*)w, bias, (const unsigned char*)res, (unsigned char*)y, (int)boards, relu, range);
     return AZ_HIP(hipGetLastError());
 }
+// k_conv3x3_spg (az_conv_spg.h): the fp32-class convolution with one WAVE per output tile -- any plane size, 64 / 128 / 256 filters.
+// `latency`: small tiles (16 couts x 32 positions per wave) so that a handful of boards fill the chip; otherwise 32 couts x 48 positions.
+// `halves` = 2: k_conv3x3_sp2's two accumulation chains (bit-identical to it at 9x9 x 128).
+template <bool RES, int KSUB, int NT, int NJ, int HALVES>
+static int launch_spg_t(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
+                        unsigned* range) {
+    const long long nct = ((long long)S * S + 15) / 16, items = boards * ((nct + NJ - 1) / NJ) * (C / (16 * NT)), grid = (items + 3) / 4;
+    if (grid > 0x7fffffffLL) return 1;
+    hipLaunchKernelGGL((k_conv3x3_spg<RES, KSUB, NT, NJ, HALVES>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w,
+                       bias, (const unsigned char*)(RES ? res : nullptr), (unsigned char*)y, (int)boards, S, C, relu, range);
+    return AZ_HIP(hipGetLastError());
+}
+template <int KSUB, int HALVES>
+static int launch_spg_k(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
+                        unsigned* range, bool latency) {
+    if (latency)
+        return res ? launch_spg_t<true, KSUB, 1, 2, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range)
+                   : launch_spg_t<false, KSUB, 1, 2, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range);
+    return res ? launch_spg_t<true, KSUB, 2, 3, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range)
+               : launch_spg_t<false, KSUB, 2, 3, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range);
+}
+static int launch_spg(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
+                      unsigned* range, bool latency, int halves) {
+    if (S < 3 || S > 64 || boards < 1 || boards > 0x7fffffffLL) return 1;
+    if (C == 64) return launch_spg_k<2, 1>(x, w, bias, res, y, boards, S, C, relu, st, range, latency);
+    if (C == 128)
+        return halves == 2 ? launch_spg_k<4, 2>(x, w, bias, res, y, boards, S, C, relu, st, range, latency)
+                           : launch_spg_k<4, 1>(x, w, bias, res, y, boards, S, C, relu, st, range, latency);
+    if (C == 256) return launch_spg_k<8, 1>(x, w, bias, res, y, boards, S, C, relu, st, range, latency);
+    return 1;
+}
+// Latency tiles (16 couts x 32 positions = one wave) per launch up to which the wave-per-tile kernel replaces a weight-stationary one of
+// the same shape (bit-identical results; the weight-stationary kernels give a board to ONE workgroup: 10 - 33 us however few boards
+// there are).  Default 1024 = one wave per SIMD of the chip: the measured crossover (tools/spg_ab.py, profiles/r06_spg_ab.txt: the kernel
+// reads its fragments through L1, a second wave per SIMD doubles its time).  AZSP_SPG_MAX_WAVES sets the initial value (0 = never),
+// azsp_small_batch_waves changes it at run time.
+static long long& spg_max_waves_ref() {
+    static long long n = [] {
+        const char* e = getenv("AZSP_SPG_MAX_WAVES");
+        const long long v = e ? atoll(e) : 1024LL;
+        return v < 0 ? 0LL : v;
+    }();
+    return n;
+}
+static long long spg_max_waves() { return spg_max_waves_ref(); }
+static long long spg_latency_waves(long long boards, int S, int C) { return boards * ((((long long)S * S + 15) / 16 + 1) / 2) * (C / 16); }
+long long small_batch_waves(long long n) {
+    const long long old = spg_max_waves_ref();
+    if (n >= 0) spg_max_waves_ref() = n;
+    return old;
+}
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void* st, unsigned* range) {
+    static const bool sp1_env = getenv("AZSP_SP1") != nullptr;
+    const bool tailored = (S == Sp17Geo::S && C == 64) || (S == SpGeo9::S && (C == 128 || C == 64));
+    if (!tailored) return launch_spg(x, w, bias, res, y, boards, S, C, relu, st, range, spg_latency_waves(boards, S, C) <= 4 * spg_max_waves(), 1);
+    if (spg_latency_waves(boards, S, C) <= spg_max_waves()) return launch_spg(x, w, bias, res, y, boards, S, C, relu, st, range, true, (C == 128 && !sp1_env) ? 2 : 1);
     if (S == Sp17Geo::S && C == 64)  // 17x17 planes x 64 filters: the 13x13 Gomoku tower (half-board tiles)
         return res ? launch_sp17<true, 8>(x, w, bias, res, y, boards, relu, st, range) : launch_sp17<false, 8>(x, w, bias, res, y, boards, relu, st, range);
     if (S != SpGeo9::S || (C != 128 && C != 64)) return 1;
@@ -373,6 +429,16 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
 // scratch for the intermediate activation of ONE 9x9 x 64 board: the odd last board of azsp_resblock_split at 9x9 runs as two unfused
 // launches (the fused kernel takes pairs of boards).  One lazily allocated buffer per device, never freed; calls on different streams of one
 // device that both end in an odd board would share it -- the evaluator runs one stream per network.
+// scratch for the intermediate activations of azsp_resblock_split on a handful of boards (two wave-per-tile convolutions): one lazily
+// allocated buffer per device for SPG_SCRATCH_BOARDS boards of 17x17 x 64, never freed; same sharing rule as sp9_tail_scratch.
+static constexpr long long SPG_SCRATCH_BOARDS = 256;
+static void* spg_block_scratch() {
+    static void* buf[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!buf[dev] && AZ_HIP(hipMalloc(&buf[dev], (size_t)SPG_SCRATCH_BOARDS * 2 * 8 * Sb17::S * Sb17::S * 16))) return nullptr;
+    return buf[dev];
+}
 static void* sp9_tail_scratch() {
     static void* buf[16] = {};
     int dev = 0;
@@ -385,6 +451,14 @@ int launch_resblock_split(const void* x, const void* w1, const float* b1, const 
     if (C != 64 || (S != Sb17::S && S != Sb9::S)) return 1;  // 17x17 planes (the 13x13 Gomoku tower) or 9x9 planes (9x9 Go, logs/go/9x9_12b64) x 64 filters
     const int n_cu = cu_count();
     if (n_cu < 0) return -1;
+    if (spg_latency_waves(boards, S, C) <= spg_max_waves() && boards <= SPG_SCRATCH_BOARDS) {
+        // a handful of boards: two wave-per-tile convolutions (az_conv_spg.h) instead of one workgroup per board -- bit-identical results
+        void* mid = spg_block_scratch();
+        if (!mid) return -1;
+        int rc = launch_spg(x, w1, b1, nullptr, mid, boards, S, C, 1, st, range, true, 1);
+        if (rc) return rc;
+        return launch_spg(mid, w2, b2, x, y, boards, S, C, 1, st, range, true, 1);
+    }
     if (S == Sb9::S) {  // blocks of TWO boards; an odd last board: the two unfused convolutions (bit-identical results)
         const long long pairs = boards / 2;
         if (pairs > 0) {

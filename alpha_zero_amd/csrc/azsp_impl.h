@@ -615,6 +615,7 @@ int launch_split_features(const float* src, void* dst, long long boards, int S, 
 int launch_stem_split(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
                       int x_lo_zero, unsigned* range);
 int split_range_read(const unsigned* rec, unsigned out[2], int reset, void* stream);  // rec null = the default record; synchronises the stream
+long long small_batch_waves(long long n);  // n >= 0 sets the tile-wave count up to which the wave-per-tile kernel runs; returns the previous value
 int launch_head_split(const HeadSplitArgs& a, void* stream);
 int launch_stem_tiled(const void* x, const void* w, const float* bias, void* y, long long boards, int S, int C, int pad, int relu, void* stream,
                       int f16 = 0);
@@ -1216,6 +1217,8 @@ int azsp_split_range_read(const uint32_t* range_rec, uint32_t* events, float* ma
 int azsp_split_range_status(uint32_t* events, float* max_abs, int32_t reset, void* stream) {
     return azsp_split_range_read(nullptr, events, max_abs, reset, stream);
 }
+
+int64_t azsp_small_batch_waves(int64_t waves) { return (int64_t)azb::small_batch_waves((long long)waves); }
 
 int azsp_head_split(const void* x, const float* head_w, const float* head_b, const float* pol_fc_wt, const float* pol_fc_b, const float* val_fc1_wt,
                     const float* val_fc1_b, const float* val_fc2_w, float val_fc2_b, float* priors, float* values, int64_t boards, int32_t S,

@@ -300,8 +300,11 @@ int azsp_resblock_tiled(const void* x_dev, const void* w1_packed_dev, const floa
  * azsp_conv3x3_split: y = act(conv3x3(x, w) + bias [+ residual]); x, residual, y in the split layout; x must not alias y; residual
  * may alias y at 9x9 and must NOT at 17x17 (AZSP_EINVAL: the half-board tiles repeat 15 positions per board in later column tiles);
  * w_split [2 planes: hi, lo][9 taps (ky*3+kx)][C out][C in] f16 with lo = (w - hi) * 2048, bias float[C].  On the device:
- * (S, C) = (9, 128), (9, 64) and (17, 64) (the 13x13 Gomoku tower behind its pad-3 stem, network.py:101-105; half-board tiles,
- * az_conv_sp17.h); AZSP_EINVAL for other shapes.
+ * weight-stationary kernels for (S, C) = (9, 128), (9, 64) and (17, 64) (the 13x13 Gomoku tower behind its pad-3 stem,
+ * network.py:101-105; half-board tiles, az_conv_sp17.h); since round 6 every other plane size 3 <= S <= 64 with C = 64, 128 or 256
+ * on the wave-per-tile kernel (az_conv_spg.h: e.g. the 19x19 x 256 jumbo tower at the reference's own precision,
+ * alpha_zero/training_go_jumbo.py:46-47) -- and the three shapes above too when the call is small (azsp_small_batch_waves below;
+ * bit-identical results).  AZSP_EINVAL for other shapes.
  * range_rec_dev: the caller's range record -- two zero-initialised uint32 words in device memory, owned by the caller (one per
  * network: two evaluators in one process never see each other's events), read with azsp_split_range_read; NULL selects the library's
  * per-device default record (azsp_split_range_status). */
@@ -356,6 +359,17 @@ int azsp_head_split(const void* x_dev, const float* head_w_dev, const float* hea
  * back to the library's fp32 convolutions -- see InferenceNet.calibrate_activation_scale. */
 int azsp_split_range_read(const uint32_t* range_rec_dev, uint32_t* events_host, float* max_abs_host, int32_t reset, void* stream);
 int azsp_split_range_status(uint32_t* events_host, float* max_abs_host, int32_t reset, void* stream);
+
+/* Small batches (round 6).  The weight-stationary kernels behind azsp_conv3x3_split / azsp_resblock_split give every board to ONE
+ * workgroup (built for tens of thousands of boards per launch: 10 - 33 us however few boards there are).  A call whose output is at most
+ * `waves` tiles of 16 couts x 32 positions (one wave each; a 17x17 x 64 board is 40 of them) runs the wave-per-tile kernel k_conv3x3_spg
+ * instead (csrc/az_conv_spg.h: a board is spread over the chip; BIT-IDENTICAL results, so an evaluation does not depend on the batch it
+ * arrives in) -- the batch-1 forwards of a drop-in uct_search (alpha_zero/core/mcts_v2.py:301-450 evaluates one leaf at a time).
+ * Sets the process-wide limit and returns the previous one; a negative argument only queries.  Default 1024 (one wave per SIMD of an
+ * MI355X: the measured crossover, profiles/r06_spg_ab.txt), or the environment variable AZSP_SPG_MAX_WAVES; 0 = always the
+ * weight-stationary kernels.  Shapes without a weight-stationary kernel (plane sizes 3 .. 64, 64 / 128 / 256 filters) always run
+ * k_conv3x3_spg (with 32-cout x 48-position tiles beyond 4 x `waves`). */
+int64_t azsp_small_batch_waves(int64_t waves);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch
  * tensors and apply_random_transformation): out_states[b] = T_op(ring_states[idx[b]]) cast to state_dtype (AZSP_FEAT_I8 / F32 /

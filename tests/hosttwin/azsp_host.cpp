@@ -176,7 +176,7 @@ static int host_conv_split(const void* x, const void* w, const float* bias, cons
 }
 int launch_conv3x3_split(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu,
                          void*, unsigned* range) {
-    if (!((S == 9 && (C == 128 || C == 64)) || (S == 17 && C == 64))) return 1;
+    if (S < 3 || S > 64 || (C != 64 && C != 128 && C != 256)) return 1;  // (round 6: any plane size, k_conv3x3_spg)
     SpRangeScope scope(range);
     return host_conv_split(x, w, bias, res, y, boards, S, C, C, relu);
 }
@@ -187,6 +187,12 @@ int launch_resblock_split(const void* x, const void* w1, const float* b1, const 
     std::vector<unsigned short> mid((size_t)boards * 2 * S * S * C);
     if (host_conv_split(x, w1, b1, nullptr, mid.data(), boards, S, C, C, 1)) return 1;
     return host_conv_split(mid.data(), w2, b2, x, y, boards, S, C, C, 1);
+}
+long long small_batch_waves(long long n) {  // (the twin's plain loops do not depend on the batch size: the value is only kept)
+    static long long cur = 1024;
+    const long long old = cur;
+    if (n >= 0) cur = n;
+    return old;
 }
 int split_range_read(const unsigned* rec, unsigned out[2], int reset, void*) {
     unsigned* r = rec ? (unsigned*)rec : g_sp_range_host;

@@ -81,7 +81,10 @@ def test_split_abi_host_twin():
     assert bnd.dll.azsp_split_bytes(3, 9, 128) == 3 * 2 * 81 * 128 * 2 and bnd.dll.azsp_split_bytes(1, 9, 12) == -1
     assert bnd.dll.azsp_conv3x3_split(None, None, None, None, None, 1, 9, 128, 1, None, None) != 0
     z = torch.zeros(2 * 2 * 121 * 64, dtype=torch.float16)
-    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.clone().data_ptr(), 1, 11, 64, 1, None, None) != 0  # unsupported plane size
+    zb = torch.zeros(64)
+    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), zb.data_ptr(), None, z.clone().data_ptr(), 1, 11, 64, 1, None, None) == 0  # (round 6: every plane size)
+    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), zb.data_ptr(), None, z.clone().data_ptr(), 1, 11, 32, 1, None, None) != 0  # unsupported filter count
+    assert bnd.dll.azsp_conv3x3_split(z.data_ptr(), z.data_ptr(), zb.data_ptr(), None, z.clone().data_ptr(), 1, 2, 64, 1, None, None) != 0   # unsupported plane size
 
 
 def test_split_abi_host_twin_17x17_and_pad3_stem():
@@ -666,3 +669,126 @@ def test_gpu_split_resblock17_records_intermediate_overflow():
     torch.cuda.synchronize()
     r = rec.cpu()
     assert int(r[0]) > 0 and float(r[1:].view(torch.float32)[0]) > 65504.0
+
+
+# ---- round 6: the wave-per-tile kernel k_conv3x3_spg (small batches of the tailored shapes, every other shape) -------------------------
+def _raw_split_conv(bnd, x, r, w, b, relu, device="cuda"):
+    """azsp_conv3x3_split on fp32 NCHW inputs; returns the raw split-layout output (f16 words) and the joined fp32 NCHW output."""
+    B, C, S, _ = x.shape
+    dll = bnd.dll
+    n = dll.azsp_split_bytes(B, S, C) // 2
+    xs, ys = torch.zeros(n, dtype=torch.float16, device=device), torch.zeros(n, dtype=torch.float16, device=device)
+    xc = x.to(device).contiguous(memory_format=torch.channels_last)
+    assert dll.azsp_split_layout(xc.data_ptr(), xs.data_ptr(), B, S, C, 1, None, None) == 0
+    rs = None
+    if r is not None:
+        rs = torch.zeros(n, dtype=torch.float16, device=device)
+        assert dll.azsp_split_layout(r.to(device).contiguous(memory_format=torch.channels_last).data_ptr(), rs.data_ptr(), B, S, C, 1, None, None) == 0
+    wsp, bb = split_weights_f16(w).to(device), b.float().to(device)
+    assert dll.azsp_conv3x3_split(xs.data_ptr(), wsp.data_ptr(), bb.data_ptr(), rs.data_ptr() if rs is not None else None, ys.data_ptr(),
+                                  B, S, C, relu, None, None) == 0
+    y = torch.empty_like(xc)
+    assert dll.azsp_split_layout(ys.data_ptr(), y.data_ptr(), B, S, C, 0, None, None) == 0
+    if device != "cpu":
+        torch.cuda.synchronize()
+    return ys.cpu(), y.cpu().contiguous()
+
+
+def test_small_batch_knob_host_twin():
+    """azsp_small_batch_waves: sets, returns the previous value, a negative argument only queries (the twin's loops ignore it)."""
+    import engine_util as eu
+
+    b, _ = eu.backend("host")
+    old = b.dll.azsp_small_batch_waves(-1)
+    assert b.dll.azsp_small_batch_waves(7) == old and b.dll.azsp_small_batch_waves(-1) == 7
+    assert b.dll.azsp_small_batch_waves(old) == 7 and b.dll.azsp_small_batch_waves(-5) == old
+    # shapes beyond the tailored ones go through the ABI since round 6 (19x19 x 64 here: the twin's plain loops vs fp64)
+    x, r, w, bb = _inputs(2, 64, 19, 5)
+    y, rt = _run_split_conv(b, x, r, w, bb, 1, "cpu")
+    ref = _ref64(x, r, w, bb, 1)
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() <= 8e-7 and rt <= 2.0 ** -21
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C", [(9, 128), (9, 64), (17, 64)])
+def test_gpu_wave_per_tile_conv_is_bit_identical_to_the_weight_stationary_kernels(S, C):
+    """k_conv3x3_spg (one wave per 16-cout x 32-position tile, fragments straight from global memory) against the tailored kernel of the
+    same shape -- k_conv3x3_sp2 (two accumulation chains), k_conv3x3_sp<.., 8, 1>, k_conv3x3_sp17 -- on the same inputs: the raw hi / lo
+    f16 words of the output are equal, with and without residual and ReLU.  The evaluator's result for a position therefore does not
+    depend on whether it arrives in a batch of 1 (drop-in uct_search) or of 32 768 (the self-play actor)."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    old = bnd.dll.azsp_small_batch_waves(-1)
+    try:
+        for boards in (1, 3, 19):
+            for res, relu in ((False, 1), (True, 1), (True, 0)):
+                x, r, w, b = _inputs(boards, C, S, 300 + boards)
+                if not relu:
+                    x = x - 0.3
+                bnd.dll.azsp_small_batch_waves(0)
+                ya, fa = _raw_split_conv(bnd, x, r if res else None, w, b, relu)
+                bnd.dll.azsp_small_batch_waves(1 << 20)
+                yb, fb = _raw_split_conv(bnd, x, r if res else None, w, b, relu)
+                if not torch.equal(ya, yb):
+                    d = (ya.view(boards, 2, C // 8, S * S, 8) != yb.view(boards, 2, C // 8, S * S, 8)).any(dim=4).any(dim=1).nonzero()
+                    raise AssertionError(f"S={S} C={C} boards={boards} res={res} relu={relu}: {len(d)} cells differ; first {d[:10].tolist()}; "
+                                         f"max |d| = {(fa - fb).abs().max().item():.3g}")
+    finally:
+        bnd.dll.azsp_small_batch_waves(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [17, 9])
+def test_gpu_small_batch_resblock_is_bit_identical_to_the_fused_block(S):
+    """azsp_resblock_split on a handful of boards = two wave-per-tile convolutions through a scratch buffer: the same bits as the fused
+    one-launch block (which is itself bit-identical to two weight-stationary launches)."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    old = bnd.dll.azsp_small_batch_waves(-1)
+    try:
+        for boards in (1, 2, 5, 25):
+            x, ws, bs = _resblock_inputs(boards, 400 + boards, S)
+            bnd.dll.azsp_small_batch_waves(0)
+            yf0, y20, _ = _resblock_both_ways(bnd, x, ws, bs, "cuda")
+            bnd.dll.azsp_small_batch_waves(1 << 20)
+            yf1, y21, _ = _resblock_both_ways(bnd, x, ws, bs, "cuda")
+            assert torch.equal(yf0, y20) and torch.equal(yf1, y21) and torch.equal(yf0, yf1), (S, boards)
+    finally:
+        bnd.dll.azsp_small_batch_waves(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C,boards", [(19, 256, 2), (19, 256, 70), (19, 128, 5), (19, 64, 3), (13, 64, 4), (13, 128, 33), (5, 64, 7), (25, 64, 2)])
+def test_gpu_wave_per_tile_conv_on_shapes_without_a_tailored_kernel(S, C, boards):
+    """The fp32-class convolution for EVERY plane size (the reference's 19x19 x 256 jumbo tower at its own precision,
+    alpha_zero/training_go_jumbo.py:46-47; 13x13 Go; 5x5 test boards): against fp64 with the bound of the tailored kernels (8e-7 of
+    max |y|; 1.2e-6 at 256 filters, twice the products per output), the library's fp32 error beside it; the two tile shapes of the kernel (latency / throughput) give the same bits."""
+    from alpha_zero_amd import _lib
+
+    bnd = _lib.load()
+    old = bnd.dll.azsp_small_batch_waves(-1)
+    try:
+        for res, relu in ((False, 1), (True, 1), (True, 0)):
+            x, r, w, b = _inputs(boards, C, S, 500 + boards)
+            if not relu:
+                x = x - 0.3
+            bnd.dll.azsp_small_batch_waves(0)        # 32 couts x 48 positions per wave
+            ya, y = _raw_split_conv(bnd, x, r if res else None, w, b, relu)
+            bnd.dll.azsp_small_batch_waves(1 << 20)  # 16 couts x 32 positions per wave
+            yb, _ = _raw_split_conv(bnd, x, r if res else None, w, b, relu)
+            assert torch.equal(ya, yb), (S, C, boards, res, relu)
+            ref = _ref64(x, r if res else None, w, b, relu)
+            lib = F.conv2d(x.cuda(), w.cuda(), b.cuda(), padding=1)
+            if res:
+                lib = lib + r.cuda()
+            lib = (torch.relu(lib) if relu else lib).cpu()
+            scale = ref.abs().max().item()
+            err, lib_err = (y.double() - ref).abs().max().item() / scale, (lib.double() - ref).abs().max().item() / scale
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "split_conv_generic_error.jsonl"), "a") as f:
+                f.write(json.dumps(dict(S=S, C=C, boards=boards, residual=res, relu=relu, err=err, library_fp32_err=lib_err)) + "\n")
+            assert err <= (8e-7 if C <= 128 else 1.2e-6), (S, C, boards, res, relu, err, lib_err)  # (2304 products per output at 256 filters)
+    finally:
+        bnd.dll.azsp_small_batch_waves(old)

@@ -38,6 +38,7 @@ for J in "$@"; do
     rocprof_c5) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rb5 && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/rb5 -- python $GRAFT_REPO_ROOT/bench.py --board 19 --games 1024 --sims 800 --blocks 20 --filters 256 --net-dtype bf16 --steps 40 --warmup 5 --no-companions --no-fresh-tree --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/bench_c5_under_rocprof.json 2> /tmp/rb5.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rb5 -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_go19_c5.txt 2>&1); echo "rocprof c5 rc=$?" | tee -a $O/status.txt; head -6 $O/kernel_stats_go19_c5.txt | cut -c1-160 ;;
     dropin_ab) timeout 300 python tools/dropin_resident_ab.py 2>&1 | grep -v amdgpu.ids > $O/dropin_resident_ab.txt; echo "dropin_ab rc=$?" | tee -a $O/status.txt; cat $O/dropin_resident_ab.txt ;;
     rocprof_dropin) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rbd && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rbd -- python $GRAFT_REPO_ROOT/tools/dropin_resident_ab.py 3 > $GRAFT_REPO_ROOT/$O/dropin_ab_under_rocprof.txt 2> /tmp/rbd.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rbd -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_dropin_c1.txt 2>&1); echo "rocprof dropin rc=$?" | tee -a $O/status.txt; head -24 $O/kernel_stats_dropin_c1.txt | cut -c1-170 ;;
+    spg_ab) timeout 600 python tools/spg_ab.py 2>&1 | grep -v amdgpu.ids > $O/spg_ab.txt; echo "spg_ab rc=$?" | tee -a $O/status.txt; head -60 $O/spg_ab.txt ;;
     conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac
