@@ -346,7 +346,8 @@ static int launch_sp17(const void* x, const void* w, const float* bias, const vo
     return AZ_HIP(hipGetLastError());
 }
 // k_conv3x3_spg (az_conv_spg.h): the fp32-class convolution with one WAVE per output tile -- any plane size, 64 / 128 / 256 filters.
-// `latency`: small tiles (16 couts x 32 positions per wave) so that a handful of boards fill the chip; otherwise 32 couts x 48 positions.
+// `latency`: small tiles (16 couts x 32 positions per wave) so that a handful of boards fill the chip; otherwise k_conv3x3_spgw:
+// 16 NT couts x 48 positions per wave, the B fragments shared by the four waves of a workgroup through LDS.
 // `halves` = 2: k_conv3x3_sp2's two accumulation chains (bit-identical to it at 9x9 x 128).
 template <bool RES, int KSUB, int NT, int NJ, int HALVES>
 static int launch_spg_t(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
@@ -357,14 +358,25 @@ static int launch_spg_t(const void* x, const void* w, const float* bias, const v
                        bias, (const unsigned char*)(RES ? res : nullptr), (unsigned char*)y, (int)boards, S, C, relu, range);
     return AZ_HIP(hipGetLastError());
 }
+// large calls: the four waves of a workgroup share their B fragments through LDS (k_conv3x3_spgw; NT cout tiles per wave, C = 64 NT x groups)
+template <bool RES, int KSUB, int NT, int HALVES>
+static int launch_spgw_t(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
+                         unsigned* range) {
+    const long long nct = ((long long)S * S + 15) / 16, grid = boards * ((nct + 2) / 3) * (C / (64 * NT));
+    if (grid > 0x7fffffffLL || C % (64 * NT)) return 1;
+    hipLaunchKernelGGL((k_conv3x3_spgw<RES, KSUB, NT, HALVES>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
+                       (const unsigned char*)(RES ? res : nullptr), (unsigned char*)y, (int)boards, S, C, relu, range);
+    return AZ_HIP(hipGetLastError());
+}
 template <int KSUB, int HALVES>
 static int launch_spg_k(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
                         unsigned* range, bool latency) {
     if (latency)
         return res ? launch_spg_t<true, KSUB, 1, 2, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range)
                    : launch_spg_t<false, KSUB, 1, 2, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range);
-    return res ? launch_spg_t<true, KSUB, 2, 3, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range)
-               : launch_spg_t<false, KSUB, 2, 3, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range);
+    constexpr int NT = KSUB == 2 ? 1 : 2;
+    return res ? launch_spgw_t<true, KSUB, NT, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range)
+               : launch_spgw_t<false, KSUB, NT, HALVES>(x, w, bias, res, y, boards, S, C, relu, st, range);
 }
 static int launch_spg(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
                       unsigned* range, bool latency, int halves) {
@@ -400,7 +412,7 @@ int launch_conv3x3_split(const void* x, const void* w, const float* bias, const 
                          void* st, unsigned* range) {
     static const bool sp1_env = getenv("AZSP_SP1") != nullptr;
     const bool tailored = (S == Sp17Geo::S && C == 64) || (S == SpGeo9::S && (C == 128 || C == 64));
-    if (!tailored) return launch_spg(x, w, bias, res, y, boards, S, C, relu, st, range, spg_latency_waves(boards, S, C) <= 4 * spg_max_waves(), 1);
+    if (!tailored) return launch_spg(x, w, bias, res, y, boards, S, C, relu, st, range, spg_latency_waves(boards, S, C) <= spg_max_waves(), 1);
     if (spg_latency_waves(boards, S, C) <= spg_max_waves()) return launch_spg(x, w, bias, res, y, boards, S, C, relu, st, range, true, (C == 128 && !sp1_env) ? 2 : 1);
     if (S == Sp17Geo::S && C == 64)  // 17x17 planes x 64 filters: the 13x13 Gomoku tower (half-board tiles)
         return res ? launch_sp17<true, 8>(x, w, bias, res, y, boards, relu, st, range) : launch_sp17<false, 8>(x, w, bias, res, y, boards, relu, st, range);

@@ -856,7 +856,9 @@ def main(argv=None):
             "value": round(total_moves / elapsed_max, 2), "unit": "moves/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "process_group": process_group,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_LABEL[args.net_dtype] if (args.net_dtype != "fp32" or (conv is not None and conv["split"])) else "fp32 (library convolutions) / f32-f64 tree",
+            "dtype": DTYPE_LABEL[args.net_dtype] if (args.net_dtype != "fp32" or (conv is not None and conv["split"])) else (
+                "fp32-class tower (f16 hi+lo pairs, 3 MFMA products, fp32 accumulate) behind library fp32 stem and heads / f32-f64 tree"
+                if "split-precision tower" in actor.evaluator_path else "fp32 (library convolutions) / f32-f64 tree"),
             "data": "synthetic",
             "config": {"workload": f"{n}x{n} {game}, {args.games} games/GPU, {args.sims} sims/move (reference budget semantics), P={args.parallel}, "
                                    f"{args.blocks}x{args.filters} net", "net_dtype": args.net_dtype, "tree_dtype": "f32 (f64 noisy root)",

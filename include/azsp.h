@@ -368,7 +368,7 @@ int azsp_split_range_status(uint32_t* events_host, float* max_abs_host, int32_t 
  * Sets the process-wide limit and returns the previous one; a negative argument only queries.  Default 1024 (one wave per SIMD of an
  * MI355X: the measured crossover, profiles/r06_spg_ab.txt), or the environment variable AZSP_SPG_MAX_WAVES; 0 = always the
  * weight-stationary kernels.  Shapes without a weight-stationary kernel (plane sizes 3 .. 64, 64 / 128 / 256 filters) always run
- * k_conv3x3_spg (with 32-cout x 48-position tiles beyond 4 x `waves`). */
+ * k_conv3x3_spg (beyond `waves`: k_conv3x3_spgw, 48-position tiles whose activations a workgroup shares through LDS). */
 int64_t azsp_small_batch_waves(int64_t waves);
 
 /* Replay sampling on the device (core/replay.py:72-83 UniformReplay.sample + core/pipeline.py:636-643: the batch

@@ -774,9 +774,9 @@ def test_gpu_wave_per_tile_conv_on_shapes_without_a_tailored_kernel(S, C, boards
             x, r, w, b = _inputs(boards, C, S, 500 + boards)
             if not relu:
                 x = x - 0.3
-            bnd.dll.azsp_small_batch_waves(0)        # 32 couts x 48 positions per wave
+            bnd.dll.azsp_small_batch_waves(0)        # k_conv3x3_spgw: 48 positions per wave, B fragments shared by the workgroup through LDS
             ya, y = _raw_split_conv(bnd, x, r if res else None, w, b, relu)
-            bnd.dll.azsp_small_batch_waves(1 << 20)  # 16 couts x 32 positions per wave
+            bnd.dll.azsp_small_batch_waves(1 << 20)  # k_conv3x3_spg: 16 couts x 32 positions per wave, no LDS
             yb, _ = _raw_split_conv(bnd, x, r if res else None, w, b, relu)
             assert torch.equal(ya, yb), (S, C, boards, res, relu)
             ref = _ref64(x, r if res else None, w, b, relu)
