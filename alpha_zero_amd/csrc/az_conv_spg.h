@@ -188,7 +188,11 @@ k_conv3x3_spgw(const unsigned char* __restrict__ x, const _Float16* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P2 = S * S, NCT = (P2 + 15) >> 4, NJG = (NCT + NJ - 1) / NJ, NCQ = C / (64 * NT);  // groups of four cout groups
-    const long long wg = blockIdx.x;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2); all workgroups of a board (NJG x NCQ of them, each
+    // reading the board's activations with a halo) are given to ONE XCD, so that the board is fetched from HBM once instead of once per XCD
+    // (PMC, 19x19 x 256: FETCH_SIZE 4.5 GB per launch = 12 x the input with the plain order).  The launcher pads the grid to a multiple of 8.
+    const long long per_xcd = gridDim.x >> 3, wg = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wg >= (long long)nboards * NJG * NCQ) return;  // (uniform per workgroup, in front of every barrier)
     const int cg = (int)(wg % NCQ) * 4 + wave, jg = (int)((wg / NCQ) % NJG);
     const long long board = wg / ((long long)NCQ * NJG);
     const size_t xplane = (size_t)NCHI * P2 * 16, yplane = (size_t)(C / 8) * P2 * 16;

@@ -362,7 +362,7 @@ static int launch_spg_t(const void* x, const void* w, const float* bias, const v
 template <bool RES, int KSUB, int NT, int HALVES>
 static int launch_spgw_t(const void* x, const void* w, const float* bias, const void* res, void* y, long long boards, int S, int C, int relu, void* st,
                          unsigned* range) {
-    const long long nct = ((long long)S * S + 15) / 16, grid = boards * ((nct + 2) / 3) * (C / (64 * NT));
+    const long long nct = ((long long)S * S + 15) / 16, grid = (boards * ((nct + 2) / 3) * (C / (64 * NT)) + 7) / 8 * 8;  // (a multiple of 8: XCD-aware order)
     if (grid > 0x7fffffffLL || C % (64 * NT)) return 1;
     hipLaunchKernelGGL((k_conv3x3_spgw<RES, KSUB, NT, HALVES>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)st, (const unsigned char*)x, (const _Float16*)w, bias,
                        (const unsigned char*)(RES ? res : nullptr), (unsigned char*)y, (int)boards, S, C, relu, range);

@@ -16,6 +16,7 @@ FAMILY_SOURCES = {
     "splitblock17": ["az_resblock_sp17.h", "az_conv_sp17.h", "az_conv_sp.h", "az_conv.h"],
     "tiled9": ["az_conv.h"],
     "hb19": ["az_conv19.h", "az_conv.h"],
+    "spg19": ["az_conv_spg.h", "az_conv_sp.h", "az_conv.h"],
 }
 # profiles/<file> -> family
 PMC_FILE_FAMILY = {
@@ -25,6 +26,7 @@ PMC_FILE_FAMILY = {
     "splitblock9_64_kernel_pmc.json": "splitblock9_64",
     "conv_kernel_pmc.json": "tiled9",
     "conv19_kernel_pmc.json": "hb19",
+    "spg19_kernel_pmc.json": "spg19",
 }
 
 

@@ -1,7 +1,7 @@
 """A handful of launches of ONE tower-convolution kernel family on post-ReLU-like data, for `rocprofv3 --pmc ...` / `--kernel-trace` passes.
 usage: python tools/pmc_launches.py <family> [boards]    family: split9 (k_conv3x3_sp, 9x9 x 128), split9_64, split17 (k_conv3x3_sp17,
 17x17 x 64), splitblock17 / splitblock9_64 (k_resblock_sp: one launch per ResNetBlock, 17x17 x 64 / 9x9 x 64), tiled9 (k_conv3x3_tiled bf16, 9x9 x 128), hb19
-(k_conv3x3_hb19 bf16, 19x19 x 256, two launches per convolution).
+(k_conv3x3_hb19 bf16, 19x19 x 256, two launches per convolution), spg19 (k_conv3x3_spgw: the wave-per-tile fp32-class convolution on 19x19 x 256, 1024 boards).
 Launch i uses a residual when i is odd (the forward alternates plain / residual layers)."""
 import os
 import sys
@@ -14,8 +14,8 @@ from alpha_zero_amd.core.network import split_weights_f16
 
 fam = sys.argv[1]
 S, C, split = {"split9": (9, 128, True), "split9_64": (9, 64, True), "splitblock9_64": (9, 64, True), "split17": (17, 64, True), "splitblock17": (17, 64, True), "tiled9": (9, 128, False),
-               "hb19": (19, 256, False)}[fam]
-B = int(sys.argv[2]) if len(sys.argv) > 2 else (4096 if fam == "hb19" else 32768)
+               "hb19": (19, 256, False), "spg19": (19, 256, True)}[fam]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (4096 if fam == "hb19" else 1024 if fam == "spg19" else 32768)
 N = int(os.environ.get("PMC_LAUNCHES", "6"))
 b = _lib.load()
 g = torch.Generator().manual_seed(0)

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kernel_digest import kernel_source_digest  # noqa: E402
 
 GEOM = {"split9": (9, 9, 128, 4, 2.5), "split9_64": (9, 9, 64, 4, 2.5), "splitblock9_64": (9, 9, 64, 4, 2.0), "split17": (13, 17, 64, 4, 2.5),
-        "splitblock17": (13, 17, 64, 4, 2.0), "tiled9": (9, 9, 128, 2, 2.5), "hb19": (19, 19, 256, 2, 2.5)}  # board, planes, channels, bytes/elem, passes
+        "splitblock17": (13, 17, 64, 4, 2.0), "tiled9": (9, 9, 128, 2, 2.5), "hb19": (19, 19, 256, 2, 2.5), "spg19": (19, 19, 256, 4, 2.5)}  # board, planes, channels, bytes/elem, passes
 
 
 def parse(txt):
@@ -26,7 +26,7 @@ def parse(txt):
             if m:
                 trace.append({"calls": int(m.group(1)), "avg_us": float(m.group(3)), "name": m.group(5).strip()})
                 continue
-        m = re.match(r"\s+(\S.*?)\s+([A-Z][A-Z_0-9]+)\s+n=(\d+)\s+mean=([\d.e+-]+)", ln)  # (demangled kernel names contain blanks)
+        m = re.match(r"\s+(\S.*?)\s+([A-Z][A-Za-z_0-9]+)\s+n=(\d+)\s+mean=([\d.e+-]+)", ln)  # (demangled kernel names contain blanks)
         if m:
             out.setdefault(m.group(1).strip(), {})[m.group(2)] = float(m.group(4))
     return trace, out
@@ -42,7 +42,7 @@ def short_name(n):
 
 def main():
     fam, src, dst = sys.argv[1], sys.argv[2], sys.argv[3]
-    rows = int(sys.argv[4]) if len(sys.argv) > 4 else (4096 if fam == "hb19" else 32768)
+    rows = int(sys.argv[4]) if len(sys.argv) > 4 else (4096 if fam == "hb19" else 1024 if fam == "spg19" else 32768)
     board, planes, ch, elem, passes = GEOM[fam]
     trace, ctr = parse(open(src).read())
     kernels = {}
@@ -61,9 +61,12 @@ def main():
                 k["mfma_busy_fraction"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
             if us:
                 k["effective_clock_GHz"] = round(cyc / (us * 1e3), 4)
-        for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
+        for n in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum",
+                  "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum"):
             if n in c:
                 k[n] = c[n]
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+            k["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
             k["lds_bank_conflict_fraction"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
         kernels[kname] = k

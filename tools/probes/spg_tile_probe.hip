@@ -30,7 +30,7 @@ template <int KSUB, int NT, int NJ, int R> static void run(const char* tag, int 
 }
 
 template <int KSUB, int NT> static void run_w(const char* tag, int boards, int S, int C, const unsigned char* x, const _Float16* w, const float* b, unsigned char* y, size_t ybytes) {
-    const long long nct = ((long long)S * S + 15) / 16, grid = boards * ((nct + 2) / 3) * (C / (64 * NT));
+    const long long nct = ((long long)S * S + 15) / 16, grid = (boards * ((nct + 2) / 3) * (C / (64 * NT)) + 7) / 8 * 8;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
