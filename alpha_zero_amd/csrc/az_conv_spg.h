@@ -288,5 +288,4 @@ k_conv3x3_spgw(const unsigned char* __restrict__ x, const _Float16* __restrict__
     }, typename CpMakeSeq<NST>::type{});
     spg_epilogue<RES, NT, NJ, HALVES>(am, ac, pos, live, res, y, board, yplane, P2, cg, kg, lo_clamp, range);
 }
-
 #endif
