@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-box job script (replaces the per-call tools/gpu_r5[a-o].sh of round 5).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_job.sh <job> [<job> ...]'      outputs under gpurun_out/r6/
-# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | smoke
+# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | rocprof_c2 | rocprof_c5 | rocprof_dropin | resblock_ab:<S> | dropin_ab | spg_ab | soak | smoke
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r6
 mkdir -p $O
