@@ -21,10 +21,20 @@
 
 #if defined(__HIPCC__)
 #define SP2_NB 13  // boards per corner batch
+#ifndef SP2_SPREAD_FRAGS
+#define SP2_SPREAD_FRAGS 1
+#endif
 
 // Vector-memory instructions a wave issues between the last LDS-DMA piece of the next board (unit 0, behind the MFMAs of k-step NPIECE) and the
 // board barrier (unit 1, k-step KS - (R - 1)): the stores of the finishing riders (2 per column tile) and unit 1's residual loads.  Mirrors the
 // kernel's schedule (same constants, same SpSpread arithmetic); every one of them is issued unconditionally.
+// one v_fma_f32, opaque to the compiler: left to itself it pairs the four joins of a hand-over into two v_pk_fma_f32, and a packed fp32
+// instruction costs about four scalar ones beside the MFMA stream (measured: profiles/r06_packed_epilogue_ab.txt)
+__device__ __forceinline__ float sp2_fma_f32(float a, float s, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c));
+    return r;
+}
 template <bool RES> __host__ __device__ constexpr int sp2_vm_younger() {
     constexpr int KS = 18, R = 2, S0 = 6, NPIECE = 16, NT = 2;
     constexpr int E1 = RES ? 4 : 2, PAIR = 2 * E1 + 8, CT_OPS = 2 * PAIR + 2, P2CT = CT_OPS + 1;
@@ -145,6 +155,14 @@ k_conv3x3_sp2(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
         for (int j = 0; j < NJ0; ++j)
             if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + lmap[j0 + j] + off + LPLANE);
     };
+    // fragment f of a k-step's 2 nj (plane f / nj, column tile f % nj) -- inside the units the requests are SPREAD over the first MFMA gaps of
+    // the k-step before (one ds_read_b128 per gap) instead of being issued as a burst of 2 nj reads in front of it
+    auto load_frag = [&](const unsigned char* img, int j0, int nj, int s, int rs, int f) __attribute__((always_inline)) {
+        const int tap = s / KSUB;
+        const int off = ((tap / 3) * G::PITCH + (tap % 3)) * 16 + (s % KSUB) * (4 * LBLK);
+        const int pl = f / nj, j = f % nj;
+        bb[rs][pl][j] = *(const sp_f16x8*)(img + lmap[j0 + j] + off + pl * LPLANE);
+    };
     {
         const unsigned char* src = x + (size_t)slot * XTILE;
 #pragma unroll
@@ -178,7 +196,7 @@ k_conv3x3_sp2(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
     const unsigned char* const xb_partner = lds + XB0 + (wave ^ 1) * 1024 + lane * 16;
     // hand-over micro-op o of column tile c of the unit with accumulator set `set`: join the partner's tile (4), write it (1)
     auto send_op = [&](int set, int c, int o) {
-        if (o < 4) xs[o] = fmaf(accc[set][c][1][o], SP_INV_SCALE, accm[set][c][1][o]);
+        if (o < 4) xs[o] = sp2_fma_f32(accc[set][c][1][o], SP_INV_SCALE, accm[set][c][1][o]);
         else *(c6_f32x4*)(xb_mine + c * XBCT) = xs;
     };
     // micro-op o of the finishing of column tile c (lmap index mj): the partner's partial (1 read), then the epilogue of the own tile
@@ -270,9 +288,11 @@ k_conv3x3_sp2(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first board: conservative
                     CV_BARRIER();
                 }
-                if constexpr (t + R - 1 < KS) load_step(Xs, j0, nj, t + R - 1, (g + R - 1) % R);
-                else if constexpr (i == 0) load_step(Xs, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
-                else load_step(Xn, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
+                // the fragments of k-step t + R - 1 (of this unit, or of the next unit: unit 1 of this board / unit 0 of the next board's image)
+                constexpr bool lsame = t + R - 1 < KS;
+                constexpr int ls = lsame ? t + R - 1 : t + R - 1 - KS, lnj = lsame ? nj : nnj, lj0 = lsame ? j0 : nj0, lrs = (g + R - 1) % R;
+                const unsigned char* limg = (lsame || i == 0) ? Xs : Xn;
+                if constexpr (!SP2_SPREAD_FRAGS) load_step(limg, lj0, lnj, ls, lrs);
                 cp_for_each([&](auto QC) __attribute__((always_inline)) {
                     constexpr int q = decltype(QC)::value, j = q % nj, r6 = q / nj, tt = r6 / 3, prod = r6 % 3;
                     constexpr int sl = t * NQ + q;  // MFMA slot of the unit
@@ -292,6 +312,7 @@ k_conv3x3_sp2(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
                         if constexpr (fa < NF_A) sp_mfma_a(accc[set][j][tt], wf[fa], bb[g % R][pl][j]);
                         else sp_mfma_v(accc[set][j][tt], wf[fa], bb[g % R][pl][j]);
                     }
+                    if constexpr (SP2_SPREAD_FRAGS && q < 2 * lnj) load_frag(limg, lj0, lnj, ls, lrs, q);
                     if constexpr (sl >= S0 && sl < S0 + P1) send_op(pset, (sl - S0) / 5, (sl - S0) % 5);
                     if constexpr (sl > SBX) {
                         constexpr int o = SP::cum(sl - 1);

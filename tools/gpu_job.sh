@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-box job script (replaces the per-call tools/gpu_r5[a-o].sh of round 5).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_job.sh <job> [<job> ...]'      outputs under gpurun_out/r6/
-# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | rocprof_c2 | rocprof_c5 | rocprof_dropin | resblock_ab:<S> | prev_ab | dropin_ab | spg_ab | soak | smoke
+# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | rocprof_c2 | rocprof_c5 | rocprof_dropin | resblock_ab:<S> | prev_ab | chunk_probe | dropin_ab | spg_ab | soak | smoke
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r6
 mkdir -p $O
@@ -40,6 +40,7 @@ for J in "$@"; do
     rocprof_dropin) (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/rbd && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rbd -- python $GRAFT_REPO_ROOT/tools/dropin_resident_ab.py 3 > $GRAFT_REPO_ROOT/$O/dropin_ab_under_rocprof.txt 2> /tmp/rbd.err; python $GRAFT_REPO_ROOT/tools/rocprof_summary.py $(find /tmp/rbd -name "*.db" | head -1) > $GRAFT_REPO_ROOT/$O/kernel_stats_dropin_c1.txt 2>&1); echo "rocprof dropin rc=$?" | tee -a $O/status.txt; head -24 $O/kernel_stats_dropin_c1.txt | cut -c1-170 ;;
     spg_ab) timeout 600 python tools/spg_ab.py 2>&1 | grep -v amdgpu.ids > $O/spg_ab.txt; echo "spg_ab rc=$?" | tee -a $O/status.txt; head -60 $O/spg_ab.txt ;;
     prev_ab) timeout 900 python tools/split_prev_ab.py 2>&1 | grep -v amdgpu.ids > $O/split_prev_ab.txt; echo "prev_ab rc=$?" | tee -a $O/status.txt; grep -v "  round" $O/split_prev_ab.txt ;;
+    chunk_probe) timeout 900 python tools/chunk_major_probe.py 2>&1 | grep -v amdgpu.ids > $O/chunk_major_probe.txt; echo "chunk_probe rc=$?" | tee -a $O/status.txt; grep -v "  round" $O/chunk_major_probe.txt ;;
     conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac

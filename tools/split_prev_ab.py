@@ -75,8 +75,8 @@ for name, mk in (("conv 9x9 x 128 plain", lambda: case_conv(9, 128, False)), ("c
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 30
-            tot[k] += ms
+            tot[k] += ms if rnd > 0 else 0.0  # (round 0 warms the clocks up)
             print(f"  round {rnd} {k:6s} {ms:7.4f} ms  frac {flops / ms / 1e9 / 2500:.4f}", flush=True)
-    print(f"  mean tree {tot['tree'] / ROUNDS:.4f} ms, other {tot['other'] / ROUNDS:.4f} ms: tree / other = {tot['tree'] / tot['other']:.4f}", flush=True)
+    print(f"  mean of rounds 1.. : tree {tot['tree'] / (ROUNDS - 1):.4f} ms, other {tot['other'] / (ROUNDS - 1):.4f} ms: tree / other = {tot['tree'] / tot['other']:.4f}", flush=True)
     del run, ys
     torch.cuda.empty_cache()
