@@ -244,6 +244,15 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
         }
     };
 
+    // fragment f of a k-step (plane f / nj, column tile f % nj): inside the units the requests are spread over the first MFMA gaps of the
+    // k-step R - 1 before their use (one ds_read_b128 per gap instead of a burst in front of a k-step; see k_conv3x3_sp)
+    auto load_frag = [&](const unsigned char* img, int j0, int nj, int s, int rs, int f) __attribute__((always_inline)) {
+        const int tap = s / KSUB;
+        const int off = ((tap / 3) * G::PITCH + (tap % 3)) * 16 + (s % KSUB) * (4 * LBLK);
+        const int pl = f / nj, j = f % nj;
+        bb[rs][pl][j] = *(const sp_f16x8*)(img + (lmap[j0 + j] & 0xffffu) + off + pl * LPLANE);
+    };
+
     {   // first tile (upper half of the first board): all pieces at once, then the first fragments
         const unsigned char* src = x + (size_t)slot * XTILE;
 #pragma unroll
@@ -351,11 +360,16 @@ k_conv3x3_sp17(const unsigned char* __restrict__ x, const _Float16* __restrict__
                     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_YOUNGER) : "memory");
                     CV_BARRIER();
                 }
-                if constexpr (t + R - 1 < KS) load_step(Xs, j0, nj, t + R - 1, (g + R - 1) % R);
-                else if constexpr (U < 3) load_step(Xs, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
-                else load_step(Xn, nj0, nnj, t + R - 1 - KS, (g + R - 1) % R);
+                // the fragments of k-step t + R - 1 (of this unit, of the next unit of this tile, or of the first unit of the next tile's image)
+                constexpr bool lsame = t + R - 1 < KS;
+                constexpr int ls = lsame ? t + R - 1 : t + R - 1 - KS, lnj = lsame ? nj : nnj, lj0 = lsame ? j0 : nj0, lrs = (g + R - 1) % R;
+                const unsigned char* limg = (lsame || U < 3) ? Xs : Xn;
                 cp_for_each([&](auto QC) __attribute__((always_inline)) {
                     constexpr int q = decltype(QC)::value, j = q % nj;
+                    cp_for_each([&](auto FC) __attribute__((always_inline)) {  // fragment q in gap q (the rest in the last gap of a short k-step)
+                        constexpr int f = decltype(FC)::value;
+                        if constexpr ((f < NQ ? f : NQ - 1) == q) load_frag(limg, lj0, lnj, ls, lrs, f);
+                    }, typename CpMakeSeq<(XLO0 ? 1 : 2) * lnj>::type{});
                     constexpr int prod = XLO0 ? (q / nj == 0 ? 0 : 2) : q / nj;       // product 0: main, 1: w_hi x_lo (skipped when x_lo = 0), 2: w_lo x_hi
                     constexpr int fa = prod == 2 ? KS + t : t, pl = prod == 1 ? 1 : 0;
                     if constexpr (prod == 0) {

@@ -312,6 +312,7 @@ k_conv3x3_sp2(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
                         if constexpr (fa < NF_A) sp_mfma_a(accc[set][j][tt], wf[fa], bb[g % R][pl][j]);
                         else sp_mfma_v(accc[set][j][tt], wf[fa], bb[g % R][pl][j]);
                     }
+                    static_assert(2 * lnj <= NQ, "a fragment per MFMA gap");
                     if constexpr (SP2_SPREAD_FRAGS && q < 2 * lnj) load_frag(limg, lj0, lnj, ls, lrs, q);
                     if constexpr (sl >= S0 && sl < S0 + P1) send_op(pset, (sl - S0) / 5, (sl - S0) % 5);
                     if constexpr (sl > SBX) {

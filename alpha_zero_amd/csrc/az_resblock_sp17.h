@@ -370,6 +370,16 @@ k_resblock_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
             if (j < nj) bb[rs][1][j] = *(const sp_f16x8*)(img + lm[rot][j].x + off + PLANE);
     };
 
+    // fragment f of a k-step's 2 nj (plane f / nj, column tile f % nj): inside the units the requests are spread over the first MFMA gaps of
+    // the k-step R - 1 before their use (one ds_read_b128 per gap instead of a burst of 2 nj in front of a k-step; az_conv_sp2.h)
+    auto load_frag = [&](auto PHC, const unsigned char* img, int rot, int nj, int s, int rs, int f) __attribute__((always_inline)) {
+        constexpr int PH = decltype(PHC)::value, BLK = PH ? MBLK : XBLK, PLANE = PH ? MPLANE : XPLANE;
+        const int tap = s / KSUB;
+        const int off = ((tap / 3) * G::PITCH + (tap % 3)) * 16 + (s % KSUB) * (4 * BLK);
+        const int pl = f / nj, j = f % nj;
+        bb[rs][pl][j] = *(const sp_f16x8*)(img + lm[rot][j].x + off + pl * PLANE);
+    };
+
     {   // first tile (upper half of the first board): all pieces at once, then the first lane-table registers and fragments
         const unsigned char* src = x + (size_t)slot * GBLOCK;
 #pragma unroll
@@ -487,10 +497,12 @@ k_resblock_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
                     CV_BARRIER();
                 }
                 if constexpr (t == 3) load_lm(NROT, ntile0, nnj);  // the next unit's lane-table registers
-                if constexpr (t + R - 1 < KS) load_step(CpInt<PH>{}, img, ROT, nj, t + R - 1, (t + R - 1) % R);
-                else if constexpr (!LAST) load_step(CpInt<PH>{}, img, NROT, nnj, t + R - 1 - KS, (t + R - 1) % R);
-                else if constexpr (PH == 1) load_step(CpInt<0>{}, Xs, NROT, nnj, t + R - 1 - KS, (t + R - 1) % R);  // next tile's phase A (behind the barrier)
-                // (last unit of phase A: the m image is complete only behind the barrier -- phase B's first fragments are read there)
+                // the fragments of k-step t + R - 1: of this unit, of the next unit, or (last unit of phase B) of the next tile's phase A (behind the
+                // barrier).  (Last unit of phase A: the m image is complete only behind the barrier -- phase B's first fragments are read there.)
+                constexpr bool lsame = t + R - 1 < KS, lhave = lsame || !LAST || PH == 1;
+                constexpr int lph = (!lsame && LAST) ? 0 : PH, lrot = lsame ? ROT : NROT, lnj = lsame ? nj : nnj;
+                constexpr int ls = lsame ? t + R - 1 : t + R - 1 - KS, lrs = (t + R - 1) % R;
+                const unsigned char* limg = (!lsame && LAST) ? Xs : img;
                 cp_for_each([&](auto QC) __attribute__((always_inline)) {
                     constexpr int q = decltype(QC)::value, j = q % nj, prod = q / nj;  // product 0: main, 1: w_hi x_lo, 2: w_lo x_hi
                     constexpr int fa = PH * NFC + (prod == 2 ? KS + t : t), pl = prod == 1 ? 1 : 0;
@@ -505,6 +517,12 @@ k_resblock_sp(const unsigned char* __restrict__ x, const _Float16* __restrict__ 
                         else sp_mfma_v(accc[set][j], wf[fa], bb[t % R][pl][j]);
                     }
                     constexpr int sl = t * NQ + q;  // MFMA slot of the unit
+                    if constexpr (lhave) {  // fragment q in gap q; a unit with fewer MFMAs per k-step than the next unit has fragments: the rest in its last gap
+                        cp_for_each([&](auto FC) __attribute__((always_inline)) {
+                            constexpr int f = decltype(FC)::value;
+                            if constexpr ((f < NQ ? f : NQ - 1) == q) load_frag(CpInt<lph>{}, limg, lrot, lnj, ls, lrs, f);
+                        }, typename CpMakeSeq<2 * lnj>::type{});
+                    }
                     if constexpr (RIDE) {
                         cp_for_each([&](auto KC) __attribute__((always_inline)) {
                             constexpr int o = SP::cum(sl - 1) + decltype(KC)::value;
