@@ -814,6 +814,10 @@ template <bool ADD> struct C1QSched {
     static_assert(vm_between(0, 1) < 63 && vm_between(1, 3) < 63 && vm_between(4, 5) < 63 && vm_after_addend(0, 0) < 63 && vm_after_addend(3, 1) < 63, "vmcnt field");
     static_assert(addend_use_slot(0) + 3 < store_slot(0) && addend_use_slot(1) + 3 < store_slot(1) && addend_use_slot(1) > store_slot(0), "an addend register is re-loaded after its last use");
 };
+// first MFMA of an accumulator that starts from zero: the C operand is the inline constant 0
+__device__ __forceinline__ void c1q_mfma_a0(cv_f32x16& acc, const cv_bf16x8& wa, const cv_bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "a"(wa), "v"(b));
+}
 #define C1Q_XB (4 * 3 * 2048)  // hand-over buffer: [destination wave][source 0..2][quad j][lane] 16 B
 
 template <bool ADD> __global__ void __launch_bounds__(CW_THREADS, 1)
@@ -919,7 +923,11 @@ k_conv3x3_op19q(const unsigned char* __restrict__ x, const unsigned short* __res
     cv_f32x16 acc[2][2];  // [accumulator set = unit parity][tile index]
     cv_u32x2 rr[2];
     f32x4 xr[2];
-    acc[0][0] = acc[1][0] = bias_ptr[0];
+    // A unit's accumulators start from the bias THROUGH THE C OPERAND of its first two MFMAs (tile 0: the bias registers below; tile 1 holds
+    // partner quads only: the inline constant 0) -- rounds 2-6 re-read 2 x 16 registers of bias from LDS per unit and wave (8 ds_read_b128 = 14 %
+    // of the kernel's LDS read traffic, issued as one burst)
+    const cv_f32x16 biasv = bias_ptr[0];
+    acc[0][0] = acc[1][0] = biasv;
     acc[0][1] = acc[1][1] = bias_ptr[1];
     rr[0] = rr[1] = (cv_u32x2){0u, 0u};
     xr[0] = xr[1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -994,7 +1002,10 @@ k_conv3x3_op19q(const unsigned char* __restrict__ x, const unsigned short* __res
                     if constexpr (ks + R - 1 < NKS) load_step(b0, ks + R - 1, (u * NKS + ks + R - 1) % R);
                     else load_step(nb0, ks + R - 1 - NKS, (u * NKS + ks + R - 1) % R);
                 }
-                if constexpr (tt * NKS + ks < 64) cw_mfma_a(acc[set][tt], wf[tt * NKS + ks], bb[(u * NKS + ks) % R]);
+                static_assert(NKS < 64, "the first fragments of both tiles are AGPR operands");
+                if constexpr (t == 0) cw_mfma_ac(acc[set][0], wf[0], bb[(u * NKS) % R], biasv);
+                else if constexpr (t == 1) c1q_mfma_a0(acc[set][1], wf[NKS], bb[(u * NKS) % R]);
+                else if constexpr (tt * NKS + ks < 64) cw_mfma_a(acc[set][tt], wf[tt * NKS + ks], bb[(u * NKS + ks) % R]);
                 else cw_mfma_v(acc[set][tt], wf[tt * NKS + ks], bb[(u * NKS + ks) % R]);
                 if constexpr (t >= SC::S0 && t < SC::S0 + 6) xwrite(pset, t - SC::S0);
                 if constexpr (ADD) {
@@ -1020,7 +1031,6 @@ k_conv3x3_op19q(const unsigned char* __restrict__ x, const unsigned short* __res
                     else if constexpr (u == 2) dma_piece(nsrc, has_next, 0, i);
                     else dma_piece(nsrc, has_next, 1, i);
                 }
-                if constexpr (t == NSTEP - 2) acc[pset][0] = bias_ptr[0], acc[pset][1] = bias_ptr[1];
                 __builtin_amdgcn_sched_barrier(0);
             }, typename CpMakeSeq<NSTEP>::type{});
         }, typename CpMakeSeq<NU>::type{});

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-box job script (replaces the per-call tools/gpu_r5[a-o].sh of round 5).
 #   gpurun --timeout 1500 -- 'bash tools/gpu_job.sh <job> [<job> ...]'      outputs under gpurun_out/r6/
-# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | rocprof_c2 | rocprof_c5 | rocprof_dropin | resblock_ab:<S> | prev_ab | chunk_probe | dropin_ab | spg_ab | soak | smoke
+# jobs: conv19_ab | tests | tests:<pytest -k expr> | bench | bench_c2 | bench_c5 | bench_12b64 | bench_c4 | probe_power | pmc:<family> | rocprof_bench | rocprof_c2 | rocprof_c5 | rocprof_dropin | resblock_ab:<S> | prev_ab | bench_ab | chunk_probe | dropin_ab | spg_ab | soak | smoke
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r6
 mkdir -p $O
@@ -41,6 +41,13 @@ for J in "$@"; do
     spg_ab) timeout 600 python tools/spg_ab.py 2>&1 | grep -v amdgpu.ids > $O/spg_ab.txt; echo "spg_ab rc=$?" | tee -a $O/status.txt; head -60 $O/spg_ab.txt ;;
     prev_ab) timeout 900 python tools/split_prev_ab.py 2>&1 | grep -v amdgpu.ids > $O/split_prev_ab.txt; echo "prev_ab rc=$?" | tee -a $O/status.txt; grep -v "  round" $O/split_prev_ab.txt ;;
     chunk_probe) timeout 900 python tools/chunk_major_probe.py 2>&1 | grep -v amdgpu.ids > $O/chunk_major_probe.txt; echo "chunk_probe rc=$?" | tee -a $O/status.txt; grep -v "  round" $O/chunk_major_probe.txt ;;
+    bench_ab) # the driver's workload (no companions) with the library of the tree and with tools/probes/libazsp_prev.so, alternating, on this box
+          cp alpha_zero_amd/libazsp.so /tmp/libazsp_tree.so
+          for R in 1 2; do for V in tree prev; do
+            if [ $V = prev ]; then cp tools/probes/libazsp_prev.so alpha_zero_amd/libazsp.so; else cp /tmp/libazsp_tree.so alpha_zero_amd/libazsp.so; fi
+            timeout 600 python bench.py --gpus 1 --steps 40 --warmup 5 ${BENCH_AB_ARGS:-} --no-companions --no-fresh-tree --no-cpu-baseline > $O/bench_ab_${V}_$R.json 2> $O/bench_ab.err; echo "bench_ab $V $R rc=$?" | tee -a $O/status.txt; summ $O/bench_ab_${V}_$R.json
+          done; done
+          cp /tmp/libazsp_tree.so alpha_zero_amd/libazsp.so ;;
     conv19_ab) timeout 600 python tools/conv19_ab.py > $O/conv19_ab.txt 2>&1; echo "conv19_ab rc=$?" | tee -a $O/status.txt; cat $O/conv19_ab.txt ;;
     *) echo "unknown job $J" ;;
   esac
