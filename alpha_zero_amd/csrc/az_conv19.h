@@ -990,7 +990,9 @@ k_conv3x3_op19q(const unsigned char* __restrict__ x, const unsigned short* __res
             const unsigned char* nb0 = Xw + (lmap[(u + 1) % NU] & 0xffffu);
             cp_for_each([&](auto TC) __attribute__((always_inline)) {
                 constexpr int t = decltype(TC)::value, ks = t >> 1, tt = t & 1;
+#ifndef C1Q_ABLATE_NO_F
                 if constexpr (t == SC::S0) CV_BARRIER();  // F: every wave is past the previous unit and its reads of the previous hand-over
+#endif
                 if constexpr (t == SB) {
                     if constexpr (u == 1 || u == 3 || u == 5) {
                         constexpr int N = u == 1 ? SC::vm_between(0, 1) : u == 3 ? SC::vm_between(1, 3) : SC::vm_between(4, 5);
