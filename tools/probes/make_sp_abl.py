@@ -24,7 +24,8 @@ def patch(text, variant, name):
 
     if variant in ("HALF_FRAG", "NO_FRAG"):
         cond = "(s & 1) == 0" if variant == "HALF_FRAG" else "false"
-        rep("        const int tap = s / KSUB;\n        const int off =", "        if (!(%s)) return;\n        const int tap = s / KSUB;\n        const int off =" % cond)
+        # (every occurrence: load_step of the prologue AND load_frag, the per-gap requests inside the units since the end of round 6)
+        rep("        const int tap = s / KSUB;\n        const int off =", "        if (!(%s)) return;\n        const int tap = s / KSUB;\n        const int off =" % cond, 0)
     elif variant == "NO_DMA":
         rep("        const unsigned long long mask = live ? dmask", "        live = false;\n        const unsigned long long mask = live ? dmask")
     elif variant.startswith("SPREAD"):  # the next tile's DMA pieces every STR-th k-step across the units instead of one per k-step in unit 0
