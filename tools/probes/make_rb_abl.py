@@ -32,16 +32,17 @@ def patch(text, variant):
             "#pragma unroll\n                for (int s = 0; s < R - 1; ++s) load_step(CpInt<1>{}, Ms, NROT, nnj, s, s);")
     elif variant == "NO_STORE":
         rep("if (store_ok) *(cv_u32x2*)(out + ooff)", "if (false) *(cv_u32x2*)(out + ooff)")
-        rep("} else if (store_ok) *(cv_u32x2*)(out + GPLANE + ooff)", "} else if (false) *(cv_u32x2*)(out + GPLANE + ooff)")
-        rep("                        rr[set][rj][rp] = *(const cv_u32x2*)", "                        if (false) rr[set][rj][rp] = *(const cv_u32x2*)")
+        rep("} else if (store_ok) *(__attribute__((address_space(1))) cv_u32x2*)(out_lo + ooff)", "} else if (false) *(__attribute__((address_space(1))) cv_u32x2*)(out_lo + ooff)")
+        rep("                        else rr[set][rj][rp] = *(const cv_u32x2*)(Xs + (lm[ROT][rj].x + skc)", "                        else if (false) rr[set][rj][rp] = *(const cv_u32x2*)(Xs + (lm[ROT][rj].x + skc)")
+        rep("                        rrx[rj][rp] = *(const cv_u32x2*)", "                        if (false) rrx[rj][rp] = *(const cv_u32x2*)")
     elif variant == "NO_MWRITE":
         rep("if (o == 2 * PAIR) *(cv_u32x2*)(Mw + ooff) = (cv_u32x2){hpk[0], hpk[1]};", "if (false) *(cv_u32x2*)(Mw + ooff) = (cv_u32x2){hpk[0], hpk[1]};")
         rep("else *(cv_u32x2*)(Mw + MPLANE + ooff) = (cv_u32x2){lpk[0], lpk[1]};", "else if (false) *(cv_u32x2*)(Mw + MPLANE + ooff) = (cv_u32x2){lpk[0], lpk[1]};")
     elif variant == "NO_FRAG":
-        rep("        const int tap = s / KSUB;\n        const int off =", "        if (it > 0) return;\n        const int tap = s / KSUB;\n        const int off =")
+        rep("        const int tap = s / KSUB;\n        const int off =", "        if (it > 0) return;\n        const int tap = s / KSUB;\n        const int off =", 0)  # load_step AND load_frag
     elif variant == "NO_EXPOSED":
-        rep("                    for (int o = 0; o < CTM; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, o, true);",
-            "                    for (int o = 0; o < 0; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, o, true);")
+        rep("                    for (int o = 0; o < CTM; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, (sb17_gptr)0, o, true);",
+            "                    for (int o = 0; o < 0; ++o) epi_op(CpInt<0>{}, set, j, lm[ROT][j].y, nullptr, (sb17_gptr)0, o, true);")
     elif variant.startswith("DMA_Q"):  # NOT an ablation: the next tile's DMA piece of a k-step is issued behind MFMA slot Q instead of behind the last
         q = int(variant[5:])
         rep("                if constexpr (PH == 1 && FIRST && t >= 1 && t - 1 < NPIECE) {\n", "                if constexpr (false) {\n")
