@@ -21,6 +21,9 @@
 
 #if defined(__HIPCC__)
 #define SP2_NB 13  // boards per corner batch
+// 1 (the product): fragment f of a k-step is requested in the MFMA gap behind MFMA f of the k-step before; 0 (-DSP2_SPREAD_FRAGS=0, for
+// same-box A/B builds): rounds 3-6's burst of all 2 nj ds_read_b128 in front of a k-step.  Same arithmetic either way (bit-identical);
+// the burst costs 3.8 % / 3.2 % of a launch (profiles/r06_spread_frags_ab.txt): with one wave per SIMD nothing issues MFMAs meanwhile.
 #ifndef SP2_SPREAD_FRAGS
 #define SP2_SPREAD_FRAGS 1
 #endif
